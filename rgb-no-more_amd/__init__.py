@@ -1,0 +1,8 @@
+"""rgb-no-more_amd: MI355X-native (gfx950) hot path of RGB-no-more -- DCT-domain augment + JPEG-ViT
+forward/backward as hand-written HIP kernels behind a C-ABI library (include/rgbnm.h).
+
+Host-side modules mirror the reference's operator surface for this path:
+  dct_manip (read_coefficients), dct_ops / custom_transforms (DCT-domain augment),
+  plainvit (ViT), cls_transforms (RandomMixup_DCT), custom_optims (WeightDecay, fused AdamW).
+"""
+from . import detfill  # noqa: F401
