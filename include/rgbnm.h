@@ -1,0 +1,213 @@
+/* rgbnm.h -- C ABI of librgbnm.so: the MI355X (gfx950) hot path of RGB-no-more.
+ *
+ * Drop-in boundary.  The reference has no native FFI for this path except
+ * dct_manip (pybind11); everything else is PyTorch ops reached from Python, so the binding a maintainer
+ * adds is a ctypes stub.  Each entry point below names the reference code it
+ * replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain pointers + sizes; device pointers unless the name says host; no C++/torch types.
+ *   - returns 0 on success, negative RGBNM_E* otherwise; never throws; never allocates device memory;
+ *     keeps no per-call state; all work is enqueued on `stream` (a hipStream_t passed as void*), no sync.
+ *   - dtype: 0 = fp32 ("strict" mode, exact-fp32 MFMA), 1 = bf16 (fp32 accumulate).  Activations and
+ *     MFMA operands use that type; parameters, gradients, statistics and optimizer state are fp32.
+ *   - tensors are dense row-major; "ld*" are row strides in elements.
+ */
+#ifndef RGBNM_H
+#define RGBNM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBNM_ABI_VERSION 1
+#define RGBNM_DT_F32 0
+#define RGBNM_DT_BF16 1
+
+/* epilogues of rgbnm_gemm_nt */
+#define RGBNM_EPI_NONE 0   /* C = A.W^T (+bias)                                         */
+#define RGBNM_EPI_RES 1    /* C = A.W^T + bias + R            (ResidualAdd, plainvit.py:475-479)       */
+#define RGBNM_EPI_GELU 2   /* C2 = u = A.W^T + bias ; C = gelu_erf(u)   (FeedForwardBlock :487-488)    */
+#define RGBNM_EPI_POS 3    /* C = A.W^T + bias + pos[row % period]      (SinCosEmbedding :97-121)      */
+#define RGBNM_EPI_DGELU 4  /* C = (A.W^T) * gelu'(R)                                              */
+#define RGBNM_EPI_TANH 5   /* C = tanh(A.W^T + bias)                    (ClassificationHead :553-554)  */
+#define RGBNM_EPI_DTANH 6  /* C = (A.W^T) * (1 - R^2)                                             */
+
+int rgbnm_abi_version(void);
+/* human readable text for a negative return code */
+const char* rgbnm_strerror(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMMs (replace nn.Linear forward/backward: plainvit.py:195,441,443,487,490,553,555)
+ * ------------------------------------------------------------------------------------------- */
+/* C[M,N] = epi(A[M,K] . W[N,K]^T).  bias fp32 [N] or NULL.  R/C2/pos as required by `epi`.
+ * c_f32 != 0 stores C as fp32 regardless of dtype (logits). */
+int rgbnm_gemm_nt(int dtype, int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+                  const float* bias, const void* R, int ldr, void* C2, int ldc2, const float* pos, int pos_period,
+                  int M, int N, int K, int c_f32, void* stream);
+
+/* dW[No,Ki] (fp32) = dY[M,No]^T . X[M,Ki]; db[No] = column sums of dY (db may be NULL).
+ * perm_heads > 0: rows of dW/db are written in the reference's interleaved '(h d qkv)' order
+ * (plainvit.py:447) although dY's columns are [q|k|v] blocks.  accumulate != 0: += into dW/db. */
+size_t rgbnm_gemm_tn_workspace(int M, int No, int Ki);
+int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int No,
+                  int Ki, int perm_heads, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One nn.Linear in the flat fp32 master buffer and where its shadows go (offsets in elements). */
+typedef struct rgbnm_linear_desc {
+  long long w_off;     /* master: weight [N,K] fp32                                   */
+  long long b_off;     /* master: bias [N] fp32                                       */
+  long long ws_off;    /* shadow: [N,K] in dtype (rows de-interleaved if perm_heads)  */
+  long long wst_off;   /* shadow: [K,N] in dtype (transpose of the above)             */
+  long long bperm_off; /* bias_perm: [N] fp32 de-interleaved bias (only if perm_heads) */
+  int N, K;
+  int perm_heads;      /* >0 for the qkv Linear: number of heads                      */
+  int _pad;
+} rgbnm_linear_desc;
+
+/* master fp32 -> per-step operand shadows for every Linear (descs_dev: device array of ndesc descriptors). */
+int rgbnm_prep_weights(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
+                       float* bias_perm, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm (nn.LayerNorm(emb), plainvit.py:513,522,551) and head pooling (:551-552)
+ * ------------------------------------------------------------------------------------------- */
+int rgbnm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int M, int E, float eps, void* stream);
+size_t rgbnm_layernorm_bwd_workspace(int M, int E);
+/* dx = [dres +] LN'(dy); dgamma/dbeta fp32.  dres may be NULL. */
+int rgbnm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int M, int E,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* pooled[b,:] = mean_t LN(x[b,t,:]) */
+int rgbnm_head_pool_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* pooled, float* mean,
+                        float* rstd, int B, int N, int E, float eps, void* stream);
+int rgbnm_head_pool_bwd(int dtype, const void* dpooled, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, float* dgamma, float* dbeta, int B, int N, int E, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention (MultiHeadAttention.forward, plainvit.py:445-464): qkv [B*N, 3*heads*64] as [q|k|v] column
+ * blocks, out [B*N, heads*64] ('b n (h d)'), lse [B*heads*N] fp32.  scale = 1/sqrt(emb_size) (!).
+ * ------------------------------------------------------------------------------------------- */
+int rgbnm_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int heads, float scale,
+                        void* stream);
+int rgbnm_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                        int B, int N, int heads, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sub-block reshuffle (patch2rearrange + apply_subblock + collapser + cat, plainvit.py:71-88,50-69,192,
+ * 200-216) for patch_size 16: y [B,1,Hb,Wb,8,8], cbcr [B,2,Hb/2,Wb/2,8,8] -> feat [B*(Hb/2)*(Wb/2), 384].
+ * conv16: the 16x16 fp32 conversion matrix A (dct_ops.py:180-208).
+ * ------------------------------------------------------------------------------------------- */
+int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* conv16,
+                         void* feat, int B, int Hb, int Wb, int transpose_a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Train-step tail
+ * ------------------------------------------------------------------------------------------- */
+/* CrossEntropyLoss (pipeline_utils.py:535) with soft [B,C] fp32 or hard int64 [B] targets (exactly one non-NULL).
+ * loss[0] = mean over rows; dlogits (dtype dl_dtype, may be NULL) = d loss / d logits * grad_scale*B... see .hip:
+ * dlogits = (softmax*sum(t) - t) * grad_scale, pass grad_scale = 1/B for the mean reduction. */
+int rgbnm_softxent(int dl_dtype, const float* logits, const float* soft_target, const long long* hard_target,
+                   float* loss_rows, float* loss, void* dlogits, int B, int C, float grad_scale, void* stream);
+/* RandomMixup_DCT (cls_transforms.py:163-176): out[b] = lam[0]*in[b] + lam[1]*in[b-1]; lam on device. */
+int rgbnm_mixup(int in_dtype, int out_dtype, const void* in, void* out, const float* lam_dev, int B,
+                long long per_sample, void* stream);
+int rgbnm_mixup_target(const long long* labels, float* target, const float* lam_dev, int B, int C, void* stream);
+/* clip_grad_norm_(max_norm) + AdamW(weight_decay=0) + WeightDecay (train.py:163-165; custom_optims.py:37-42)
+ * over flat fp32 buffers of n elements (n % 256 == 0; every tensor starts on a 256-element boundary);
+ * wd_flag_per_256[i] != 0 marks chunks that belong to a decayed tensor; wd_factor = (lr/base_lr)*wd.
+ * step = 1-based Adam step.  norm_out (may be NULL) receives the pre-clip global norm. max_norm<=0: no clip. */
+size_t rgbnm_clip_adamw_wd_workspace(void);
+int rgbnm_clip_adamw_wd_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_flag_per_256,
+                             long long n, float lr, float beta1, float beta2, float eps, int step, float wd_factor,
+                             float max_norm, float* norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Composite stages: one call per autograd node (ViT, plainvit.py:559-611)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rgbnm_vit_cfg {
+  int dtype, B, N, E, heads;
+  float ln_eps, attn_scale;
+} rgbnm_vit_cfg;
+
+typedef struct rgbnm_block_params {      /* TransformerEncoderBlock, plainvit.py:493-529 */
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const float *bqkv_perm, *bproj, *b1, *b2;
+  const void *wqkv, *wqkv_t, *wproj, *wproj_t, *w1, *w1_t, *w2, *w2_t;
+} rgbnm_block_params;
+
+typedef struct rgbnm_block_acts {        /* saved for backward; caller-owned */
+  void* x_in;   /* [M,E]   block input (residual stream)   */
+  void* xn1;    /* [M,E]   LN1 output                      */
+  float *mean1, *rstd1;
+  void* qkv;    /* [M,3I]  q|k|v                           */
+  float* lse;   /* [B*heads*N]                             */
+  void* attn;   /* [M,I]   merged heads, pre-projection    */
+  void* x_mid;  /* [M,E]   after attention residual        */
+  void* xn2;    /* [M,E]                                   */
+  float *mean2, *rstd2;
+  void* u;      /* [M,4E]  fc1 pre-activation              */
+  void* gl;     /* [M,4E]  gelu(u)                         */
+  void* x_out;  /* [M,E]                                   */
+} rgbnm_block_acts;
+
+typedef struct rgbnm_block_grads {       /* fp32, reference layouts */
+  float *dln1_g, *dln1_b, *dln2_g, *dln2_b;
+  float *dwqkv, *dbqkv, *dwproj, *dbproj, *dw1, *db1, *dw2, *db2;
+} rgbnm_block_grads;
+
+typedef struct rgbnm_block_scratch {     /* backward temporaries, caller-owned, reusable across blocks */
+  void* du;      /* [M,4E] */
+  void* dxn;     /* [M,E]  */
+  void* dx_mid;  /* [M,E]  */
+  void* dattn;   /* [M,I]  */
+  void* dqkv;    /* [M,3I] */
+  void* ws;      /* generic workspace */
+  size_t ws_bytes;
+} rgbnm_block_scratch;
+
+size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* cfg);
+int rgbnm_vit_block_fwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, const rgbnm_block_acts* a,
+                        void* stream);
+/* dy = grad wrt x_out, dx = grad wrt x_in (dx may alias dy). */
+int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, const rgbnm_block_acts* a,
+                        const rgbnm_block_grads* g, const rgbnm_block_scratch* s, const void* dy, void* dx,
+                        void* stream);
+
+/* PatchEmbedding_DCT_Group (plainvit.py:157-218): feat = subblock(y,cbcr); x0 = feat.Wpe^T + b + sincos */
+int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* cfg, int in_dtype, const void* y, const void* cbcr,
+                          const float* conv16, const void* wpe, const float* bpe, const float* pos, void* feat,
+                          void* x0, int Hb, int Wb, void* stream);
+int rgbnm_patch_embed_bwd(const rgbnm_vit_cfg* cfg, const void* dx0, const void* feat, float* dwpe, float* dbpe,
+                          void* ws, size_t ws_bytes, void* stream);
+
+typedef struct rgbnm_head_params {       /* ClassificationHead, plainvit.py:542-557 */
+  const float *ln_g, *ln_b, *b1, *b2;
+  const void *w1, *w1_t, *w2, *w2_t;
+  int n_classes;
+  int _pad;
+} rgbnm_head_params;
+typedef struct rgbnm_head_acts {
+  void* x;        /* [M,E] encoder output */
+  float *mean, *rstd;
+  void* pooled;   /* [B,E] */
+  void* h1;       /* [B,E] tanh output */
+  float* logits;  /* [B,C] fp32 */
+} rgbnm_head_acts;
+typedef struct rgbnm_head_grads {
+  float *dln_g, *dln_b, *dw1, *db1, *dw2, *db2;
+} rgbnm_head_grads;
+int rgbnm_head_fwd(const rgbnm_vit_cfg* cfg, const rgbnm_head_params* p, const rgbnm_head_acts* a, void* stream);
+/* dlogits [B,C] in cfg->dtype; da, dpooled: [B,E] scratch; dx [M,E] out. */
+int rgbnm_head_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_head_params* p, const rgbnm_head_acts* a,
+                   const rgbnm_head_grads* g, const void* dlogits, void* da, void* dpooled, void* dx, void* ws,
+                   size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBNM_H */

@@ -6,3 +6,5 @@ Host-side modules mirror the reference's operator surface for this path:
   plainvit (ViT), cls_transforms (RandomMixup_DCT), custom_optims (WeightDecay, fused AdamW).
 """
 from . import detfill  # noqa: F401
+from . import lib, dct_ops, plainvit, cls_transforms, custom_optims  # noqa: F401,E402
+from .plainvit import ViT  # noqa: F401,E402

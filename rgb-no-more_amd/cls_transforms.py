@@ -1,0 +1,80 @@
+"""Mirror of the reference `utils/cls_transforms.py::RandomMixup_DCT` (:100-193) on device tensors, plus the
+soft-label cross entropy used on its output (pipeline_utils.py:535)."""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from . import lib as L
+
+
+class RandomMixup_DCT(torch.nn.Module):
+    """Roll-by-one batch mixup of (Y, CbCr) and labels; lambda ~ Dirichlet(alpha, alpha) sorted descending
+    (cls_transforms.py:135-182).  lambda stays on the device: no host sync in the step."""
+
+    def __init__(self, num_classes: int, alpha: float = 1.0, inplace: bool = False) -> None:
+        super().__init__()
+        if num_classes < 1:
+            raise ValueError(f"Please provide a valid positive value for the num_classes. Got num_classes={num_classes}")
+        if alpha <= 0:
+            raise ValueError("Alpha param can't be zero.")
+        self.num_classes, self.alpha, self.inplace = num_classes, alpha, inplace
+        self.out_dtype = None   # None: keep the input dtype
+
+    def sample_lambda(self, device):
+        lam, _ = torch._sample_dirichlet(torch.tensor([self.alpha, self.alpha], device=device)).sort(descending=True)
+        return lam.to(torch.float32).contiguous()
+
+    def forward(self, batch, target: Tensor, lam: Tensor = None) -> Tuple[Tensor, Tensor]:
+        if target.ndim != 1:
+            raise ValueError(f"Target ndim should be 1. Got {target.ndim}")
+        if target.dtype != torch.int64:
+            raise TypeError(f"Target dtype should be torch.int64. Got {target.dtype}")
+        single = not isinstance(batch, (tuple, list))
+        items = [batch] if single else list(batch)
+        L.require_cuda(*items, target)
+        if lam is None:
+            lam = self.sample_lambda(target.device)
+        outs = []
+        for t in items:
+            od = self.out_dtype or t.dtype
+            o = torch.empty(t.shape, device=t.device, dtype=od)
+            B = t.shape[0]
+            L.check(L.lib().rgbnm_mixup(L.dt_of(t.dtype), L.dt_of(od), t.data_ptr(), o.data_ptr(), lam.data_ptr(), B,
+                                        t.numel() // B, L.stream()), "mixup")
+            outs.append(o)
+        tgt = torch.empty(target.shape[0], self.num_classes, device=target.device, dtype=torch.float32)
+        L.check(L.lib().rgbnm_mixup_target(target.data_ptr(), tgt.data_ptr(), lam.data_ptr(), target.shape[0],
+                                           self.num_classes, L.stream()), "mixup_target")
+        return (outs[0] if single else tuple(outs)), tgt
+
+
+class _SoftXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, dl_dtype):
+        B, Cn = logits.shape
+        hard = target.dtype == torch.int64
+        rows = torch.empty(B, device=logits.device, dtype=torch.float32)
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+        dl = torch.empty(B, Cn, device=logits.device, dtype=dl_dtype)
+        L.check(L.lib().rgbnm_softxent(L.dt_of(dl_dtype), logits.data_ptr(), None if hard else target.data_ptr(),
+                                       target.data_ptr() if hard else None, rows.data_ptr(), loss.data_ptr(),
+                                       dl.data_ptr(), B, Cn, 1.0 / B, L.stream()), "softxent")
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dl,) = ctx.saved_tensors
+        return dl * gout.to(dl.dtype), None, None
+
+
+def cross_entropy(logits: Tensor, target: Tensor, grad_dtype=torch.float32) -> Tensor:
+    """torch.nn.CrossEntropyLoss()(logits, target) for class-index (int64 [B]) or probability ([B,C] fp32)
+    targets, mean reduction; loss and dlogits come from one HIP kernel."""
+    L.require_cuda(logits, target)
+    if logits.dtype != torch.float32:
+        logits = logits.float()
+    if target.dtype != torch.int64:
+        target = target.float().contiguous()
+    return _SoftXent.apply(logits.contiguous(), target, grad_dtype)

@@ -1,0 +1,105 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of rgb-no-more_amd.
+// Written for MI355X only: no portability layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RGBNM_OK 0
+#define RGBNM_EINVAL (-1)
+#define RGBNM_ELAUNCH (-2)
+#define RGBNM_EWORKSPACE (-3)
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+#define LAUNCH_CHECK()                                  \
+  do {                                                  \
+    hipError_t e__ = hipGetLastError();                 \
+    if (e__ != hipSuccess) return RGBNM_ELAUNCH;        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// MFMA operand fragments.  One fragment = 16 bytes per lane = EPL elements of T along the reduction
+// axis.  Lane l supplies row/col (l & 31) and reduction slots [g*EPL, (g+1)*EPL) of a 32-byte chunk,
+// g = l >> 5.  `mma` computes acc[i][n] += sum over both lane groups and all slots of A*B; because A and
+// B fragments are always built with the same slot<->index assignment, any consistent assignment is
+// valid (the dot product is permutation invariant) -- kernels exploit this (see attention.hip).
+// C/D layout of every 32x32 MFMA on gfx950: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+  bf16x8 v;
+  static constexpr int EPL = 8;
+};
+template <> struct Frag<float> {
+  f32x4 v;
+  static constexpr int EPL = 4;
+};
+
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// row index inside a 32x32 accumulator tile held by this lane in register r
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <typename T> __device__ __forceinline__ Frag<T> load_frag(const T* p);  // 16-byte aligned
+template <> __device__ __forceinline__ Frag<bf16> load_frag<bf16>(const bf16* p) {
+  Frag<bf16> f;
+  f.v = *reinterpret_cast<const bf16x8*>(p);
+  return f;
+}
+template <> __device__ __forceinline__ Frag<float> load_frag<float>(const float* p) {
+  Frag<float> f;
+  f.v = *reinterpret_cast<const f32x4*>(p);
+  return f;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+// 4 consecutive elements <-> 4 floats (8-byte / 16-byte accesses)
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16> { typedef bf16x4 type; };
+template <> struct Vec4<float> { typedef f32x4 type; };
+
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p) {
+  typename Vec4<T>::type v = *reinterpret_cast<const typename Vec4<T>::type*>(p);
+  f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return o;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v) {
+  typename Vec4<T>::type o;
+  o[0] = (T)v[0]; o[1] = (T)v[1]; o[2] = (T)v[2]; o[3] = (T)v[3];
+  *reinterpret_cast<typename Vec4<T>::type*>(p) = o;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }

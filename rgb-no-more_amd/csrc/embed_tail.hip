@@ -1,0 +1,297 @@
+// Entry and exit of the train step around the encoder (HBM / launch bound, no MFMA):
+//   subblock_embed : 2x2 8x8 luma DCT blocks -> one 16x16 DCT block (A.X.A^T) + Cb|Cr concat, the
+//                    "sub-block reshuffle" (models/plainvit.py:71-88,50-69,192,200-216)
+//   softxent       : soft- or hard-label cross entropy, loss + dlogits (pipeline_utils.py:535)
+//   mixup          : roll-by-one batch mixup of (Y, CbCr) and labels (utils/cls_transforms.py:163-176)
+//   clip_adamw_wd  : global-norm clip + AdamW(wd=0) + schedule-relative WeightDecay in one pass over flat
+//                    fp32 buffers (train.py:163-165, utils/custom_optims.py:37-42)
+#include "common.h"
+#include "../../include/rgbnm.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// One wave per 16x16 patch.  X is gathered block-major ('(pdh p1) (pdw p2)', plainvit.py:83):
+// X[8*pdh + p1][8*pdw + p2] = y[b,0,2*ph+pdh,2*pw+pdw,p1,p2].  Output row layout 'b h w (c i j)':
+// [0,256) = Z row-major, [256,320) = Cb, [320,384) = Cr.
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void subblock_embed_kernel(const TI* __restrict__ y, const TI* __restrict__ cbcr,
+                                                             const float* __restrict__ A, T* __restrict__ feat,
+                                                             int B, int Hb, int Wb, int transpose_a) {
+  __shared__ float As[16][17];
+  __shared__ float Xs[4][16][17];
+  __shared__ float Ts[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  {
+    const int i = tid >> 4, j = tid & 15;
+    As[i][j] = transpose_a ? A[j * 16 + i] : A[i * 16 + j];
+  }
+  const int ph_n = Hb / 2, pw_n = Wb / 2;
+  const long long npatch = (long long)B * ph_n * pw_n;
+  const long long patch = (long long)blockIdx.x * 4 + w;
+  const bool valid = patch < npatch;
+  int b = 0, ph = 0, pw = 0;
+  if (valid) {
+    b = (int)(patch / (ph_n * pw_n));
+    const int rem = (int)(patch % (ph_n * pw_n));
+    ph = rem / pw_n;
+    pw = rem % pw_n;
+    const int pdh = lane >> 5, pdw = (lane >> 4) & 1, l16 = lane & 15;
+    const TI* src = y + ((((size_t)b * Hb + 2 * ph + pdh) * Wb) + 2 * pw + pdw) * 64 + l16 * 4;
+    const f32x4 v = load4<TI>(src);
+    const int p1 = l16 >> 1, p2 = (l16 & 1) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Xs[w][8 * pdh + p1][8 * pdw + p2 + e] = v[e];
+  }
+  __syncthreads();
+  const int i = lane >> 2, j0 = (lane & 3) * 4;
+  if (valid) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const float a = As[i][o];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = fmaf(a, Xs[w][o][j0 + e], t[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Ts[w][i][j0 + e] = t[e];
+  }
+  __syncthreads();
+  if (valid) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const float tv = Ts[w][i][o];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = fmaf(tv, As[j0 + e][o], z[e]);
+    }
+    T* dst = feat + (size_t)patch * 384;
+    store4<T>(dst + i * 16 + j0, z);
+    // chroma: 128 values, 2 per lane (identity sub-block conversion for 8x8 chroma patches)
+    const int e0 = lane * 2, c = e0 >> 6, k = e0 & 63;
+    const TI* cs = cbcr + ((((size_t)b * 2 + c) * ph_n + ph) * pw_n + pw) * 64 + k;
+    dst[256 + e0] = from_f32<T>(to_f32(cs[0]));
+    dst[256 + e0 + 1] = from_f32<T>(to_f32(cs[1]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softxent_kernel(const float* __restrict__ logits, const float* __restrict__ soft,
+                                                       const long long* __restrict__ hard, float* __restrict__ loss_rows,
+                                                       T* __restrict__ dlogits, int C, float gscale) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* z = logits + (size_t)b * C;
+  const long long lab = hard ? hard[b] : -1;
+  float m = -INFINITY;
+  for (int c = tid; c < C; c += 256) m = fmaxf(m, z[c]);
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f, st = 0.f, stz = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+    se += __expf(z[c] - m);
+    st += t;
+    stz += t * z[c];
+  }
+  float vals[3] = {se, st, stz};
+  for (int k = 0; k < 3; ++k) {
+    const float v = wave_sum(vals[k]);
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    vals[k] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+  const float lse = m + __logf(vals[0]);
+  if (tid == 0) loss_rows[b] = lse * vals[1] - vals[2];
+  if (dlogits) {
+    for (int c = tid; c < C; c += 256) {
+      const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+      dlogits[(size_t)b * C + c] = from_f32<T>((__expf(z[c] - lse) * vals[1] - t) * gscale);
+    }
+  }
+}
+
+__global__ void mean_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += x[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b] = lam[0]*in[b] + lam[1]*in[(b-1) mod B]   (torch.roll(1, 0)); lam lives on the device (no sync)
+template <typename TI, typename TO>
+__global__ void mixup_kernel(const TI* __restrict__ in, TO* __restrict__ out, const float* __restrict__ lam, int B,
+                             long long per) {
+  const float l0 = lam[0], l1 = lam[1];
+  const long long n = (long long)B * per;
+  for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4; i < n;
+       i += (long long)gridDim.x * blockDim.x * 4) {
+    const long long b = i / per, r = i % per;
+    const long long pb = (b + B - 1) % B;
+    const f32x4 a = load4<TI>(in + i), c = load4<TI>(in + pb * per + r);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e] * l0 + c[e] * l1;
+    store4<TO>(out + i, o);
+  }
+}
+
+__global__ void mixup_target_kernel(const long long* __restrict__ lab, float* __restrict__ tgt,
+                                    const float* __restrict__ lam, int B, int C) {
+  const float l0 = lam[0], l1 = lam[1];
+  const long long n = (long long)B * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / C), c = (int)(i % C);
+    const int pb = (b + B - 1) % B;
+    tgt[i] = (lab[b] == c ? l0 : 0.f) + (lab[pb] == c ? l1 : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int NORM_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (long long i = (blockIdx.x * 256LL + threadIdx.x) * 4; i < n; i += (long long)NORM_BLOCKS * 256 * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);   // n is a multiple of 256 (padded segments)
+    a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; const unsigned char* wd_flag; const float* part; float* norm_out;
+  long long n;
+  float lr, beta1, beta2, eps, bc1, bc2_sqrt, wd_factor, max_norm;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  __shared__ float red[4];
+  __shared__ float coef_s;
+  {
+    float t = a.part[threadIdx.x];   // NORM_BLOCKS == blockDim.x
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float total = sqrtf(red[0] + red[1] + red[2] + red[3]);
+      float c = a.max_norm > 0.f ? a.max_norm / (total + 1e-6f) : 1.f;
+      coef_s = c < 1.f ? c : 1.f;
+      if (blockIdx.x == 0 && a.norm_out) a.norm_out[0] = total;
+    }
+    __syncthreads();
+  }
+  const float coef = coef_s;
+  const float step = a.lr / a.bc1;
+  for (long long chunk = blockIdx.x; chunk * 256 < a.n; chunk += gridDim.x) {
+    const long long i = chunk * 256 + threadIdx.x;
+    const float g = a.g[i] * coef;
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    float p = a.p[i];
+    p -= step * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+    if (a.wd_flag[chunk]) p -= a.wd_factor * p;
+    a.p[i] = p;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* conv16,
+                         void* feat, int B, int Hb, int Wb, int transpose_a, void* stream) {
+  if (!y || !cbcr || !conv16 || !feat || B <= 0 || Hb <= 0 || Wb <= 0 || (Hb & 1) || (Wb & 1)) return RGBNM_EINVAL;
+  const long long npatch = (long long)B * (Hb / 2) * (Wb / 2);
+  const dim3 grid((unsigned)cdivl(npatch, 4)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define SB(TI, TO) hipLaunchKernelGGL((subblock_embed_kernel<TI, TO>), grid, blk, 0, st, (const TI*)y, (const TI*)cbcr, conv16, (TO*)feat, B, Hb, Wb, transpose_a)
+  if (in_dtype == DT_F32 && out_dtype == DT_F32) SB(float, float);
+  else if (in_dtype == DT_F32 && out_dtype == DT_BF16) SB(float, bf16);
+  else if (in_dtype == DT_BF16 && out_dtype == DT_BF16) SB(bf16, bf16);
+  else if (in_dtype == DT_BF16 && out_dtype == DT_F32) SB(bf16, float);
+  else return RGBNM_EINVAL;
+#undef SB
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_softxent(int dl_dtype, const float* logits, const float* soft_target, const long long* hard_target,
+                   float* loss_rows, float* loss, void* dlogits, int B, int C, float grad_scale, void* stream) {
+  if (!logits || (!soft_target && !hard_target) || !loss_rows || !loss || B <= 0 || C <= 0) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dl_dtype == DT_BF16)
+    hipLaunchKernelGGL((softxent_kernel<bf16>), dim3(B), dim3(256), 0, st, logits, soft_target, hard_target, loss_rows, (bf16*)dlogits, C, grad_scale);
+  else if (dl_dtype == DT_F32)
+    hipLaunchKernelGGL((softxent_kernel<float>), dim3(B), dim3(256), 0, st, logits, soft_target, hard_target, loss_rows, (float*)dlogits, C, grad_scale);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, loss_rows, loss, B);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_mixup(int in_dtype, int out_dtype, const void* in, void* out, const float* lam_dev, int B,
+                long long per_sample, void* stream) {
+  if (!in || !out || !lam_dev || B <= 0 || per_sample <= 0 || (per_sample & 3)) return RGBNM_EINVAL;
+  const long long n = (long long)B * per_sample;
+  const dim3 grid((unsigned)min(4096LL, cdivl(n, 1024))), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define MX(TI, TO) hipLaunchKernelGGL((mixup_kernel<TI, TO>), grid, blk, 0, st, (const TI*)in, (TO*)out, lam_dev, B, per_sample)
+  if (in_dtype == DT_F32 && out_dtype == DT_F32) MX(float, float);
+  else if (in_dtype == DT_F32 && out_dtype == DT_BF16) MX(float, bf16);
+  else if (in_dtype == DT_BF16 && out_dtype == DT_BF16) MX(bf16, bf16);
+  else return RGBNM_EINVAL;
+#undef MX
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_mixup_target(const long long* labels, float* target, const float* lam_dev, int B, int C, void* stream) {
+  if (!labels || !target || !lam_dev || B <= 0 || C <= 0) return RGBNM_EINVAL;
+  hipLaunchKernelGGL(mixup_target_kernel, dim3((unsigned)min(2048LL, cdivl((long long)B * C, 256))), dim3(256), 0,
+                     (hipStream_t)stream, labels, target, lam_dev, B, C);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+size_t rgbnm_clip_adamw_wd_workspace(void) { return NORM_BLOCKS * sizeof(float); }
+
+int rgbnm_clip_adamw_wd_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_flag_per_256,
+                             long long n, float lr, float beta1, float beta2, float eps, int step, float wd_factor,
+                             float max_norm, float* norm_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!p || !g || !m || !v || !wd_flag_per_256 || !workspace || n <= 0 || (n & 255) || step < 1) return RGBNM_EINVAL;
+  if (workspace_bytes < NORM_BLOCKS * sizeof(float)) return RGBNM_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, g, n, part);
+  LAUNCH_CHECK();
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.wd_flag = wd_flag_per_256; a.part = part; a.norm_out = norm_out; a.n = n;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.wd_factor = wd_factor; a.max_norm = max_norm;
+  const int grid = (int)min(4096LL, n / 256);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, a);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+// GEMM family for the JPEG-ViT hot path (all Linear layers, forward and backward) on gfx950.
+//
+//   gemm_nt : C[M,N] = epi( A[M,K] . W[N,K]^T )            forward Linear (reference nn.Linear layout
+//                                                          (out,in), plainvit.py:195,441,443,487,490,553,555)
+//                                                          and dX = dY . W via the transposed weight shadow.
+//   gemm_tn : dW[No,Ki] = dY[M,No]^T . X[M,Ki]  (+ db)     weight gradients; split over tokens, fp32
+//                                                          partials + deterministic reduce.
+//   prep_weights : fp32 master -> T shadow [N,K] (rows optionally de-interleaved for qkv) and [K,N].
+//
+// Tiles are 128 x (64*NB) with four waves in a 2x2 grid; each wave owns 64 x (32*NB) as 32x32 MFMA
+// tiles (v_mfma_f32_32x32x16_bf16, or 4x v_mfma_f32_32x32x2_f32 in strict fp32 mode).  LDS rows are
+// 128 B of the reduction axis + 16 B pad (144 B pitch): ds_read_b128 of 32 rows at one k-offset is
+// bank-conflict free (9*i mod 16 distinct).
+#include "common.h"
+#include "../../include/rgbnm.h"
+
+namespace {
+
+enum { EPI_NONE = 0, EPI_RES = 1, EPI_GELU = 2, EPI_POS = 3, EPI_DGELU = 4, EPI_TANH = 5, EPI_DTANH = 6 };
+
+struct GemmNT {
+  const void* A; const void* W; void* C; const float* bias; const void* R; void* C2; const float* pos;
+  int lda, ldw, ldc, ldr, ldc2, pos_period;
+  int M, N, K;
+  int c_f32;
+  int mtiles, ntiles;
+};
+
+constexpr int BM = 128;
+constexpr int PITCH_B = 144;  // bytes per LDS tile row
+
+template <typename T, int NB, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+  constexpr int BN = 64 * NB;
+  constexpr int EPV = 16 / (int)sizeof(T);      // elements per 16-byte vector
+  constexpr int BK = 128 / (int)sizeof(T);      // elements per k-tile row
+  constexpr int PE = PITCH_B / (int)sizeof(T);  // LDS pitch in elements
+  constexpr int CH = 32 / (int)sizeof(T);       // elements per 32-byte mma chunk
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * PITCH_B];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = reinterpret_cast<T*>(smem + BM * PITCH_B);
+
+  // XCD-aware block -> tile map: blocks that share an A row-panel run on one XCD (b % 8), back to back.
+  const int id = blockIdx.x;
+  const int xcd = id & 7, j = id >> 3;
+  const int nt_i = j % p.ntiles;
+  const int mt_i = (j / p.ntiles) * 8 + xcd;
+  if (mt_i >= p.mtiles) return;
+  const int m0 = mt_i * BM, n0 = nt_i * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, g = lane >> 5;
+  const int vcol = tid & 7, vrow = tid >> 3;
+
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* W = reinterpret_cast<const T*>(p.W);
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  Frag<T> ra[4], rb[2 * NB];
+  const int KT = (p.K + BK - 1) / BK;
+
+  auto gload = [&](int kt) {
+    const int k = kt * BK + vcol * EPV;
+    const bool kin = (k + EPV) <= p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = m0 + vrow + 32 * i;
+      row = row < p.M ? row : p.M - 1;
+      if (kin) ra[i] = load_frag<T>(A + (size_t)row * p.lda + k);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) ra[i].v[e] = (T)0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NB; ++i) {
+      int row = n0 + vrow + 32 * i;
+      row = row < p.N ? row : p.N - 1;
+      if (kin) rb[i] = load_frag<T>(W + (size_t)row * p.ldw + k);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) rb[i].v[e] = (T)0.f;
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<decltype(ra[i].v)*>(As + (vrow + 32 * i) * PE + vcol * EPV) = ra[i].v;
+#pragma unroll
+    for (int i = 0; i < 2 * NB; ++i) *reinterpret_cast<decltype(rb[i].v)*>(Bs + (vrow + 32 * i) * PE + vcol * EPV) = rb[i].v;
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) gload(kt + 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Frag<T> fa[2], fb[NB];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = load_frag<T>(As + (wm * 64 + a * 32 + l31) * PE + c * CH + g * Frag<T>::EPL);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) fb[b] = load_frag<T>(Bs + (wn * 32 * NB + b * 32 + l31) * PE + c * CH + g * Frag<T>::EPL);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mma(acc[a][b], fa[a], fb[b]);
+    }
+    __syncthreads();
+    if (kt + 1 < KT) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  T* C = reinterpret_cast<T*>(p.C);
+  float* Cf = reinterpret_cast<float*>(p.C);
+  const T* R = reinterpret_cast<const T*>(p.R);
+  T* C2 = reinterpret_cast<T*>(p.C2);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = n0 + wn * 32 * NB + b * 32 + l31;
+    if (col >= p.N) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + a * 32 + acc_row(r, lane);
+        if (row >= p.M) continue;
+        float v = acc[a][b][r] + bv;
+        if (EPI == EPI_RES) v += to_f32(R[(size_t)row * p.ldr + col]);
+        if (EPI == EPI_GELU) {
+          C2[(size_t)row * p.ldc2 + col] = from_f32<T>(v);
+          v = gelu_f(to_f32(from_f32<T>(v)));  // GELU of the value as stored (what backward will see)
+        }
+        if (EPI == EPI_POS) v += p.pos[(size_t)(row % p.pos_period) * p.N + col];
+        if (EPI == EPI_DGELU) v *= dgelu_f(to_f32(R[(size_t)row * p.ldr + col]));
+        if (EPI == EPI_TANH) v = tanhf(v);
+        if (EPI == EPI_DTANH) {
+          const float h = to_f32(R[(size_t)row * p.ldr + col]);
+          v *= (1.f - h * h);
+        }
+        if (p.c_f32) Cf[(size_t)row * p.ldc + col] = v;
+        else C[(size_t)row * p.ldc + col] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+template <typename T, int NB>
+int launch_nt_epi(const GemmNT& p, int epi, hipStream_t st) {
+  const int grid = ((p.mtiles + 7) / 8) * 8 * p.ntiles;
+  switch (epi) {
+#define CASE(E) case E: hipLaunchKernelGGL((gemm_nt_kernel<T, NB, E>), dim3(grid), dim3(256), 0, st, p); break;
+    CASE(EPI_NONE) CASE(EPI_RES) CASE(EPI_GELU) CASE(EPI_POS) CASE(EPI_DGELU) CASE(EPI_TANH) CASE(EPI_DTANH)
+#undef CASE
+    default: return RGBNM_EINVAL;
+  }
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+template <typename T>
+int launch_nt(GemmNT p, int epi, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return RGBNM_EINVAL;
+  const int epv = 16 / (int)sizeof(T);
+  if (p.K % epv || p.lda % epv || p.ldw % epv) return RGBNM_EINVAL;
+  p.mtiles = cdiv(p.M, BM);
+  if (p.N % 192 == 0) {
+    p.ntiles = p.N / 192;
+    return launch_nt_epi<T, 3>(p, epi, st);
+  }
+  p.ntiles = cdiv(p.N, 128);
+  return launch_nt_epi<T, 2>(p, epi, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: dW[No,Ki] = sum_m dY[m,No] * X[m,Ki].  Tiles are staged in their natural [token][feature] layout
+// (coalesced 16-byte rows); the MFMA fragments (reduction = tokens) are gathered with strided LDS reads.
+// ------------------------------------------------------------------------------------------------
+struct GemmTN {
+  const void* dY; const void* X; float* part; float* bpart;
+  int ldy, ldx;
+  int M, No, Ki, S, tok_per_split;
+  int rtiles, ctiles;
+};
+
+template <typename T> __device__ __forceinline__ Frag<T> gather_frag(const T* base, int pitch_e) {
+  Frag<T> f;
+#pragma unroll
+  for (int j = 0; j < Frag<T>::EPL; ++j) f.v[j] = base[j * pitch_e];
+  return f;
+}
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+  constexpr int BN = 64 * NB;
+  constexpr int EPV = 16 / (int)sizeof(T);
+  constexpr int TK = 128 / (int)sizeof(T);                 // tokens per k-tile (64 bf16 / 32 f32)
+  constexpr int PA = (BM * (int)sizeof(T) + 64) / (int)sizeof(T);   // pitch (elements), +64 B pad
+  constexpr int PB = (BN * (int)sizeof(T) + 64) / (int)sizeof(T);
+  constexpr int VA = BM / EPV, VB = BN / EPV;              // 16-byte vectors per tile row
+  constexpr int NLA = TK * VA / 256, NLB = TK * VB / 256;  // vectors per thread
+  constexpr int EPL = Frag<T>::EPL;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TK * (PA + PB) * sizeof(T)];
+  T* Ys = reinterpret_cast<T*>(smem);
+  T* Xs = Ys + TK * PA;
+
+  const int tile = blockIdx.x, s = blockIdx.y;
+  const int rt = tile / p.ctiles, ct = tile % p.ctiles;
+  const int r0 = rt * BM, c0 = ct * BN;
+  const int tok0 = s * p.tok_per_split;
+  const int tok1 = min(p.M, tok0 + p.tok_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, g = lane >> 5;
+  const T* dY = reinterpret_cast<const T*>(p.dY);
+  const T* X = reinterpret_cast<const T*>(p.X);
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = (p.bpart != nullptr) && (ct == 0) && (tid < BM);
+
+  Frag<T> ra[NLA], rb[NLB];
+  auto gload = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      const int idx = tid + 256 * i, row = idx / VA, v = idx % VA;
+      const int tok = t0 + row, f = r0 + v * EPV;
+      if (tok < tok1 && f + EPV <= p.No) ra[i] = load_frag<T>(dY + (size_t)tok * p.ldy + f);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) ra[i].v[e] = (T)0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int idx = tid + 256 * i, row = idx / VB, v = idx % VB;
+      const int tok = t0 + row, f = c0 + v * EPV;
+      if (tok < tok1 && f + EPV <= p.Ki) rb[i] = load_frag<T>(X + (size_t)tok * p.ldx + f);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) rb[i].v[e] = (T)0.f;
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      const int idx = tid + 256 * i, row = idx / VA, v = idx % VA;
+      *reinterpret_cast<decltype(ra[i].v)*>(Ys + row * PA + v * EPV) = ra[i].v;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int idx = tid + 256 * i, row = idx / VB, v = idx % VB;
+      *reinterpret_cast<decltype(rb[i].v)*>(Xs + row * PB + v * EPV) = rb[i].v;
+    }
+  };
+
+  if (tok0 < tok1) {
+    gload(tok0);
+    lstore();
+    __syncthreads();
+    for (int t0 = tok0; t0 < tok1; t0 += TK) {
+      const bool more = (t0 + TK) < tok1;
+      if (more) gload(t0 + TK);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        Frag<T> fa[2], fb[NB];
+        const int trow = c * 2 * EPL + g * EPL;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = gather_frag<T>(Ys + trow * PA + wm * 64 + a * 32 + l31, PA);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) fb[b] = gather_frag<T>(Xs + trow * PB + wn * 32 * NB + b * 32 + l31, PB);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) mma(acc[a][b], fa[a], fb[b]);
+      }
+      if (do_bias) {
+#pragma unroll 8
+        for (int t = 0; t < TK; ++t) bsum += to_f32(Ys[t * PA + tid]);
+      }
+      __syncthreads();
+      if (more) {
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+
+  float* part = p.part + (size_t)s * p.No * p.Ki;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = c0 + wn * 32 * NB + b * 32 + l31;
+    if (col >= p.Ki) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + wm * 64 + a * 32 + acc_row(r, lane);
+        if (row < p.No) part[(size_t)row * p.Ki + col] = acc[a][b][r];
+      }
+  }
+  if (do_bias && r0 + tid < p.No) p.bpart[(size_t)s * p.No + r0 + tid] = bsum;
+}
+
+// out[rowmap(n)][k] (+)= sum_s part[s][n][k];  rowmap de-interleaves qkv rows (n = s3*H*64 + h*64 + d ->
+// reference row h*192 + d*3 + s3, plainvit.py:447 '(h d qkv)') when perm_heads > 0.
+__device__ __forceinline__ int qkv_row(int n, int heads) {
+  const int inner = heads * 64;
+  const int s3 = n / inner, rem = n % inner;
+  const int h = rem / 64, d = rem % 64;
+  return h * 192 + d * 3 + s3;
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int rows,
+                                       int cols, int perm_heads, int accumulate) {
+  const long long n = (long long)rows * cols;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(size_t)s * n + i];
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const int orow = perm_heads > 0 ? qkv_row(r, perm_heads) : r;
+    float* o = out + (size_t)orow * cols + c;
+    *o = accumulate ? (*o + a) : a;
+  }
+}
+
+template <typename T>
+int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hipStream_t st) {
+  const int epv = 16 / (int)sizeof(T);
+  if (p.M <= 0 || p.No % epv || p.Ki % epv || p.ldy % epv || p.ldx % epv) return RGBNM_EINVAL;
+  const int TK = 128 / (int)sizeof(T);
+  p.rtiles = cdiv(p.No, BM);
+  const bool nb3 = (p.Ki % 192 == 0);
+  p.ctiles = nb3 ? p.Ki / 192 : cdiv(p.Ki, 128);
+  const int tiles = p.rtiles * p.ctiles;
+  // split the token axis so that ~512 workgroups exist; each split is a whole number of k-tiles
+  int ktiles = cdiv(p.M, TK);
+  int S = min(p.S, max(1, min(ktiles, cdiv(512, tiles))));
+  int kt_per = cdiv(ktiles, S);
+  S = cdiv(ktiles, kt_per);
+  p.S = S;
+  p.tok_per_split = kt_per * TK;
+  if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3>), dim3(tiles, S), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<T, 2>), dim3(tiles, S), dim3(256), 0, st, p);
+  LAUNCH_CHECK();
+  const long long n = (long long)p.No * p.Ki;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(2048LL, cdivl(n, 256))), dim3(256), 0, st, p.part, dW, S,
+                     p.No, p.Ki, perm_heads, accumulate);
+  LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.No, 256)), dim3(256), 0, st, p.bpart, db, S, p.No, 1,
+                       perm_heads, accumulate);
+    LAUNCH_CHECK();
+  }
+  return RGBNM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep_weights: per Linear, fp32 master W[N,K] -> shadow Ws[N,K] (T) and WsT[K,N] (T); rows of qkv are
+// de-interleaved so that q|k|v come out as contiguous [heads*64] column blocks of the GEMM output.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void prep_weights_kernel(const rgbnm_linear_desc* __restrict__ descs, const float* __restrict__ master,
+                                    T* __restrict__ shadow) {
+  const rgbnm_linear_desc d = descs[blockIdx.y];
+  const long long n = (long long)d.N * d.K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / d.K), c = (int)(i % d.K);   // r = shadow (GEMM) row
+    const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
+    const T v = from_f32<T>(master[d.w_off + (size_t)src * d.K + c]);
+    shadow[d.ws_off + i] = v;
+    shadow[d.wst_off + (size_t)c * d.N + r] = v;
+  }
+}
+
+__global__ void gather_bias_kernel(const rgbnm_linear_desc* __restrict__ descs, const float* __restrict__ master,
+                                   float* __restrict__ bias_out) {
+  const rgbnm_linear_desc d = descs[blockIdx.y];
+  if (d.perm_heads <= 0) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x)
+    bias_out[d.bperm_off + i] = master[d.b_off + qkv_row(i, d.perm_heads)];
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int rgbnm_gemm_nt(int dtype, int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+                  const float* bias, const void* R, int ldr, void* C2, int ldc2, const float* pos, int pos_period,
+                  int M, int N, int K, int c_f32, void* stream) {
+  GemmNT p;
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.R = R; p.C2 = C2; p.pos = pos;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldc2 = ldc2; p.pos_period = pos_period > 0 ? pos_period : 1;
+  p.M = M; p.N = N; p.K = K; p.c_f32 = c_f32; p.mtiles = p.ntiles = 0;
+  if (!A || !W || !C) return RGBNM_EINVAL;
+  if ((epi == EPI_RES || epi == EPI_DGELU || epi == EPI_DTANH) && !R) return RGBNM_EINVAL;
+  if (epi == EPI_GELU && !C2) return RGBNM_EINVAL;
+  if (epi == EPI_POS && !pos) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) return launch_nt<bf16>(p, epi, st);
+  if (dtype == DT_F32) return launch_nt<float>(p, epi, st);
+  return RGBNM_EINVAL;
+}
+
+size_t rgbnm_gemm_tn_workspace(int M, int No, int Ki) {
+  // worst case split count is capped at 64
+  return (size_t)64 * ((size_t)No * Ki + No) * sizeof(float);
+}
+
+int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int No,
+                  int Ki, int perm_heads, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dY || !X || !dW || !workspace) return RGBNM_EINVAL;
+  if (workspace_bytes < rgbnm_gemm_tn_workspace(M, No, Ki)) return RGBNM_EWORKSPACE;
+  GemmTN p;
+  p.dY = dY; p.X = X; p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki; p.S = 64;
+  p.part = reinterpret_cast<float*>(workspace);
+  p.bpart = db ? p.part + (size_t)64 * No * Ki : nullptr;
+  p.tok_per_split = 0; p.rtiles = p.ctiles = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) return launch_tn<bf16>(p, dW, db, perm_heads, accumulate, st);
+  if (dtype == DT_F32) return launch_tn<float>(p, dW, db, perm_heads, accumulate, st);
+  return RGBNM_EINVAL;
+}
+
+int rgbnm_prep_weights(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
+                       float* bias_perm, void* stream) {
+  if (!descs_dev || !master || !shadow || ndesc <= 0) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((prep_weights_kernel<bf16>), dim3(96, ndesc), dim3(256), 0, st, descs_dev, master, (bf16*)shadow);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(96, ndesc), dim3(256), 0, st, descs_dev, master, (float*)shadow);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  if (bias_perm) {
+    hipLaunchKernelGGL(gather_bias_kernel, dim3(3, ndesc), dim3(256), 0, st, descs_dev, master, bias_perm);
+    LAUNCH_CHECK();
+  }
+  return RGBNM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,346 @@
+// LayerNorm forward / backward over the embedding axis (E = 192 or 384; eps 1e-5) for the pre-LN
+// residual blocks (reference: nn.LayerNorm in models/plainvit.py:513,522,551) plus the fused head pooling
+// (LN -> token mean, plainvit.py:551-552).  HBM-bound: 16 lanes own one row, 8/16-byte vector accesses,
+// statistics in fp32 with a two-pass (mean, then centred variance) reduction held in registers.
+#include "common.h"
+#include "../../include/rgbnm.h"
+
+namespace {
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// NV = E / 64 : each of the 16 lanes of a row group holds NV vectors of 4 consecutive elements,
+// element index e = (v*16 + l16)*4 + i.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                     float eps) {
+  constexpr int E = NV * 64;
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  f32x4 gm[NV], bt[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * 16 + l16) * 4);
+    bt[v] = *reinterpret_cast<const f32x4*>(beta + (v * 16 + l16) * 4);
+  }
+  for (int row = blockIdx.x * 16 + grp; row < M; row += gridDim.x * 16) {
+    f32x4 xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xv[v] = load4<T>(x + (size_t)row * E + (v * 16 + l16) * 4);
+      s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+    }
+    const float mu = group16_sum(s) * (1.f / E);
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float d = xv[v][i] - mu;
+        q += d * d;
+      }
+    const float rs = rsqrtf(group16_sum(q) * (1.f / E) + eps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (xv[v][i] - mu) * rs * gm[v][i] + bt[v][i];
+      store4<T>(y + (size_t)row * E + (v * 16 + l16) * 4, o);
+    }
+    if (l16 == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+// dx = [dres +] rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ part, int M) {
+  constexpr int E = NV * 64;
+  __shared__ float red[16][E + 4];
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  f32x4 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * 16 + l16) * 4);
+    dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 16 + grp; row < M; row += gridDim.x * 16) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NV], gv[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const size_t off = (size_t)row * E + (v * 16 + l16) * 4;
+      const f32x4 xv = load4<T>(x + off);
+      const f32x4 dv = load4<T>(dy + off);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xh[v][i] = (xv[i] - mu) * rs;
+        gv[v][i] = dv[i] * gm[v][i];
+        s1 += gv[v][i];
+        s2 += gv[v][i] * xh[v][i];
+        dg[v][i] += dv[i] * xh[v][i];
+        db[v][i] += dv[i];
+      }
+    }
+    const float c1 = group16_sum(s1) * (1.f / E), c2 = group16_sum(s2) * (1.f / E);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const size_t off = (size_t)row * E + (v * 16 + l16) * 4;
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2);
+      if (dres) {
+        const f32x4 rv = load4<T>(dres + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += rv[i];
+      }
+      store4<T>(dx + off, o);
+    }
+  }
+  // block-level column reduction of dgamma / dbeta (fixed order => deterministic)
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[grp][(v * 16 + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += red[r][e];
+      part[((size_t)blockIdx.x * 2 + pass) * E + e] = a;
+    }
+  }
+}
+
+__global__ void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                 int nblk, int E, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * E) return;
+  const int which = e / E, c = e % E;
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += part[((size_t)b * 2 + which) * E + c];
+  float* o = (which == 0 ? dgamma : dbeta) + c;
+  *o = accumulate ? (*o + a) : a;
+}
+
+// ---- head pooling: pooled[b] = mean_t LN(x[b,t,:])  (one workgroup per image) ------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ pooled,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int N,
+                                                       float eps) {
+  constexpr int E = NV * 64;
+  __shared__ float red[16][E + 4];
+  const int b = blockIdx.x;
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  f32x4 acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = grp; t < N; t += 16) {
+    const size_t row = (size_t)b * N + t;
+    f32x4 xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xv[v] = load4<T>(x + row * E + (v * 16 + l16) * 4);
+      s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+    }
+    const float mu = group16_sum(s) * (1.f / E);
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float d = xv[v][i] - mu;
+        q += d * d;
+      }
+    const float rs = rsqrtf(group16_sum(q) * (1.f / E) + eps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[v][i] += (xv[v][i] - mu) * rs;
+    if (l16 == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[grp][(v * 16 + l16) * 4 + i] = acc[v][i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += red[r][e];
+    // mean_t (xhat*gamma + beta) = gamma * mean_t(xhat) + beta
+    pooled[(size_t)b * E + e] = from_f32<T>(a * (1.f / N) * gamma[e] + beta[e]);
+  }
+}
+
+// dx[b,t,:] = LN-backward of dy = dpooled[b,:]/N (same for every token); partial dgamma/dbeta per image.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dpooled, const T* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, T* __restrict__ dx,
+                                                       float* __restrict__ part, int N) {
+  constexpr int E = NV * 64;
+  __shared__ float red[16][E + 4];
+  const int b = blockIdx.x;
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const float invN = 1.f / N;
+  f32x4 gm[NV], dv[NV], dg[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * 16 + l16) * 4);
+    dv[v] = load4<T>(dpooled + (size_t)b * E + (v * 16 + l16) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dv[v][i] *= invN;
+    dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int t = grp; t < N; t += 16) {
+    const size_t row = (size_t)b * N + t;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NV], gv[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const f32x4 xv = load4<T>(x + row * E + (v * 16 + l16) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xh[v][i] = (xv[i] - mu) * rs;
+        gv[v][i] = dv[v][i] * gm[v][i];
+        s1 += gv[v][i];
+        s2 += gv[v][i] * xh[v][i];
+        dg[v][i] += dv[v][i] * xh[v][i];
+      }
+    }
+    const float c1 = group16_sum(s1) * (1.f / E), c2 = group16_sum(s2) * (1.f / E);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2);
+      store4<T>(dx + row * E + (v * 16 + l16) * 4, o);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[grp][(v * 16 + l16) * 4 + i] = dg[v][i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += red[r][e];
+    part[((size_t)b * 2 + 0) * E + e] = a;
+    // dbeta contribution of this image = sum_t dy = dpooled[b,e]
+    part[((size_t)b * 2 + 1) * E + e] = to_f32(dpooled[(size_t)b * E + e]);
+  }
+}
+
+constexpr int LN_BWD_BLOCKS = 512;
+
+template <typename T>
+int ln_fwd_t(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int E, float eps,
+             hipStream_t st) {
+  const int grid = min(cdiv(M, 16), 4096);
+  if (E == 192) hipLaunchKernelGGL((ln_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (T*)y, mean, rstd, M, eps);
+  else if (E == 384) hipLaunchKernelGGL((ln_fwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (T*)y, mean, rstd, M, eps);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+template <typename T>
+int ln_bwd_t(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, const void* dres,
+             void* dx, float* dgamma, float* dbeta, int M, int E, int accumulate, float* ws, hipStream_t st) {
+  const int grid = min(cdiv(M, 16), LN_BWD_BLOCKS);
+  if (E == 192) hipLaunchKernelGGL((ln_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
+  else if (E == 384) hipLaunchKernelGGL((ln_bwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(2 * E, 256)), dim3(256), 0, st, ws, dgamma, dbeta, grid, E, accumulate);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rgbnm_layernorm_bwd_workspace(int M, int E) {
+  int blocks = cdiv(M, 16);
+  if (blocks < LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;   // also covers pool_bwd (one block per image) up to 512
+  return (size_t)blocks * 2 * E * sizeof(float);
+}
+
+int rgbnm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int M, int E, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0) return RGBNM_EINVAL;
+  if (dtype == DT_BF16) return ln_fwd_t<bf16>(x, gamma, beta, y, mean, rstd, M, E, eps, (hipStream_t)stream);
+  if (dtype == DT_F32) return ln_fwd_t<float>(x, gamma, beta, y, mean, rstd, M, E, eps, (hipStream_t)stream);
+  return RGBNM_EINVAL;
+}
+
+int rgbnm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int M, int E,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || M <= 0) return RGBNM_EINVAL;
+  if (workspace_bytes < (size_t)LN_BWD_BLOCKS * 2 * E * sizeof(float)) return RGBNM_EWORKSPACE;
+  if (dtype == DT_BF16) return ln_bwd_t<bf16>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, M, E, accumulate, (float*)workspace, (hipStream_t)stream);
+  if (dtype == DT_F32) return ln_bwd_t<float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, M, E, accumulate, (float*)workspace, (hipStream_t)stream);
+  return RGBNM_EINVAL;
+}
+
+int rgbnm_head_pool_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* pooled, float* mean,
+                        float* rstd, int B, int N, int E, float eps, void* stream) {
+  if (!x || !gamma || !beta || !pooled || !mean || !rstd || B <= 0 || N <= 0) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+#define POOL(T, NV) hipLaunchKernelGGL((pool_fwd_kernel<T, NV>), dim3(B), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)pooled, mean, rstd, N, eps)
+  if (dtype == DT_BF16 && E == 192) POOL(bf16, 3);
+  else if (dtype == DT_BF16 && E == 384) POOL(bf16, 6);
+  else if (dtype == DT_F32 && E == 192) POOL(float, 3);
+  else if (dtype == DT_F32 && E == 384) POOL(float, 6);
+  else return RGBNM_EINVAL;
+#undef POOL
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_head_pool_bwd(int dtype, const void* dpooled, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, float* dgamma, float* dbeta, int B, int N, int E, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dpooled || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return RGBNM_EINVAL;
+  if (workspace_bytes < (size_t)B * 2 * E * sizeof(float)) return RGBNM_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+#define POOLB(T, NV) hipLaunchKernelGGL((pool_bwd_kernel<T, NV>), dim3(B), dim3(256), 0, st, (const T*)dpooled, (const T*)x, gamma, mean, rstd, (T*)dx, ws, N)
+  if (dtype == DT_BF16 && E == 192) POOLB(bf16, 3);
+  else if (dtype == DT_BF16 && E == 384) POOLB(bf16, 6);
+  else if (dtype == DT_F32 && E == 192) POOLB(float, 3);
+  else if (dtype == DT_F32 && E == 384) POOLB(float, 6);
+  else return RGBNM_EINVAL;
+#undef POOLB
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(2 * E, 256)), dim3(256), 0, st, ws, dgamma, dbeta, B, E, accumulate);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // extern "C"

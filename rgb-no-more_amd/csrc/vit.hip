@@ -1,0 +1,126 @@
+// Composite stages of the JPEG-ViT (reference: models/plainvit.py:493-529 TransformerEncoderBlock,
+// :157-218 PatchEmbedding_DCT_Group, :542-557 ClassificationHead): each is one C-ABI call that enqueues
+// its kernels on the caller's stream, so the Python side pays one ctypes call per autograd node.
+#include "common.h"
+#include "../../include/rgbnm.h"
+
+#define TRY(x)                 \
+  do {                         \
+    int rc__ = (x);            \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+static inline size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+extern "C" {
+
+int rgbnm_abi_version(void) { return RGBNM_ABI_VERSION; }
+
+const char* rgbnm_strerror(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case RGBNM_EINVAL: return "invalid argument (null pointer, bad shape, alignment or dtype)";
+    case RGBNM_ELAUNCH: return "HIP kernel launch failed";
+    case RGBNM_EWORKSPACE: return "workspace too small";
+    default: return "unknown rgbnm error";
+  }
+}
+
+size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* c) {
+  if (!c) return 0;
+  const int M = c->B * c->N, E = c->E, I = c->heads * 64;
+  size_t w = rgbnm_gemm_tn_workspace(M, 4 * E, E);
+  w = max_sz(w, rgbnm_gemm_tn_workspace(M, 3 * I, E));
+  w = max_sz(w, rgbnm_gemm_tn_workspace(M, E, 4 * E));
+  w = max_sz(w, rgbnm_gemm_tn_workspace(M, E, 384));
+  w = max_sz(w, rgbnm_gemm_tn_workspace(c->B, 1024, E));
+  w = max_sz(w, rgbnm_layernorm_bwd_workspace(M, E));
+  w = max_sz(w, (size_t)c->B * 2 * E * sizeof(float));
+  return w;
+}
+
+int rgbnm_vit_block_fwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, const rgbnm_block_acts* a, void* st) {
+  if (!c || !p || !a) return RGBNM_EINVAL;
+  const int dt = c->dtype, M = c->B * c->N, E = c->E, I = c->heads * 64;
+  TRY(rgbnm_layernorm_fwd(dt, a->x_in, p->ln1_g, p->ln1_b, a->xn1, a->mean1, a->rstd1, M, E, c->ln_eps, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, a->xn1, E, p->wqkv, E, a->qkv, 3 * I, p->bqkv_perm, 0, 0, 0, 0, 0, 0, M,
+                    3 * I, E, 0, st));
+  TRY(rgbnm_attention_fwd(dt, a->qkv, a->attn, a->lse, c->B, c->N, c->heads, c->attn_scale, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_RES, a->attn, I, p->wproj, I, a->x_mid, E, p->bproj, a->x_in, E, 0, 0, 0, 0, M, E,
+                    I, 0, st));
+  TRY(rgbnm_layernorm_fwd(dt, a->x_mid, p->ln2_g, p->ln2_b, a->xn2, a->mean2, a->rstd2, M, E, c->ln_eps, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_GELU, a->xn2, E, p->w1, E, a->gl, 4 * E, p->b1, 0, 0, a->u, 4 * E, 0, 0, M, 4 * E,
+                    E, 0, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_RES, a->gl, 4 * E, p->w2, 4 * E, a->x_out, E, p->b2, a->x_mid, E, 0, 0, 0, 0, M, E,
+                    4 * E, 0, st));
+  return RGBNM_OK;
+}
+
+int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, const rgbnm_block_acts* a,
+                        const rgbnm_block_grads* g, const rgbnm_block_scratch* s, const void* dy, void* dx, void* st) {
+  if (!c || !p || !a || !g || !s || !dy || !dx) return RGBNM_EINVAL;
+  const int dt = c->dtype, M = c->B * c->N, E = c->E, I = c->heads * 64;
+  // ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ------------------------------------
+  TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, s->ws, s->ws_bytes, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DGELU, dy, E, p->w2_t, E, s->du, 4 * E, 0, a->u, 4 * E, 0, 0, 0, 0, M, 4 * E, E, 0,
+                    st));
+  TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, s->ws, s->ws_bytes, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->du, 4 * E, p->w1_t, 4 * E, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 4 * E, 0,
+                    st));
+  TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid, g->dln2_g, g->dln2_b, M,
+                          E, 0, s->ws, s->ws_bytes, st));
+  // ---- attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in)))) -------------------------------
+  TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, s->ws, s->ws_bytes, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dx_mid, E, p->wproj_t, E, s->dattn, I, 0, 0, 0, 0, 0, 0, 0, M, I, E, 0, st));
+  TRY(rgbnm_attention_bwd(dt, a->qkv, a->attn, s->dattn, a->lse, s->dqkv, c->B, c->N, c->heads, c->attn_scale, st));
+  TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, s->ws, s->ws_bytes,
+                    st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dqkv, 3 * I, p->wqkv_t, 3 * I, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 3 * I,
+                    0, st));
+  TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_in, p->ln1_g, a->mean1, a->rstd1, s->dx_mid, dx, g->dln1_g, g->dln1_b, M,
+                          E, 0, s->ws, s->ws_bytes, st));
+  return RGBNM_OK;
+}
+
+int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* c, int in_dtype, const void* y, const void* cbcr, const float* conv16,
+                          const void* wpe, const float* bpe, const float* pos, void* feat, void* x0, int Hb, int Wb,
+                          void* st) {
+  if (!c) return RGBNM_EINVAL;
+  const int M = c->B * c->N;
+  if ((Hb / 2) * (Wb / 2) != c->N) return RGBNM_EINVAL;
+  TRY(rgbnm_subblock_embed(in_dtype, c->dtype, y, cbcr, conv16, feat, c->B, Hb, Wb, 0, st));
+  TRY(rgbnm_gemm_nt(c->dtype, RGBNM_EPI_POS, feat, 384, wpe, 384, x0, c->E, bpe, 0, 0, 0, 0, pos, c->N, M, c->E, 384,
+                    0, st));
+  return RGBNM_OK;
+}
+
+int rgbnm_patch_embed_bwd(const rgbnm_vit_cfg* c, const void* dx0, const void* feat, float* dwpe, float* dbpe,
+                          void* ws, size_t ws_bytes, void* st) {
+  if (!c) return RGBNM_EINVAL;
+  return rgbnm_gemm_tn(c->dtype, dx0, c->E, feat, 384, dwpe, dbpe, c->B * c->N, c->E, 384, 0, 0, ws, ws_bytes, st);
+}
+
+int rgbnm_head_fwd(const rgbnm_vit_cfg* c, const rgbnm_head_params* p, const rgbnm_head_acts* a, void* st) {
+  if (!c || !p || !a) return RGBNM_EINVAL;
+  const int dt = c->dtype, E = c->E, C = p->n_classes;
+  TRY(rgbnm_head_pool_fwd(dt, a->x, p->ln_g, p->ln_b, a->pooled, a->mean, a->rstd, c->B, c->N, E, c->ln_eps, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_TANH, a->pooled, E, p->w1, E, a->h1, E, p->b1, 0, 0, 0, 0, 0, 0, c->B, E, E, 0, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, a->h1, E, p->w2, E, a->logits, C, p->b2, 0, 0, 0, 0, 0, 0, c->B, C, E, 1, st));
+  return RGBNM_OK;
+}
+
+int rgbnm_head_bwd(const rgbnm_vit_cfg* c, const rgbnm_head_params* p, const rgbnm_head_acts* a,
+                   const rgbnm_head_grads* g, const void* dlogits, void* da, void* dpooled, void* dx, void* ws,
+                   size_t ws_bytes, void* st) {
+  if (!c || !p || !a || !g || !dlogits || !da || !dpooled || !dx) return RGBNM_EINVAL;
+  const int dt = c->dtype, E = c->E, C = p->n_classes, B = c->B;
+  TRY(rgbnm_gemm_tn(dt, dlogits, C, a->h1, E, g->dw2, g->db2, B, C, E, 0, 0, ws, ws_bytes, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DTANH, dlogits, C, p->w2_t, C, da, E, 0, a->h1, E, 0, 0, 0, 0, B, E, C, 0, st));
+  TRY(rgbnm_gemm_tn(dt, da, E, a->pooled, E, g->dw1, g->db1, B, E, E, 0, 0, ws, ws_bytes, st));
+  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, da, E, p->w1_t, E, dpooled, E, 0, 0, 0, 0, 0, 0, 0, B, E, E, 0, st));
+  TRY(rgbnm_head_pool_bwd(dt, dpooled, a->x, p->ln_g, a->mean, a->rstd, dx, g->dln_g, g->dln_b, B, c->N, E, 0, ws,
+                          ws_bytes, st));
+  return RGBNM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""ctypes binding of librgbnm.so (include/rgbnm.h).  There is NO fallback: if the HIP library is missing or
+a call fails, an exception is raised (the product path never routes through a CPU/oracle implementation)."""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librgbnm.so")
+
+DT_F32, DT_BF16 = 0, 1
+EPI_NONE, EPI_RES, EPI_GELU, EPI_POS, EPI_DGELU, EPI_TANH, EPI_DTANH = range(7)
+
+_vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [("w_off", _ll), ("b_off", _ll), ("ws_off", _ll), ("wst_off", _ll), ("bperm_off", _ll),
+                ("N", _i), ("K", _i), ("perm_heads", _i), ("_pad", _i)]
+
+
+class VitCfg(C.Structure):
+    _fields_ = [("dtype", _i), ("B", _i), ("N", _i), ("E", _i), ("heads", _i), ("ln_eps", _f), ("attn_scale", _f)]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "bqkv_perm", "bproj", "b1", "b2",
+                                   "wqkv", "wqkv_t", "wproj", "wproj_t", "w1", "w1_t", "w2", "w2_t")]
+
+
+class BlockActs(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x_in", "xn1", "mean1", "rstd1", "qkv", "lse", "attn", "x_mid", "xn2", "mean2",
+                                   "rstd2", "u", "gl", "x_out")]
+
+
+class BlockGrads(C.Structure):
+    _fields_ = [(n, _vp) for n in ("dln1_g", "dln1_b", "dln2_g", "dln2_b", "dwqkv", "dbqkv", "dwproj", "dbproj",
+                                   "dw1", "db1", "dw2", "db2")]
+
+
+class BlockScratch(C.Structure):
+    _fields_ = [("du", _vp), ("dxn", _vp), ("dx_mid", _vp), ("dattn", _vp), ("dqkv", _vp), ("ws", _vp),
+                ("ws_bytes", _sz)]
+
+
+class HeadParams(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln_g", "ln_b", "b1", "b2", "w1", "w1_t", "w2", "w2_t")] + \
+               [("n_classes", _i), ("_pad", _i)]
+
+
+class HeadActs(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x", "mean", "rstd", "pooled", "h1", "logits")]
+
+
+class HeadGrads(C.Structure):
+    _fields_ = [(n, _vp) for n in ("dln_g", "dln_b", "dw1", "db1", "dw2", "db2")]
+
+
+_P = C.POINTER
+# name -> (restype, argtypes); every symbol include/rgbnm.h declares
+PROTOTYPES = {
+    "rgbnm_abi_version": (_i, []),
+    "rgbnm_strerror": (C.c_char_p, [_i]),
+    "rgbnm_gemm_nt": (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbnm_gemm_tn_workspace": (_sz, [_i, _i, _i]),
+    "rgbnm_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "rgbnm_prep_weights": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "rgbnm_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "rgbnm_layernorm_bwd_workspace": (_sz, [_i, _i]),
+    "rgbnm_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "rgbnm_head_pool_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "rgbnm_head_pool_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "rgbnm_attention_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "rgbnm_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "rgbnm_subblock_embed": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rgbnm_softxent": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "rgbnm_mixup": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _vp]),
+    "rgbnm_mixup_target": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "rgbnm_clip_adamw_wd_workspace": (_sz, []),
+    "rgbnm_clip_adamw_wd_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _sz, _vp]),
+    "rgbnm_vit_workspace": (_sz, [_P(VitCfg)]),
+    "rgbnm_vit_block_fwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _vp]),
+    "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
+                                 _vp, _vp]),
+    "rgbnm_patch_embed_fwd": (_i, [_P(VitCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "rgbnm_patch_embed_bwd": (_i, [_P(VitCfg), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rgbnm_head_fwd": (_i, [_P(VitCfg), _P(HeadParams), _P(HeadActs), _vp]),
+    "rgbnm_head_bwd": (_i, [_P(VitCfg), _P(HeadParams), _P(HeadActs), _P(HeadGrads), _vp, _vp, _vp, _vp, _vp, _sz,
+                            _vp]),
+}
+
+_lib = None
+
+
+class RgbnmError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librgbnm.so (built by __graft_entry__.build() / rgb-no-more_amd/build.py).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RgbnmError(f"HIP extension missing: {LIB_PATH} (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                             "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)       # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rgbnm_strerror(rc).decode()
+        raise RgbnmError(f"{what}: rgbnm error {rc}: {msg}")
+
+
+def dt_of(t):
+    if t == torch.float32:
+        return DT_F32
+    if t == torch.bfloat16:
+        return DT_BF16
+    raise TypeError(f"unsupported dtype {t} (float32 or bfloat16)")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RgbnmError("rgb-no-more_amd kernels need device (HIP) tensors; there is no CPU fallback")
+        if t is not None and not t.is_contiguous():
+            raise RgbnmError("tensor must be contiguous")

@@ -1,0 +1,429 @@
+"""Drop-in mirror of the reference `models/plainvit.py` ViT for `--domain DCT`, embed_type 1
+(PatchEmbedding_DCT_Group, plainvit.py:157-218, :559-611), executing on hand-written HIP kernels.
+
+* same constructor signature as `pvit.ViT(...)` (pipeline_utils.py:335-349) and the same 152 `state_dict()`
+  keys / shapes / default init (parameter holders are ordinary nn.Linear / nn.LayerNorm modules, never called);
+* `forward(y, cbcr) -> logits (B, n_classes) fp32`;
+* compute dtype = the active autocast dtype (bf16) or fp32 when autocast is off, so train.py's
+  `--amp/--ampdtype` flags and its DDP loop work unchanged;
+* one autograd node per stage (patch-embed, each encoder block, head) = one C-ABI call each; parameter
+  gradients are ordinary leaf grads, so DDP's bucketed all-reduce (RCCL) overlaps with backward.
+
+There is no fallback path: without librgbnm.so / a HIP device `forward` raises.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import dct_ops as dops
+from . import lib as L
+
+_SEG = 256  # every tensor starts on a 256-element boundary of the flat buffers
+
+
+def _align(n, a=_SEG):
+    return (n + a - 1) // a * a
+
+
+# ------------------------------------------------------------------ parameter-holder module tree
+class ResidualAdd(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, emb_size, num_heads, head_size, input_embed=-1, device="cpu", dtype=torch.float32):
+        super().__init__()
+        inner = num_heads * head_size
+        self.qkv = nn.Linear(emb_size if input_embed < 0 else input_embed, inner * 3, device=device, dtype=dtype)
+        self.projection = nn.Linear(inner, emb_size, device=device, dtype=dtype)
+
+
+class PatchEmbedding_DCT_Group(nn.Module):
+    """plainvit.py:157-218; only the parameters live here, compute is rgbnm_patch_embed_fwd."""
+
+    def __init__(self, patch_size=16, emb_size=768, use_subblock=True, chroma_scale=2, device="cpu",
+                 dtype=torch.float32):
+        super().__init__()
+        assert not (patch_size & (patch_size - 1)) and patch_size >= 2, \
+            f"Patch size should be 2^n (n>0, n=int). Current value: {patch_size}"
+        if patch_size != 16 or chroma_scale != 2 or not use_subblock:
+            raise NotImplementedError("HIP path covers patch_size=16, 4:2:0, use_subblock=True (JPEG-Ti/S configs)")
+        self.patch_size = patch_size
+        fin = patch_size ** 2 + 2 * (patch_size // chroma_scale) ** 2
+        self.projection = nn.Sequential(nn.Linear(fin, emb_size, device=device, dtype=dtype))
+        # conv_Y is a plain attribute in the reference too (not a buffer, not in the state_dict)
+        self.conv_Y = dops.generate_conversion_matrix(8, patch_size // 8, scale=True, dtype=torch.float32)
+
+
+def sincos_table(h, w, e, device="cpu"):
+    """SinCosEmbedding (plainvit.py:90-121) as a constant (h*w, e) fp32 table."""
+    hg, wg = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    fr = torch.log(torch.tensor(10000, dtype=torch.int32)) / (e // 4 - 1)
+    fr = torch.exp(-torch.arange(e // 4, dtype=torch.float32) * fr)
+    ph = torch.einsum("p,f->pf", hg.flatten().float(), fr)
+    pw = torch.einsum("p,f->pf", wg.flatten().float(), fr)
+    return torch.cat((pw.sin(), pw.cos(), ph.sin(), ph.cos()), dim=-1).contiguous().to(device)
+
+
+# ------------------------------------------------------------------ per-forward state
+class _Arena:
+    """Activation / scratch buffers for one (B, dtype, grad) configuration with pre-built ctypes structs."""
+
+    def __init__(self, model, B, cdtype, need_grad):
+        dev = model._flat.device
+        E, I, N, D = model.emb_size, model.inner, model.n_tokens, model.depth
+        M = B * N
+        T = cdtype
+        self.B, self.cdtype, self.need_grad = B, cdtype, need_grad
+        e = lambda *s, dt=T: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        f32 = torch.float32
+        self.cfg = L.VitCfg(L.dt_of(T), B, N, E, model.num_heads, 1e-5, 1.0 / math.sqrt(E))
+        self.feat = e(M, 384)
+        nx = D + 1 if need_grad else 2
+        self.x = [e(M, E) for _ in range(nx)]
+        nb = D if need_grad else 1
+        self.blk = []
+        for _ in range(nb):
+            self.blk.append(dict(xn1=e(M, E), mean1=e(M, dt=f32), rstd1=e(M, dt=f32), qkv=e(M, 3 * I),
+                                 lse=e(B * model.num_heads * N, dt=f32), attn=e(M, I), x_mid=e(M, E), xn2=e(M, E),
+                                 mean2=e(M, dt=f32), rstd2=e(M, dt=f32), u=e(M, 4 * E), gl=e(M, 4 * E)))
+        self.hmean, self.hrstd = e(M, dt=f32), e(M, dt=f32)
+        self.pooled, self.h1 = e(B, E), e(B, E)
+        ws_bytes = L.lib().rgbnm_vit_workspace(C.byref(self.cfg))
+        self.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        if need_grad:
+            self.du, self.dxn, self.dx_mid = e(M, 4 * E), e(M, E), e(M, E)
+            self.dattn, self.dqkv = e(M, I), e(M, 3 * I)
+            self.dx = [e(M, E), e(M, E)]
+            self.da, self.dpooled = e(B, E), e(B, E)
+            self.scratch = L.BlockScratch(self.du.data_ptr(), self.dxn.data_ptr(), self.dx_mid.data_ptr(),
+                                          self.dattn.data_ptr(), self.dqkv.data_ptr(), self.ws.data_ptr(), ws_bytes)
+        self.ws_bytes = ws_bytes
+        self.acts = []
+        for i in range(D):
+            b = self.blk[i if need_grad else 0]
+            xi, xo = (self.x[i], self.x[i + 1]) if need_grad else (self.x[i & 1], self.x[(i + 1) & 1])
+            self.acts.append(L.BlockActs(xi.data_ptr(), b["xn1"].data_ptr(), b["mean1"].data_ptr(),
+                                         b["rstd1"].data_ptr(), b["qkv"].data_ptr(), b["lse"].data_ptr(),
+                                         b["attn"].data_ptr(), b["x_mid"].data_ptr(), b["xn2"].data_ptr(),
+                                         b["mean2"].data_ptr(), b["rstd2"].data_ptr(), b["u"].data_ptr(),
+                                         b["gl"].data_ptr(), xo.data_ptr()))
+
+    def xbuf(self, i):
+        return self.x[i] if self.need_grad else self.x[i & 1]
+
+
+class _FwdState:
+    """Shared by the autograd nodes of one forward; hands the arena back to the pool when the graph dies."""
+
+    def __init__(self, model, arena, gbuf):
+        self.model, self.arena, self.gbuf = model, arena, gbuf
+
+    def __del__(self):
+        try:
+            self.model._release_arena(self.arena)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ autograd nodes
+class _PatchEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, cbcr, st, w, b):
+        m, a = st.model, st.arena
+        Hb, Wb = y.shape[2], y.shape[3]
+        L.check(L.lib().rgbnm_patch_embed_fwd(C.byref(a.cfg), L.dt_of(y.dtype), y.data_ptr(), cbcr.data_ptr(),
+                                              m._conv16.data_ptr(), m._sh_ptr("pe", "ws"), b.data_ptr(),
+                                              m._pos.data_ptr(), a.feat.data_ptr(), a.xbuf(0).data_ptr(), Hb, Wb,
+                                              L.stream()), "patch_embed_fwd")
+        ctx.st = st
+        return a.xbuf(0).detach()   # fresh tensor object per call (arena buffers are reused across steps)
+
+    @staticmethod
+    def backward(ctx, dx0):
+        st = ctx.st
+        m, a = st.model, st.arena
+        dx0 = dx0.contiguous()
+        gw, gb = m._gview(st.gbuf, "patchembed.projection.0.weight"), m._gview(st.gbuf, "patchembed.projection.0.bias")
+        L.check(L.lib().rgbnm_patch_embed_bwd(C.byref(a.cfg), dx0.data_ptr(), a.feat.data_ptr(), gw.data_ptr(),
+                                              gb.data_ptr(), a.ws.data_ptr(), a.ws_bytes, L.stream()), "patch_embed_bwd")
+        return None, None, None, gw, gb
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, st, idx, *params):
+        m, a = st.model, st.arena
+        assert x.data_ptr() == a.xbuf(idx).data_ptr()
+        L.check(L.lib().rgbnm_vit_block_fwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
+                                            L.stream()), "vit_block_fwd")
+        ctx.st, ctx.idx = st, idx
+        return a.xbuf(idx + 1).detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        st, idx = ctx.st, ctx.idx
+        m, a = st.model, st.arena
+        dy = dy.contiguous()
+        dx = a.dx[idx & 1]
+        if dx.data_ptr() == dy.data_ptr():
+            dx = a.dx[(idx + 1) & 1]
+        grads = [m._gview(st.gbuf, n) for n in m._block_names[idx]]
+        g = L.BlockGrads(*[t.data_ptr() for t in grads])
+        L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
+                                            C.byref(g), C.byref(a.scratch), dy.data_ptr(), dx.data_ptr(),
+                                            L.stream()), "vit_block_bwd")
+        # grads come back in BlockGrads field order; reorder to the order the params were passed in
+        by_name = dict(zip(m._block_names[idx], grads))
+        return (dx, None, None) + tuple(by_name[n] for n in m._block_param_order[idx])
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, st, *params):
+        m, a = st.model, st.arena
+        logits = torch.empty(a.B, m.n_classes, device=x.device, dtype=torch.float32)
+        acts = L.HeadActs(x.data_ptr(), a.hmean.data_ptr(), a.hrstd.data_ptr(), a.pooled.data_ptr(),
+                          a.h1.data_ptr(), logits.data_ptr())
+        L.check(L.lib().rgbnm_head_fwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(acts), L.stream()), "head_fwd")
+        ctx.st, ctx.acts, ctx.x = st, acts, x
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        st = ctx.st
+        m, a = st.model, st.arena
+        dl = dlogits.to(a.cdtype).contiguous()
+        names = m._head_names
+        grads = [m._gview(st.gbuf, n) for n in names]
+        g = L.HeadGrads(*[t.data_ptr() for t in grads])
+        dx = a.dx[0]
+        L.check(L.lib().rgbnm_head_bwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(ctx.acts), C.byref(g),
+                                       dl.data_ptr(), a.da.data_ptr(), a.dpooled.data_ptr(), dx.data_ptr(),
+                                       a.ws.data_ptr(), a.ws_bytes, L.stream()), "head_bwd")
+        by_name = dict(zip(names, grads))
+        return (dx, None) + tuple(by_name[n] for n in m._head_param_order)
+
+
+# ------------------------------------------------------------------ the model
+class ViT(nn.Module):
+    """Vision Transformer on DCT coefficients -- same ctor as the reference `ViT` (plainvit.py:559-599)."""
+
+    def __init__(self, in_channels: int = 3, patch_size: int = 16, emb_size: int = 768, input_embed: int = -1,
+                 depth: int = 12, n_classes: int = 1000, drop_p=0.1, pixel_space="RGB", ver=1, use_subblock=True,
+                 device="cpu", dtype=torch.float32, num_heads: int = 8, head_size: int = 64, **kwargs):
+        super().__init__()
+        if pixel_space.lower() not in ("dct", "rgb2dct"):
+            raise NotImplementedError("rgb-no-more_amd implements the --domain DCT path only")
+        if ver != 1:
+            raise NotImplementedError("embed_type 1 (PatchEmbedding_DCT_Group) only; see SURVEY.md 8f f3")
+        if drop_p not in (0, 0.0):
+            raise NotImplementedError("dropout p must be 0 (cfg.TRAIN.DROP default, configs.py:27)")
+        if head_size != 64 or emb_size not in (192, 384) or input_embed >= 0:
+            raise NotImplementedError("HIP kernels cover head_size 64 and emb_size 192/384 (JPEG-Ti / JPEG-S)")
+        if dtype != torch.float32:
+            raise NotImplementedError("parameters are fp32 masters; choose bf16 compute with autocast")
+        self.pixel_space = pixel_space
+        self.emb_size, self.depth, self.n_classes = emb_size, depth, n_classes
+        self.num_heads, self.inner = num_heads, num_heads * head_size
+        self.n_tokens = 196
+        E = emb_size
+        kw = dict(device=device, dtype=dtype)
+        self.patchembed = PatchEmbedding_DCT_Group(patch_size, E, use_subblock, **kw)
+        blocks = []
+        for _ in range(depth):
+            att = ResidualAdd(nn.Sequential(OrderedDict([
+                ("eb_lrnorm1", nn.LayerNorm(E, **kw)),
+                ("eb_mha", MultiHeadAttention(E, num_heads, head_size, **kw)),
+                ("eb_drop1", nn.Identity())])))
+            ffn = ResidualAdd(nn.Sequential(OrderedDict([
+                ("eb_lrnorm2", nn.LayerNorm(E, **kw)),
+                ("eb_ffb", nn.Sequential(nn.Linear(E, 4 * E, **kw), nn.Identity(), nn.Identity(),
+                                         nn.Linear(4 * E, E, **kw))),
+                ("eb_drop2", nn.Identity())])))
+            blocks.append(nn.Sequential(att, ffn))
+        self.encoder = nn.Sequential(*blocks)
+        self.classhead = nn.Sequential(OrderedDict([
+            ("ch_lrnorm", nn.LayerNorm(E, **kw)), ("ch_gap", nn.Identity()),
+            ("ch_linear1", nn.Linear(E, E, **kw)), ("ch_tanh", nn.Identity()),
+            ("ch_linear2", nn.Linear(E, n_classes, **kw))]))
+        self._flat = None
+        self._arenas = {}
+        self.compute_dtype = None      # None: follow autocast; or force torch.float32 / torch.bfloat16
+
+    # ---------------------------------------------------------------- flat buffers / shadows
+    def _names(self):
+        return [n for n, _ in self.named_parameters()]
+
+    def _flatten(self):
+        """(Re)pack every parameter into one fp32 buffer (256-element aligned segments) and describe the
+        Linear layers for rgbnm_prep_weights.  Called lazily; survives .to(), load_state_dict (in-place copy)."""
+        params = list(self.named_parameters())
+        dev = params[0][1].device
+        if dev.type != "cuda":
+            raise L.RgbnmError("model parameters must live on a HIP device (no CPU fallback)")
+        offs, total = {}, 0
+        for n, p in params:
+            offs[n] = total
+            total += _align(p.numel())
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        for n, p in params:
+            seg = flat[offs[n]:offs[n] + p.numel()].view(p.shape)
+            seg.copy_(p.data)
+            p.data = seg
+        self._flat, self._offs, self._total = flat, offs, total
+        self._shapes = {n: tuple(p.shape) for n, p in params}
+        self._gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+        # weight-decay mask per 256-chunk following the reference's name filter (pipeline_utils.py:537)
+        flags = torch.zeros(total // _SEG, dtype=torch.uint8)
+        for n, p in params:
+            if (".weight" in n) and ("lrnorm" not in n):
+                flags[offs[n] // _SEG:(offs[n] + _align(p.numel())) // _SEG] = 1
+        self._wd_flags = flags.to(dev)
+        # ---- Linear descriptors + shadow layout
+        lin = [("pe", "patchembed.projection.0", 0)]
+        for i in range(self.depth):
+            lin += [(f"qkv{i}", f"encoder.{i}.0.fn.eb_mha.qkv", self.num_heads),
+                    (f"proj{i}", f"encoder.{i}.0.fn.eb_mha.projection", 0),
+                    (f"fc1{i}", f"encoder.{i}.1.fn.eb_ffb.0", 0), (f"fc2{i}", f"encoder.{i}.1.fn.eb_ffb.3", 0)]
+        lin += [("h1", "classhead.ch_linear1", 0), ("h2", "classhead.ch_linear2", 0)]
+        descs = (L.LinearDesc * len(lin))()
+        self._sh_off, so, bo = {}, 0, 0
+        for k, (key, name, ph) in enumerate(lin):
+            Nn, Kk = self._shapes[name + ".weight"]
+            ws, wst = so, so + _align(Nn * Kk)
+            so = wst + _align(Nn * Kk)
+            bp = bo
+            if ph:
+                bo += _align(Nn)
+            descs[k] = L.LinearDesc(offs[name + ".weight"], offs[name + ".bias"], ws, wst, bp, Nn, Kk, ph, 0)
+            self._sh_off[key] = (ws, wst, bp)
+        self._ndesc, self._sh_total = len(lin), so
+        self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        self._bias_perm = torch.zeros(max(bo, 1), device=dev, dtype=torch.float32)
+        self._shadow = {}
+        self._conv16 = self.patchembed.conv_Y.to(dev).contiguous()
+        self._pos = sincos_table(14, 14, self.emb_size, dev)
+        # names in the field order of BlockGrads / HeadGrads
+        self._block_names, self._block_param_order, self._bparams_by_dtype = [], [], {}
+        for i in range(self.depth):
+            a, b = f"encoder.{i}.0.fn.", f"encoder.{i}.1.fn."
+            self._block_names.append([a + "eb_lrnorm1.weight", a + "eb_lrnorm1.bias", b + "eb_lrnorm2.weight",
+                                      b + "eb_lrnorm2.bias", a + "eb_mha.qkv.weight", a + "eb_mha.qkv.bias",
+                                      a + "eb_mha.projection.weight", a + "eb_mha.projection.bias",
+                                      b + "eb_ffb.0.weight", b + "eb_ffb.0.bias", b + "eb_ffb.3.weight",
+                                      b + "eb_ffb.3.bias"])
+            self._block_param_order.append([n for n in self._names() if n.startswith(f"encoder.{i}.")])
+        self._head_names = ["classhead.ch_lrnorm.weight", "classhead.ch_lrnorm.bias", "classhead.ch_linear1.weight",
+                            "classhead.ch_linear1.bias", "classhead.ch_linear2.weight", "classhead.ch_linear2.bias"]
+        self._head_param_order = [n for n in self._names() if n.startswith("classhead.")]
+        self._arenas = {}
+        self._named = dict(params)
+        self._probe_params = [params[0], params[len(params) // 2], params[-1]]
+
+    def _ensure_flat(self):
+        ok = self._flat is not None
+        if ok:
+            base, end = self._flat.data_ptr(), self._flat.data_ptr() + self._flat.numel() * 4
+            for n, p in self._probe_params:
+                if p.data_ptr() != base + self._offs[n] * 4:
+                    ok = False
+                    break
+        if not ok:
+            self._flatten()
+
+    def _pptr(self, name):
+        return self._flat.data_ptr() + self._offs[name] * 4
+
+    def _sh_ptr(self, key, which):
+        sh = self._shadow[self._cur_dtype]
+        ws, wst, _ = self._sh_off[key]
+        return sh.data_ptr() + (ws if which == "ws" else wst) * sh.element_size()
+
+    def _gview(self, gbuf, name):
+        n = 1
+        for s in self._shapes[name]:
+            n *= s
+        return gbuf[self._offs[name]:self._offs[name] + n].view(self._shapes[name])
+
+    def _prep(self, cdtype):
+        """fp32 masters -> operand shadows (cast, qkv de-interleave, transposes) for this step."""
+        if cdtype not in self._shadow:
+            self._shadow[cdtype] = torch.zeros(self._sh_total, device=self._flat.device, dtype=cdtype)
+        self._cur_dtype = cdtype
+        L.check(L.lib().rgbnm_prep_weights(L.dt_of(cdtype), self._descs_dev.data_ptr(), self._ndesc,
+                                           self._flat.data_ptr(), self._shadow[cdtype].data_ptr(),
+                                           self._bias_perm.data_ptr(), L.stream()), "prep_weights")
+        if cdtype not in self._bparams_by_dtype:
+            bps = []
+            for i in range(self.depth):
+                a, b = f"encoder.{i}.0.fn.", f"encoder.{i}.1.fn."
+                bps.append(L.BlockParams(
+                    self._pptr(a + "eb_lrnorm1.weight"), self._pptr(a + "eb_lrnorm1.bias"),
+                    self._pptr(b + "eb_lrnorm2.weight"), self._pptr(b + "eb_lrnorm2.bias"),
+                    self._bias_perm.data_ptr() + self._sh_off[f"qkv{i}"][2] * 4,
+                    self._pptr(a + "eb_mha.projection.bias"), self._pptr(b + "eb_ffb.0.bias"),
+                    self._pptr(b + "eb_ffb.3.bias"),
+                    self._sh_ptr(f"qkv{i}", "ws"), self._sh_ptr(f"qkv{i}", "wst"),
+                    self._sh_ptr(f"proj{i}", "ws"), self._sh_ptr(f"proj{i}", "wst"),
+                    self._sh_ptr(f"fc1{i}", "ws"), self._sh_ptr(f"fc1{i}", "wst"),
+                    self._sh_ptr(f"fc2{i}", "ws"), self._sh_ptr(f"fc2{i}", "wst")))
+            hp = L.HeadParams(self._pptr("classhead.ch_lrnorm.weight"), self._pptr("classhead.ch_lrnorm.bias"),
+                              self._pptr("classhead.ch_linear1.bias"), self._pptr("classhead.ch_linear2.bias"),
+                              self._sh_ptr("h1", "ws"), self._sh_ptr("h1", "wst"), self._sh_ptr("h2", "ws"),
+                              self._sh_ptr("h2", "wst"), self.n_classes, 0)
+            self._bparams_by_dtype[cdtype] = (bps, hp)
+        self._bparams, self._hparams = self._bparams_by_dtype[cdtype]
+
+    # ---------------------------------------------------------------- arenas
+    def _acquire_arena(self, B, cdtype, need_grad):
+        key = (B, cdtype, need_grad)
+        pool = self._arenas.setdefault(key, [])
+        return pool.pop() if pool else _Arena(self, B, cdtype, need_grad)
+
+    def _release_arena(self, arena):
+        pool = self._arenas.setdefault((arena.B, arena.cdtype, arena.need_grad), [])
+        if len(pool) < 2:
+            pool.append(arena)
+
+    def _grad_buffer(self):
+        """flat fp32 buffer the backward kernels write into; a fresh one if live .grad tensors still alias it
+        (gradient accumulation across several backward passes)."""
+        base, end = self._gflat.data_ptr(), self._gflat.data_ptr() + self._gflat.numel() * 4
+        for p in self.parameters():
+            if p.grad is not None and base <= p.grad.data_ptr() < end:
+                return torch.zeros_like(self._gflat)
+        return self._gflat
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, x, cbcr=None):
+        """x: Y coefficients (B,1,28,28,8,8); cbcr: (B,2,14,14,8,8); fp32 or bf16 (reference: plainvit.py:601-611)."""
+        if cbcr is None:
+            raise ValueError("DCT path needs both Y and CbCr tensors")
+        L.require_cuda(x, cbcr)
+        if x.dim() != 6 or x.shape[1:] != (1, 28, 28, 8, 8) or cbcr.shape[1:] != (2, 14, 14, 8, 8):
+            raise ValueError(f"expected Y (B,1,28,28,8,8) and CbCr (B,2,14,14,8,8), got {tuple(x.shape)} {tuple(cbcr.shape)}")
+        if x.dtype != cbcr.dtype:
+            raise TypeError("Y and CbCr must share a dtype")
+        cdtype = self.compute_dtype
+        if cdtype is None:
+            cdtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+        if cdtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"compute dtype {cdtype}: the MI355X path implements fp32 and bf16")
+        self._ensure_flat()
+        B = x.shape[0]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        self._prep(cdtype)
+        arena = self._acquire_arena(B, cdtype, need_grad)
+        st = _FwdState(self, arena, self._grad_buffer() if need_grad else None)
+        named = self._named
+        h = _PatchEmbedFn.apply(x, cbcr, st, named["patchembed.projection.0.weight"],
+                                named["patchembed.projection.0.bias"])
+        for i in range(self.depth):
+            h = _BlockFn.apply(h, st, i, *[named[n] for n in self._block_param_order[i]])
+        return _HeadFn.apply(h, st, *[named[n] for n in self._head_param_order])

@@ -1,0 +1,65 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol include/rgbnm.h declares,
+the drop-in module keeps the reference's state_dict surface, and the product path fails loudly (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import rgb_no_more_amd as rg
+from rgb_no_more_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "rgbnm.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgbnm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    dll = ctypes.CDLL(L.LIB_PATH)
+    for s in syms:
+        assert hasattr(dll, s), f"librgbnm.so does not export {s}"
+    # and the python prototypes cover exactly the header
+    assert sorted(L.PROTOTYPES) == syms
+    assert L.lib().rgbnm_abi_version() == 1
+    assert b"workspace" in L.lib().rgbnm_strerror(-3)
+
+
+def test_state_dict_surface_matches_reference(golden):
+    g = golden("g11_model.npz")
+    m = rg.ViT(3, 16, 192, depth=12, n_classes=1000, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
+    assert list(m.state_dict().keys()) == [str(s) for s in g["ti_d12_names"]]
+    assert len(m.state_dict()) == 152 and sum(p.numel() for p in m.parameters()) == 5642728
+    ms = rg.ViT(3, 16, 384, depth=12, n_classes=1000, drop_p=0.0, num_heads=6, head_size=64, pixel_space="DCT", ver=1)
+    assert sum(p.numel() for p in ms.parameters()) == 21975016
+    # the weight-decay name filter of pipeline_utils.py:537 selects the Linear weights only
+    sel = [n for n, _ in m.named_parameters() if (".weight" in n) and ("lrnorm" not in n)]
+    assert len(sel) == 1 + 12 * 4 + 2
+
+
+def test_no_cpu_fallback():
+    m = rg.ViT(3, 16, 192, depth=1, n_classes=10, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
+    y = torch.zeros(1, 1, 28, 28, 8, 8)
+    c = torch.zeros(1, 2, 14, 14, 8, 8)
+    with pytest.raises(L.RgbnmError):
+        m(y, c)
+    with pytest.raises(NotImplementedError):
+        rg.ViT(3, 16, 192, depth=1, pixel_space="RGB", drop_p=0.0, num_heads=3)
+    with pytest.raises(L.RgbnmError):
+        rg.cls_transforms.cross_entropy(torch.zeros(2, 10), torch.zeros(2, dtype=torch.int64))
+
+
+def test_conversion_matrix_matches_reference_golden(golden):
+    g = golden("g3_convmat.npz")
+    for ls, mlt in [(8, 2), (4, 2), (2, 4), (8, 1)]:
+        A = rg.dct_ops.generate_conversion_matrix(ls, mlt).numpy()
+        np.testing.assert_allclose(A, g[f"A_{ls}_{mlt}"], atol=1e-6)
+    t = rg.plainvit.sincos_table(14, 14, 192)
+    assert np.array_equal(t.numpy(), golden("g10_sincos.npz")["t192"])

@@ -1,0 +1,300 @@
+"""GPU parity: every C-ABI kernel of librgbnm.so vs the oracle (oracle/*.py, torch fp32 / numpy) on the same
+seeded inputs.  fp32 ("strict") mode carries the tight tolerances; bf16 tolerances are stated per test."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import rgb_no_more_amd as rg
+from rgb_no_more_amd import detfill, lib as L
+from oracle import vit_torch as V
+from oracle import dct_np as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTS = [torch.float32, torch.bfloat16]
+
+
+def dev(a, dt=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dt).contiguous()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def tol(dt, f32, bf16):
+    return f32 if dt == torch.float32 else bf16
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def gemm_nt(dt, epi, A, W, bias=None, R=None, pos=None, period=0, c_f32=False):
+    M, K = A.shape
+    N = W.shape[0]
+    Cc = torch.empty(M, N, device=DEV, dtype=torch.float32 if c_f32 else dt)
+    C2 = torch.empty(M, N, device=DEV, dtype=dt) if epi == L.EPI_GELU else None
+    L.check(L.lib().rgbnm_gemm_nt(L.dt_of(dt), epi, A.data_ptr(), K, W.data_ptr(), K, Cc.data_ptr(), N, L.ptr(bias),
+                                  L.ptr(R), N, L.ptr(C2), N, L.ptr(pos), period, M, N, K, int(c_f32), L.stream()))
+    return Cc, C2
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(256, 192, 192), (1568, 576, 192), (200, 1000, 192), (392, 192, 768),
+                                   (130, 192, 384), (64, 192, 1000), (300, 768, 192)])
+def test_gemm_nt_bias(dt, M, N, K):
+    A = dev(detfill.normalish((M, K), 1), dt)
+    W = dev(detfill.uniform((N, K), 2, -0.1, 0.1), dt)
+    b = dev(detfill.uniform((N,), 3))
+    out, _ = gemm_nt(dt, L.EPI_NONE, A, W, b)
+    ref = A.float() @ W.float().T + b
+    sync()
+    e = relerr(out, ref)
+    assert e < tol(dt, 2e-6, 4e-3), e
+    out32, _ = gemm_nt(dt, L.EPI_NONE, A, W, b, c_f32=True)
+    assert out32.dtype == torch.float32 and relerr(out32, ref) < tol(dt, 2e-6, 1e-5 if dt == torch.float32 else 2e-3)
+
+
+def test_gemm_nt_transpose_detecting():
+    # asymmetric operands, A = selector: catches row/col swaps of the accumulator layout
+    M, N, K = 128, 192, 64
+    A = torch.zeros(M, K, device=DEV)
+    for i in range(M):
+        A[i, (i * 7) % K] = 1.0
+    W = dev(detfill.uniform((N, K), 5))
+    out, _ = gemm_nt(torch.float32, L.EPI_NONE, A, W)
+    ref = A @ W.T
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_nt_epilogues(dt):
+    M, N, K = 392, 192, 192
+    A = dev(detfill.normalish((M, K), 11), dt)
+    W = dev(detfill.uniform((N, K), 12, -0.1, 0.1), dt)
+    b = dev(detfill.uniform((N,), 13))
+    R = dev(detfill.normalish((M, N), 14), dt)
+    base = A.float() @ W.float().T
+    t_hi = tol(dt, 5e-6, 6e-3)
+    out, _ = gemm_nt(dt, L.EPI_RES, A, W, b, R=R)
+    assert relerr(out, base + b + R.float()) < t_hi
+    out, u = gemm_nt(dt, L.EPI_GELU, A, W, b)
+    assert relerr(u, base + b) < t_hi
+    assert relerr(out, torch.nn.functional.gelu(u.float())) < tol(dt, 2e-6, 4e-3)
+    pos = dev(detfill.uniform((196, N), 15))
+    out, _ = gemm_nt(dt, L.EPI_POS, A, W, b, pos=pos, period=196)
+    rows = torch.arange(M, device=DEV) % 196
+    assert relerr(out, base + b + pos[rows]) < t_hi
+    x = R.float().clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    out, _ = gemm_nt(dt, L.EPI_DGELU, A, W, None, R=R)
+    assert relerr(out, base * x.grad) < t_hi
+    out, _ = gemm_nt(dt, L.EPI_TANH, A, W, b)
+    assert relerr(out, torch.tanh(base + b)) < t_hi
+    h = torch.tanh(R.float()).to(dt)
+    out, _ = gemm_nt(dt, L.EPI_DTANH, A, W, None, R=h)
+    assert relerr(out, base * (1 - h.float() ** 2)) < t_hi
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,No,Ki,heads", [(1568, 576, 192, 3), (392, 192, 768, 0), (392, 768, 192, 0),
+                                           (100, 1000, 192, 0), (260, 192, 384, 0), (50176 // 8, 1152, 384, 6)])
+def test_gemm_tn(dt, M, No, Ki, heads):
+    dY = dev(detfill.normalish((M, No), 21), dt)
+    X = dev(detfill.normalish((M, Ki), 22), dt)
+    dW = torch.full((No, Ki), 7.0, device=DEV)
+    db = torch.full((No,), 7.0, device=DEV)
+    wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
+    ws = torch.empty(wsb, device=DEV, dtype=torch.uint8)
+    L.check(L.lib().rgbnm_gemm_tn(L.dt_of(dt), dY.data_ptr(), No, X.data_ptr(), Ki, dW.data_ptr(), db.data_ptr(), M, No,
+                                  Ki, heads, 0, ws.data_ptr(), wsb, L.stream()))
+    ref = dY.float().T @ X.float()
+    rb = dY.float().sum(0)
+    if heads:
+        inner = heads * 64
+        n = torch.arange(No, device=DEV)
+        s3, rem = n // inner, n % inner
+        dst = (rem // 64) * 192 + (rem % 64) * 3 + s3
+        r2, b2 = torch.empty_like(ref), torch.empty_like(rb)
+        r2[dst] = ref
+        b2[dst] = rb
+        ref, rb = r2, b2
+    sync()
+    assert relerr(dW, ref) < tol(dt, 3e-6, 1e-5), relerr(dW, ref)   # inputs are exact in both modes; fp32 accumulate
+    assert relerr(db, rb) < 1e-5
+    # accumulate
+    L.check(L.lib().rgbnm_gemm_tn(L.dt_of(dt), dY.data_ptr(), No, X.data_ptr(), Ki, dW.data_ptr(), db.data_ptr(), M, No,
+                                  Ki, heads, 1, ws.data_ptr(), wsb, L.stream()))
+    assert relerr(dW, 2 * ref) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("E", [192, 384])
+def test_layernorm(dt, E):
+    M = 1000
+    x = dev(detfill.normalish((M, E), 31) * 2 + 0.5, dt)
+    g = dev(1 + detfill.uniform((E,), 32, -0.2, 0.2))
+    b = dev(detfill.uniform((E,), 33, -0.2, 0.2))
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    L.check(L.lib().rgbnm_layernorm_fwd(L.dt_of(dt), x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                        mean.data_ptr(), rstd.data_ptr(), M, E, 1e-5, L.stream()))
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (E,), gr, br, 1e-5)
+    assert relerr(y, yr) < tol(dt, 2e-6, 3e-3)
+    assert relerr(mean, xr.mean(1)) < 1e-5
+    dy = dev(detfill.normalish((M, E), 34), dt)
+    dres = dev(detfill.normalish((M, E), 35), dt)
+    yr.backward(dy.float())
+    dx = torch.empty_like(x)
+    dg, dbt = torch.empty(E, device=DEV), torch.empty(E, device=DEV)
+    wsb = L.lib().rgbnm_layernorm_bwd_workspace(M, E)
+    ws = torch.empty(wsb, device=DEV, dtype=torch.uint8)
+    L.check(L.lib().rgbnm_layernorm_bwd(L.dt_of(dt), dy.data_ptr(), x.data_ptr(), g.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), dres.data_ptr(), dx.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                                        M, E, 0, ws.data_ptr(), wsb, L.stream()))
+    assert relerr(dx, xr.grad + dres.float()) < tol(dt, 3e-6, 4e-3)
+    assert relerr(dg, gr.grad) < 1e-5 and relerr(dbt, br.grad) < 1e-5
+
+
+def ref_attention(qkv, B, N, H, scale):
+    I = H * 64
+    q, k, v = [qkv[:, i * I:(i + 1) * I].reshape(B, N, H, 64).permute(0, 2, 1, 3) for i in range(3)]
+    att = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    out = (att @ v).permute(0, 2, 1, 3).reshape(B * N, I)
+    lse = torch.logsumexp((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    return out, lse
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,N,H", [(3, 196, 3), (2, 196, 6), (2, 64, 3), (1, 100, 2)])
+def test_attention_fwd_bwd(dt, B, N, H):
+    I = H * 64
+    scale = 1.0 / math.sqrt(H * 64)
+    qkv = dev(detfill.normalish((B * N, 3 * I), 41) * 1.5, dt)
+    out = torch.empty(B * N, I, device=DEV, dtype=dt)
+    lse = torch.empty(B * H * N, device=DEV)
+    L.check(L.lib().rgbnm_attention_fwd(L.dt_of(dt), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, scale,
+                                        L.stream()))
+    qr = qkv.float().clone().requires_grad_(True)
+    oref, lref = ref_attention(qr, B, N, H, scale)
+    sync()
+    assert relerr(out, oref) < tol(dt, 3e-6, 6e-3), relerr(out, oref)
+    assert relerr(lse.view(B, H, N), lref) < tol(dt, 2e-6, 2e-3)
+    dout = dev(detfill.normalish((B * N, I), 42), dt)
+    oref.backward(dout.float())
+    dqkv = torch.full_like(qkv, float("nan"))
+    L.check(L.lib().rgbnm_attention_bwd(L.dt_of(dt), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                        dqkv.data_ptr(), B, N, H, scale, L.stream()))
+    sync()
+    assert torch.isfinite(dqkv.float()).all()
+    for i, nm in enumerate("qkv"):
+        e = relerr(dqkv[:, i * I:(i + 1) * I], qr.grad[:, i * I:(i + 1) * I])
+        assert e < tol(dt, 1e-5, 1.5e-2), (nm, e)
+
+
+def test_attention_spiked_scores():
+    # one query/key pair with a huge score: softmax must stay finite and exact (max-subtraction path)
+    B, N, H, dt = 1, 196, 3, torch.float32
+    I = H * 64
+    qkv = dev(detfill.normalish((B * N, 3 * I), 43) * 0.5)
+    qkv[17, :64] *= 40
+    qkv[101, I:I + 64] = qkv[17, :64]
+    out = torch.empty(B * N, I, device=DEV)
+    lse = torch.empty(B * H * N, device=DEV)
+    scale = 1 / math.sqrt(192)
+    L.check(L.lib().rgbnm_attention_fwd(0, qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, scale, L.stream()))
+    oref, _ = ref_attention(qkv, B, N, H, scale)
+    assert torch.isfinite(out).all() and relerr(out, oref) < 1e-5
+
+
+@pytest.mark.parametrize("odt", DTS)
+def test_subblock_embed_golden(golden, odt):
+    g = golden("g9_subblock.npz")
+    y = dev(detfill.normalish((2, 1, 4, 6, 8, 8), 61))
+    c = dev(detfill.normalish((2, 2, 2, 3, 8, 8), 62))
+    A = rg.dct_ops.generate_conversion_matrix(8, 2).to(DEV).contiguous()
+    np.testing.assert_allclose(A.cpu().numpy(), g["convY"], atol=2e-6)
+    feat = torch.empty(2 * 2 * 3, 384, device=DEV, dtype=odt)
+    L.check(L.lib().rgbnm_subblock_embed(0, L.dt_of(odt), y.data_ptr(), c.data_ptr(), A.data_ptr(), feat.data_ptr(), 2, 4,
+                                         6, 0, L.stream()))
+    ref = torch.from_numpy(g["feat"]).reshape(12, 384)
+    if odt == torch.float32:
+        # index shuffle bit-exact on the chroma half; A.X.A^T within fp32 round-off
+        assert torch.equal(feat[:, 256:].cpu(), ref[:, 256:])
+        assert (feat[:, :256].cpu() - ref[:, :256]).abs().max() < 5e-6
+    else:
+        assert torch.equal(feat[:, 256:].cpu(), ref[:, 256:].bfloat16())
+        assert relerr(feat, ref) < 3e-3
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_softxent(hard):
+    B, Cn = 37, 1000
+    z = dev(detfill.normalish((B, Cn), 51) * 3)
+    if hard:
+        t = torch.from_numpy(detfill.integers((B,), 52, 0, Cn - 1, np.int64)).to(DEV)
+    else:
+        tt = detfill.uniform((B, Cn), 53, 0, 1)
+        t = dev(tt / tt.sum(1, keepdims=True))
+    zr = z.clone().requires_grad_(True)
+    lr = torch.nn.CrossEntropyLoss()(zr, t)
+    lr.backward()
+    zz = z.clone().requires_grad_(True)
+    loss = rg.cls_transforms.cross_entropy(zz, t)
+    loss.backward()
+    assert abs(loss.item() - lr.item()) < 2e-6 * max(1, abs(lr.item()))
+    assert relerr(zz.grad, zr.grad) < 1e-5
+
+
+def test_mixup_golden(golden):
+    g = golden("g13_mixup.npz")
+    mix = rg.cls_transforms.RandomMixup_DCT(10, alpha=0.2)
+    lam = dev(g["lam"])
+    (my, mc), mt = mix((dev(g["y"]), dev(g["c"])), torch.from_numpy(g["lab"]).to(DEV), lam=lam)
+    np.testing.assert_allclose(my.cpu().numpy(), g["my"], atol=1e-6)
+    np.testing.assert_allclose(mc.cpu().numpy(), g["mc"], atol=1e-6)
+    np.testing.assert_allclose(mt.cpu().numpy(), g["mt"], atol=1e-6)
+    lam2 = mix.sample_lambda(DEV)
+    assert lam2[0] >= lam2[1] and abs(lam2.sum().item() - 1) < 1e-5
+
+
+def test_clip_adamw_wd_golden(golden):
+    g = golden("g12_optim.npz")
+    names = ["a.weight", "a.bias", "x_lrnorm.weight", "b.weight"]
+    shapes = [(5, 7), (5,), (7,), (3, 5)]
+    offs, total = [], 0
+    for s in shapes:
+        offs.append(total)
+        total += (int(np.prod(s)) + 255) // 256 * 256
+    p = torch.zeros(total, device=DEV)
+    gr, m, v = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    flags = torch.zeros(total // 256, dtype=torch.uint8)
+    for i, s in enumerate(shapes):
+        n = int(np.prod(s))
+        p[offs[i]:offs[i] + n] = dev(detfill.uniform(s, 81 + i)).reshape(-1)
+        if (".weight" in names[i]) and ("lrnorm" not in names[i]):
+            flags[offs[i] // 256] = 1
+    flags = flags.to(DEV)
+    ws = torch.empty(L.lib().rgbnm_clip_adamw_wd_workspace(), device=DEV, dtype=torch.uint8)
+    norm = torch.zeros(1, device=DEV)
+    lrs = [3e-3, 1.5e-3, 2.5e-3]
+    for it in range(3):
+        for i, s in enumerate(shapes):
+            n = int(np.prod(s))
+            gr[offs[i]:offs[i] + n] = dev(detfill.uniform(s, 91 + 10 * it + i, -2.0, 2.0)).reshape(-1)
+        L.check(L.lib().rgbnm_clip_adamw_wd_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                 flags.data_ptr(), total, lrs[it], 0.9, 0.999, 1e-8, it + 1,
+                                                 (lrs[it] / 3e-3) * 1e-4, 1.0, norm.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), L.stream()))
+        flat = np.concatenate([p[offs[i]:offs[i] + int(np.prod(s))].cpu().numpy() for i, s in enumerate(shapes)])
+        np.testing.assert_allclose(flat, g[f"p{it + 1}"], rtol=0, atol=3e-6)
+        assert abs(norm.item() - float(g[f"norm{it + 1}"])) < 1e-4

@@ -1,0 +1,174 @@
+"""GPU parity of the drop-in ViT (rgb_no_more_amd.plainvit.ViT) against golden logits/gradients captured from
+the reference model (tests/golden/g11_model.npz) and against the torch fp32 oracle.
+
+Tolerances (north_star: logits within 1e-3 of the reference):
+  * fp32 compute mode : |logits - reference| <= 1e-3 (measured ~1e-5), gradients rel 1e-3.
+  * bf16 compute mode : bf16 operands cannot meet 1e-3 against an fp32 reference (torch's own bf16 autocast of
+    the reference deviates ~7e-3); the stated bound is 2.5e-2 abs on logits of magnitude
+    <= 0.9 and the error must not exceed 2x the error of the oracle run under torch bf16 autocast.
+"""
+import numpy as np
+import pytest
+import torch
+
+import rgb_no_more_amd as rg
+from rgb_no_more_amd import detfill
+from oracle import vit_torch as V
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CASES = {"ti_d2": (192, 3, 2, 2), "ti_d12": (192, 3, 12, 4), "s_d2": (384, 6, 2, 2)}
+
+
+def build(tag, compute=None):
+    emb, heads, depth, B = CASES[tag]
+    m = rg.ViT(3, 16, emb, depth=depth, n_classes=1000, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
+               pixel_space="DCT", ver=1, use_subblock=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = detfill.fill_state_dict(shapes, base_seed=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.compute_dtype = compute
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 73, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    return m, sd, y, c, tgt
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_fp32_logits_and_grads_vs_reference_golden(golden, tag):
+    g = golden("g11_model.npz")
+    m, sd, y, c, tgt = build(tag, torch.float32)
+    assert [str(s) for s in g[tag + "_names"]] == list(m.state_dict().keys())
+    m.train()
+    logits = m(y, c)
+    assert logits.dtype == torch.float32 and logits.shape == (y.shape[0], 1000)
+    err = np.abs(logits.detach().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] fp32 max |dlogit| = {err:.3e}")
+    assert err <= 1e-3          # north_star tolerance
+    assert err <= 5e-5          # what exact-fp32 MFMA actually delivers
+    loss = rg.cls_transforms.cross_entropy(logits, tgt)
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-5
+    loss.backward()
+    names = [n for n, _ in m.named_parameters()]
+    gn = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=1e-3, atol=1e-7)
+    named = dict(m.named_parameters())
+    for nm in ("patchembed.projection.0.weight", "encoder.0.0.fn.eb_mha.qkv.weight", "encoder.0.0.fn.eb_mha.qkv.bias",
+               "encoder.1.1.fn.eb_ffb.3.weight", "encoder.0.0.fn.eb_lrnorm1.weight", "classhead.ch_linear2.bias"):
+        got = named[nm].grad.reshape(-1)[::37].cpu().numpy()
+        np.testing.assert_allclose(got, g[tag + "_grad_" + nm], rtol=2e-3, atol=3e-7, err_msg=nm)
+    # hard labels (benchmark.py semantics)
+    m.zero_grad()
+    lab = torch.from_numpy(detfill.integers((y.shape[0],), 74, 0, 998, np.int64)).to(DEV)
+    l2 = rg.cls_transforms.cross_entropy(m(y, c), lab)
+    assert abs(l2.item() - float(g[tag + "_loss_int"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["ti_d2", "ti_d12"])
+def test_bf16_logits_vs_reference_golden(golden, tag):
+    g = golden("g11_model.npz")
+    m, sd, y, c, tgt = build(tag, None)
+    m.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = m(y, c)
+    ref = g[tag + "_logits"]
+    err = np.abs(logits.detach().cpu().numpy() - ref).max()
+    # the oracle under torch's own bf16 autocast on CPU, same weights/inputs
+    emb, heads, depth, B = CASES[tag]
+    p = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lo = V.vit_forward(p, y.cpu(), c.cpu(), depth, heads, emb).float()
+    err_autocast = np.abs(lo.numpy() - ref).max()
+    print(f"[{tag}] bf16 max |dlogit| ours = {err:.3e}, torch-autocast oracle = {err_autocast:.3e}")
+    assert err <= 2.5e-2
+    assert err <= 2.0 * err_autocast + 2e-3
+    loss = rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16)
+    loss.backward()
+    gn = np.array([pp.grad.double().norm().item() for _, pp in m.named_parameters()])
+    rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    print(f"[{tag}] bf16 grad-norm rel err: median {np.median(rel):.3e} max {rel.max():.3e}")
+    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+
+
+def test_eval_no_grad_matches_train_forward():
+    m, sd, y, c, tgt = build("ti_d2", torch.float32)
+    m.train()
+    a = m(y, c).detach().clone()
+    m.eval()
+    with torch.no_grad():
+        b = m(y, c)
+    assert torch.equal(a, b)
+
+
+def test_training_steps_track_oracle_fp32():
+    """3 optimizer steps (clip + AdamW + WeightDecay, train.py:153-176) in fp32: loss curve and weights follow
+    the oracle (torch autograd + oracle optimizer restatement)."""
+    tag = "ti_d2"
+    emb, heads, depth, B = CASES[tag]
+    m, sd, y, c, tgt = build(tag, torch.float32)
+    opt = rg.custom_optims.FusedClipAdamWWD(m, lr=3e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
+    names = list(sd.keys())
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    mm = [np.zeros_like(sd[k]) for k in names]
+    vv = [np.zeros_like(sd[k]) for k in names]
+    mask = [(".weight" in n) and ("lrnorm" not in n) for n in names]
+    yc, cc, tc = y.cpu(), c.cpu(), tgt.cpu()
+    for step in range(1, 4):
+        opt.zero_grad()
+        loss = rg.cls_transforms.cross_entropy(m(y, c), tgt)
+        loss.backward()
+        opt.step()
+        for k in names:
+            p[k].grad = None
+        lo = V.soft_xent(V.vit_forward(p, yc, cc, depth, heads, emb), tc)
+        lo.backward()
+        assert abs(loss.item() - lo.item()) < 2e-5, (step, loss.item(), lo.item())
+        params = [p[k].detach().numpy() for k in names]
+        grads = [p[k].grad.numpy() for k in names]
+        tn = V.clip_adamw_wd_step(params, grads, mm, vv, step, 3e-3, 3e-3, 1e-4, mask)
+        assert abs(opt.last_norm.item() - tn) < 1e-3 * max(1.0, tn)
+    got = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    worst = max(np.abs(got[k] - p[k].detach().numpy()).max() for k in names)
+    print(f"max |w - w_oracle| after 3 steps = {worst:.3e}")
+    # Adam's first steps are sign-like (|update| ~ lr): elements whose gradient is ~0 can flip; bound loosely
+    assert worst < 2e-3
+    med = np.median(np.concatenate([np.abs(got[k] - p[k].detach().numpy()).reshape(-1) for k in names]))
+    assert med < 1e-6
+
+
+def test_grad_accumulation_two_backwards():
+    m, sd, y, c, tgt = build("ti_d2", torch.float32)
+    l1 = rg.cls_transforms.cross_entropy(m(y, c), tgt)
+    l1.backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    l2 = rg.cls_transforms.cross_entropy(m(y, c), tgt)
+    l2.backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-5, atol=1e-8), n
+
+
+def test_state_dict_roundtrip_and_torch_optimizers():
+    """The module behaves like an ordinary nn.Module: torch.optim.AdamW + reference-style WeightDecay work."""
+    m, sd, y, c, tgt = build("ti_d2", torch.float32)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0, eps=1e-8)
+    wd = rg.custom_optims.WeightDecay([p for n, p in m.named_parameters() if (".weight" in n) and ("lrnorm" not in n)],
+                                      lr=1e-3, weight_decay=1e-4)
+    l0 = None
+    for _ in range(3):
+        opt.zero_grad()
+        loss = rg.cls_transforms.cross_entropy(m(y, c), tgt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1)
+        opt.step()
+        wd.step()
+        l0 = l0 or loss.item()
+    assert loss.item() < l0
+    sd2 = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = rg.ViT(3, 16, 192, depth=2, n_classes=1000, drop_p=0.0, device=DEV, num_heads=3, head_size=64,
+                pixel_space="DCT", ver=1)
+    m2.load_state_dict(sd2)
+    m2.compute_dtype = torch.float32
+    with torch.no_grad():
+        assert torch.equal(m2(y, c), m(y, c))
