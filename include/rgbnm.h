@@ -36,6 +36,10 @@ extern "C" {
 #define RGBNM_EPI_DTANH 6  /* C = (A.W^T) * (1 - R^2)                                             */
 
 int rgbnm_abi_version(void);
+/* runtime switches (A/B testing, profiling): "nt_staged" (coalesced LDS-staged GEMM epilogue, default 1),
+ * "tn_tr" (ds_read_b64_tr_b16 fragment loads in the weight-gradient GEMM, default 1), "trace" (0). */
+int rgbnm_set_option(const char* name, int value);
+int rgbnm_get_option(const char* name);
 /* human readable text for a negative return code */
 const char* rgbnm_strerror(int code);
 

@@ -29,14 +29,22 @@ struct GemmNT {
 constexpr int BM = 128;
 constexpr int PITCH_B = 144;  // bytes per LDS tile row
 
-template <typename T, int NB, int EPI>
+// STAGED (bf16 only): the MFMA is issued with operands swapped (D rows <-> weight rows, D cols <-> tokens) so a
+// lane owns ONE token and 4 consecutive output features per register quad; the tile is rounded to bf16 into LDS
+// (8-byte writes, pitch BN+4 elements: conflict free) and leaves the CU as coalesced 16-byte rows, where the
+// residual / GELU / dGELU operands are also read as 16-byte vectors.
+template <typename T, int NB, int EPI, bool STAGED>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   constexpr int BN = 64 * NB;
+  constexpr int CP = BN + 4;                    // staging pitch (elements)
+  constexpr int TILE_BYTES = (BM + BN) * PITCH_B;
+  constexpr int STAGE_BYTES = STAGED ? BM * CP * 2 : 0;
+  constexpr int SMEM_BYTES = TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES;
   constexpr int EPV = 16 / (int)sizeof(T);      // elements per 16-byte vector
   constexpr int BK = 128 / (int)sizeof(T);      // elements per k-tile row
   constexpr int PE = PITCH_B / (int)sizeof(T);  // LDS pitch in elements
   constexpr int CH = 32 / (int)sizeof(T);       // elements per 32-byte mma chunk
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * PITCH_B];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   T* As = reinterpret_cast<T*>(smem);
   T* Bs = reinterpret_cast<T*>(smem + BM * PITCH_B);
 
@@ -113,7 +121,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) mma(acc[a][b], fa[a], fb[b]);
+        for (int b = 0; b < NB; ++b) {
+          if (STAGED) mma(acc[a][b], fb[b], fa[a]);
+          else mma(acc[a][b], fa[a], fb[b]);
+        }
     }
     __syncthreads();
     if (kt + 1 < KT) {
@@ -122,7 +133,74 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     }
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------
+  if constexpr (STAGED) {
+    // ---- pass 1: registers -> LDS (bf16(acc + bias [+ pos])) ; lane = token, quad = 4 features ----
+    bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ml = wm * 64 + a * 32 + l31;
+      int prow = m0 + ml;
+      prow = prow < p.M ? prow : p.M - 1;
+      const float* posr = (EPI == EPI_POS) ? p.pos + (size_t)(prow % p.pos_period) * p.N : nullptr;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = wn * 32 * NB + b * 32 + 8 * q + 4 * g;
+          int nc = n0 + nl;
+          nc = nc + 4 <= p.N ? nc : 0;
+          f32x4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+          if (p.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + nc);
+            v += bv;
+          }
+          if (EPI == EPI_POS) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(posr + nc);
+            v += pv;
+          }
+          store4<bf16>(Cs + ml * CP + nl, v);
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: LDS -> global, 8 features (16 B) per thread-iteration, rows fully coalesced ----
+    constexpr int VPR = BN / 8;
+    bf16* C = reinterpret_cast<bf16*>(p.C);
+    const bf16* R = reinterpret_cast<const bf16*>(p.R);
+    bf16* C2 = reinterpret_cast<bf16*>(p.C2);
+#pragma unroll 4
+    for (int i = 0; i < BM * VPR / 256; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / VPR, vec = idx % VPR;
+      const int gm = m0 + row, gn = n0 + vec * 8;
+      if (gm >= p.M || gn >= p.N) continue;
+      const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(Cs + row * CP + vec * 8);
+      const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(Cs + row * CP + vec * 8 + 4);
+      bf16x8 cv = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      if (EPI == EPI_GELU) *reinterpret_cast<bf16x8*>(C2 + (size_t)gm * p.ldc2 + gn) = cv;
+      if (EPI != EPI_NONE && EPI != EPI_POS) {
+        bf16x8 rv;
+        if (EPI == EPI_RES || EPI == EPI_DGELU || EPI == EPI_DTANH)
+          rv = *reinterpret_cast<const bf16x8*>(R + (size_t)gm * p.ldr + gn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = (float)cv[e];
+          if (EPI == EPI_RES) v += (float)rv[e];
+          if (EPI == EPI_GELU) v = gelu_f(v);
+          if (EPI == EPI_DGELU) v *= dgelu_f((float)rv[e]);
+          if (EPI == EPI_TANH) v = tanhf(v);
+          if (EPI == EPI_DTANH) {
+            const float h = (float)rv[e];
+            v *= (1.f - h * h);
+          }
+          cv[e] = (bf16)v;
+        }
+      }
+      *reinterpret_cast<bf16x8*>(C + (size_t)gm * p.ldc + gn) = cv;
+    }
+    return;
+  }
+
+  // ---- direct epilogue (fp32 mode, fp32 outputs, ragged N) --------------------------------------
   T* C = reinterpret_cast<T*>(p.C);
   float* Cf = reinterpret_cast<float*>(p.C);
   const T* R = reinterpret_cast<const T*>(p.R);
@@ -158,17 +236,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   }
 }
 
-template <typename T, int NB>
+template <typename T, int NB, bool STAGED>
 int launch_nt_epi(const GemmNT& p, int epi, hipStream_t st) {
   const int grid = ((p.mtiles + 7) / 8) * 8 * p.ntiles;
   switch (epi) {
-#define CASE(E) case E: hipLaunchKernelGGL((gemm_nt_kernel<T, NB, E>), dim3(grid), dim3(256), 0, st, p); break;
+#define CASE(E) case E: hipLaunchKernelGGL((gemm_nt_kernel<T, NB, E, STAGED>), dim3(grid), dim3(256), 0, st, p); break;
     CASE(EPI_NONE) CASE(EPI_RES) CASE(EPI_GELU) CASE(EPI_POS) CASE(EPI_DGELU) CASE(EPI_TANH) CASE(EPI_DTANH)
 #undef CASE
     default: return RGBNM_EINVAL;
   }
   LAUNCH_CHECK();
   return RGBNM_OK;
+}
+
+template <typename T, int NB>
+int launch_nt_sel(const GemmNT& p, int epi, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    const bool ok = !p.c_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!p.R || p.ldr % 8 == 0) &&
+                    (!p.C2 || p.ldc2 % 8 == 0) && rgbnm_get_option("nt_staged");
+    if (ok) return launch_nt_epi<T, NB, true>(p, epi, st);
+  }
+  return launch_nt_epi<T, NB, false>(p, epi, st);
 }
 
 template <typename T>
@@ -179,10 +267,10 @@ int launch_nt(GemmNT p, int epi, hipStream_t st) {
   p.mtiles = cdiv(p.M, BM);
   if (p.N % 192 == 0) {
     p.ntiles = p.N / 192;
-    return launch_nt_epi<T, 3>(p, epi, st);
+    return launch_nt_sel<T, 3>(p, epi, st);
   }
   p.ntiles = cdiv(p.N, 128);
-  return launch_nt_epi<T, 2>(p, epi, st);
+  return launch_nt_sel<T, 2>(p, epi, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,7 +291,47 @@ template <typename T> __device__ __forceinline__ Frag<T> gather_frag(const T* ba
   return f;
 }
 
-template <typename T, int NB>
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the address of 4 contiguous bf16 (row i>>2 of a
+// 4 x 16 block, columns 4*(i&3)..+3) and receives column i of that block (4 rows).  With tiles stored in their
+// natural [token][feature] layout this hands every lane 4 tokens of ITS feature: two reads = one MFMA fragment
+// (8 reduction slots), instead of 8 strided 2-byte reads.  A and B fragments use the same token<->slot mapping.
+__device__ __forceinline__ bf16x8 tr_pack(u32x2 lo, u32x2 hi) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NB, int PAB, int PBB>   // pitches in BYTES
+__device__ __forceinline__ void tr_load_chunk(unsigned addrA, unsigned addrB, Frag<bf16> (&fa)[2], Frag<bf16> (&fb)[NB]) {
+  u32x2 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h, b2l, b2h;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %10\n\t"
+      "ds_read_b64_tr_b16 %1, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:64\n\t"
+      "ds_read_b64_tr_b16 %3, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %11\n\t"
+      "ds_read_b64_tr_b16 %5, %11 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:64\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%15\n\t"
+      "ds_read_b64_tr_b16 %8, %11 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %9, %11 offset:%17\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h), "=&v"(b2l),
+        "=&v"(b2h)
+      : "v"(addrA), "v"(addrB), "i"(4 * PAB), "i"(64 + 4 * PAB), "i"(4 * PBB), "i"(64 + 4 * PBB),
+        "i"(NB == 3 ? 128 : 0), "i"(NB == 3 ? 128 + 4 * PBB : 4 * PBB)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  fa[0].v = tr_pack(a0l, a0h);
+  fa[1].v = tr_pack(a1l, a1h);
+  fb[0].v = tr_pack(b0l, b0h);
+  fb[1].v = tr_pack(b1l, b1h);
+  if constexpr (NB == 3) fb[2].v = tr_pack(b2l, b2h);
+}
+
+template <typename T, int NB, bool TR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   constexpr int BN = 64 * NB;
   constexpr int EPV = 16 / (int)sizeof(T);
@@ -285,10 +413,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
       for (int c = 0; c < 4; ++c) {
         Frag<T> fa[2], fb[NB];
         const int trow = c * 2 * EPL + g * EPL;
+        if constexpr (TR) {
+          const int tr = trow + ((lane & 15) >> 2);
+          const int fc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+          const unsigned aA = (unsigned)(size_t)(Ys + tr * PA + wm * 64 + fc);
+          const unsigned aB = (unsigned)(size_t)(Xs + tr * PB + wn * 32 * NB + fc);
+          tr_load_chunk<NB, PA * 2, PB * 2>(aA, aB, fa, fb);
+        } else {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) fa[a] = gather_frag<T>(Ys + trow * PA + wm * 64 + a * 32 + l31, PA);
+          for (int a = 0; a < 2; ++a) fa[a] = gather_frag<T>(Ys + trow * PA + wm * 64 + a * 32 + l31, PA);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) fb[b] = gather_frag<T>(Xs + trow * PB + wn * 32 * NB + b * 32 + l31, PB);
+          for (int b = 0; b < NB; ++b) fb[b] = gather_frag<T>(Xs + trow * PB + wn * 32 * NB + b * 32 + l31, PB);
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -331,16 +467,27 @@ __device__ __forceinline__ int qkv_row(int n, int heads) {
   return h * 192 + d * 3 + s3;
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int rows,
-                                       int cols, int perm_heads, int accumulate) {
+// one launch reduces the weight partials [S][rows][cols] and (optionally) the bias partials [S][rows]
+__global__ void reduce_partials_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
+                                       float* __restrict__ out, float* __restrict__ bout, int S, int rows, int cols,
+                                       int perm_heads, int accumulate) {
   const long long n = (long long)rows * cols;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+  const long long nt = n + (bpart ? rows : 0);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nt; i += (long long)gridDim.x * blockDim.x) {
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(size_t)s * n + i];
-    const int r = (int)(i / cols), c = (int)(i % cols);
-    const int orow = perm_heads > 0 ? qkv_row(r, perm_heads) : r;
-    float* o = out + (size_t)orow * cols + c;
-    *o = accumulate ? (*o + a) : a;
+    if (i < n) {
+#pragma unroll 4
+      for (int s = 0; s < S; ++s) a += part[(size_t)s * n + i];
+      const int r = (int)(i / cols), c = (int)(i % cols);
+      const int orow = perm_heads > 0 ? qkv_row(r, perm_heads) : r;
+      float* o = out + (size_t)orow * cols + c;
+      *o = accumulate ? (*o + a) : a;
+    } else {
+      const int r = (int)(i - n);
+      for (int s = 0; s < S; ++s) a += bpart[(size_t)s * rows + r];
+      float* o = bout + (perm_heads > 0 ? qkv_row(r, perm_heads) : r);
+      *o = accumulate ? (*o + a) : a;
+    }
   }
 }
 
@@ -360,18 +507,23 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   S = cdiv(ktiles, kt_per);
   p.S = S;
   p.tok_per_split = kt_per * TK;
-  if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3>), dim3(tiles, S), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_tn_kernel<T, 2>), dim3(tiles, S), dim3(256), 0, st, p);
-  LAUNCH_CHECK();
-  const long long n = (long long)p.No * p.Ki;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(2048LL, cdivl(n, 256))), dim3(256), 0, st, p.part, dW, S,
-                     p.No, p.Ki, perm_heads, accumulate);
-  LAUNCH_CHECK();
-  if (db) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.No, 256)), dim3(256), 0, st, p.bpart, db, S, p.No, 1,
-                       perm_heads, accumulate);
-    LAUNCH_CHECK();
+  bool tr = false;
+  if constexpr (sizeof(T) == 2) tr = rgbnm_get_option("tn_tr") != 0;
+  if constexpr (sizeof(T) == 2) {
+    if (tr) {
+      if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3, true>), dim3(tiles, S), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_tn_kernel<T, 2, true>), dim3(tiles, S), dim3(256), 0, st, p);
+    }
   }
+  if (!tr) {
+    if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3, false>), dim3(tiles, S), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<T, 2, false>), dim3(tiles, S), dim3(256), 0, st, p);
+  }
+  LAUNCH_CHECK();
+  const long long n = (long long)p.No * p.Ki + (db ? p.No : 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(2048LL, cdivl(n, 256))), dim3(256), 0, st, p.part,
+                     db ? p.bpart : nullptr, dW, db, S, p.No, p.Ki, perm_heads, accumulate);
+  LAUNCH_CHECK();
   return RGBNM_OK;
 }
 

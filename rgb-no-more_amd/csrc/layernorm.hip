@@ -127,15 +127,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-__global__ void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                 int nblk, int E, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * E) return;
+// 32 columns per workgroup, 8 row-groups stride through the partial blocks (fixed order => deterministic)
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int nblk, int E, int accumulate) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + cl;          // 2E is a multiple of 32
   const int which = e / E, c = e % E;
   float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += part[((size_t)b * 2 + which) * E + c];
-  float* o = (which == 0 ? dgamma : dbeta) + c;
-  *o = accumulate ? (*o + a) : a;
+  for (int b = rg; b < nblk; b += 8) a += part[((size_t)b * 2 + which) * E + c];
+  red[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    float* o = (which == 0 ? dgamma : dbeta) + c;
+    *o = accumulate ? (*o + t) : t;
+  }
 }
 
 // ---- head pooling: pooled[b] = mean_t LN(x[b,t,:])  (one workgroup per image) ------------------------
@@ -275,7 +284,7 @@ int ln_bwd_t(const void* dy, const void* x, const float* g, const float* mean, c
   else if (E == 384) hipLaunchKernelGGL((ln_bwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(2 * E, 256)), dim3(256), 0, st, ws, dgamma, dbeta, grid, E, accumulate);
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 32), dim3(256), 0, st, ws, dgamma, dbeta, grid, E, accumulate);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
@@ -338,7 +347,7 @@ int rgbnm_head_pool_bwd(int dtype, const void* dpooled, const void* x, const flo
   else return RGBNM_EINVAL;
 #undef POOLB
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(2 * E, 256)), dim3(256), 0, st, ws, dgamma, dbeta, B, E, accumulate);
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 32), dim3(256), 0, st, ws, dgamma, dbeta, B, E, accumulate);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

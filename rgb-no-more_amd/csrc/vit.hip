@@ -12,9 +12,26 @@
 
 static inline size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
+#include <string.h>
+namespace {
+struct Opt { const char* name; int value; };
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"trace", 0}};
+}
+
 extern "C" {
 
 int rgbnm_abi_version(void) { return RGBNM_ABI_VERSION; }
+
+int rgbnm_set_option(const char* name, int value) {
+  for (auto& o : g_opts)
+    if (name && !strcmp(o.name, name)) { o.value = value; return RGBNM_OK; }
+  return RGBNM_EINVAL;
+}
+int rgbnm_get_option(const char* name) {
+  for (auto& o : g_opts)
+    if (name && !strcmp(o.name, name)) return o.value;
+  return -1;
+}
 
 const char* rgbnm_strerror(int code) {
   switch (code) {

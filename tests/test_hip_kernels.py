@@ -298,3 +298,31 @@ def test_clip_adamw_wd_golden(golden):
         flat = np.concatenate([p[offs[i]:offs[i] + int(np.prod(s))].cpu().numpy() for i, s in enumerate(shapes)])
         np.testing.assert_allclose(flat, g[f"p{it + 1}"], rtol=0, atol=3e-6)
         assert abs(norm.item() - float(g[f"norm{it + 1}"])) < 1e-4
+
+
+# ---- both code paths of the runtime switches stay parity-green ------------------------------------------
+@pytest.fixture
+def option():
+    saved = {}
+
+    def set_(name, val):
+        saved.setdefault(name, L.lib().rgbnm_get_option(name.encode()))
+        L.check(L.lib().rgbnm_set_option(name.encode(), val))
+    yield set_
+    for k, v in saved.items():
+        L.lib().rgbnm_set_option(k.encode(), v)
+
+
+@pytest.mark.parametrize("staged", [0, 1])
+def test_gemm_nt_bf16_epilogue_paths(option, staged):
+    option("nt_staged", staged)
+    test_gemm_nt_epilogues(torch.bfloat16)
+    for shp in [(1568, 576, 192), (200, 1000, 192), (64, 192, 1000), (300, 768, 192)]:
+        test_gemm_nt_bias(torch.bfloat16, *shp)
+
+
+@pytest.mark.parametrize("tr", [0, 1])
+def test_gemm_tn_bf16_fragment_paths(option, tr):
+    option("tn_tr", tr)
+    for shp in [(1568, 576, 192, 3), (392, 192, 768, 0), (100, 1000, 192, 0), (260, 192, 384, 0)]:
+        test_gemm_tn(torch.bfloat16, *shp)
