@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-images", type=int, default=96)
     ap.add_argument("--trace", action="store_true", help="per-kernel HIP-event timing of the timed region")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B experiments)")
     return ap.parse_args()
 
 
@@ -94,6 +95,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
+    for o in a.opt:
+        k, v = o.split("=")
+        L.check(L.lib().rgbnm_set_option(k.encode(), int(v)), f"option {k}")
     emb, heads = ARCH[a.arch]
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(1234 + rank)

@@ -83,6 +83,31 @@ template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v) {
   *reinterpret_cast<typename Vec4<T>::type*>(p) = o;
 }
 
+// bf16-path GELU: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution) with the hardware
+// exp/rcp; one exponential serves both the cdf and the pdf (exp(-(x/sqrt2)^2) = exp(-x^2/2)).
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float e = __expf(-ax * ax);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfa = fmaf(-poly * t, e, 1.0f);        // erf(|x|/sqrt2)
+  cdf = 0.5f * (1.0f + copysignf(erfa, x));
+  pdf_x = 0.39894228040143267794f * e * x;            // x * phi(x)
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float c, p;
+  gelu_parts_fast(x, c, p);
+  return x * c;
+}
+__device__ __forceinline__ float dgelu_fast(float x) {
+  float c, p;
+  gelu_parts_fast(x, c, p);
+  return c + p;
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

@@ -167,10 +167,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     bf16* C = reinterpret_cast<bf16*>(p.C);
     const bf16* R = reinterpret_cast<const bf16*>(p.R);
     bf16* C2 = reinterpret_cast<bf16*>(p.C2);
+    int row = tid / VPR, vec = tid % VPR;
 #pragma unroll 4
-    for (int i = 0; i < BM * VPR / 256; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / VPR, vec = idx % VPR;
+    for (int i = 0; i < BM * VPR / 256; ++i, row += 256 / VPR, vec += 256 % VPR) {
+      if (vec >= VPR) { vec -= VPR; row += 1; }
       const int gm = m0 + row, gn = n0 + vec * 8;
       if (gm >= p.M || gn >= p.N) continue;
       const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(Cs + row * CP + vec * 8);
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         for (int e = 0; e < 8; ++e) {
           float v = (float)cv[e];
           if (EPI == EPI_RES) v += (float)rv[e];
-          if (EPI == EPI_GELU) v = gelu_f(v);
-          if (EPI == EPI_DGELU) v *= dgelu_f((float)rv[e]);
+          if (EPI == EPI_GELU) v = gelu_fast(v);
+          if (EPI == EPI_DGELU) v *= dgelu_fast((float)rv[e]);
           if (EPI == EPI_TANH) v = tanhf(v);
           if (EPI == EPI_DTANH) {
             const float h = (float)rv[e];
@@ -345,7 +345,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   T* Ys = reinterpret_cast<T*>(smem);
   T* Xs = Ys + TK * PA;
 
-  const int tile = blockIdx.x, s = blockIdx.y;
+  // 1-D grid, XCD-aware: all output tiles of one token split run on the same XCD (they re-read the same X rows)
+  const int ntile = p.rtiles * p.ctiles;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int tile = jj % ntile, s = (jj / ntile) * 8 + xcd;
+  if (s >= p.S) return;
   const int rt = tile / p.ctiles, ct = tile % p.ctiles;
   const int r0 = rt * BM, c0 = ct * BN;
   const int tok0 = s * p.tok_per_split;
@@ -502,7 +506,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   const int tiles = p.rtiles * p.ctiles;
   // split the token axis so that ~512 workgroups exist; each split is a whole number of k-tiles
   int ktiles = cdiv(p.M, TK);
-  int S = min(p.S, max(1, min(ktiles, cdiv(512, tiles))));
+  int S = min(p.S, max(1, min(ktiles, cdiv(rgbnm_get_option("tn_wgs"), tiles))));
   int kt_per = cdiv(ktiles, S);
   S = cdiv(ktiles, kt_per);
   p.S = S;
@@ -511,13 +515,13 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   if constexpr (sizeof(T) == 2) tr = rgbnm_get_option("tn_tr") != 0;
   if constexpr (sizeof(T) == 2) {
     if (tr) {
-      if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3, true>), dim3(tiles, S), dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_tn_kernel<T, 2, true>), dim3(tiles, S), dim3(256), 0, st, p);
+      if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3, true>), dim3(tiles * ((S + 7) / 8) * 8), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_tn_kernel<T, 2, true>), dim3(tiles * ((S + 7) / 8) * 8), dim3(256), 0, st, p);
     }
   }
   if (!tr) {
-    if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3, false>), dim3(tiles, S), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_tn_kernel<T, 2, false>), dim3(tiles, S), dim3(256), 0, st, p);
+    if (nb3) hipLaunchKernelGGL((gemm_tn_kernel<T, 3, false>), dim3(tiles * ((S + 7) / 8) * 8), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<T, 2, false>), dim3(tiles * ((S + 7) / 8) * 8), dim3(256), 0, st, p);
   }
   LAUNCH_CHECK();
   const long long n = (long long)p.No * p.Ki + (db ? p.No : 0);

@@ -130,18 +130,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // 32 columns per workgroup, 8 row-groups stride through the partial blocks (fixed order => deterministic)
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int nblk, int E, int accumulate) {
-  __shared__ float red[8][33];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + cl;          // 2E is a multiple of 32
+  __shared__ float red[32][9];
+  const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;   // 8 columns x 32 row groups per workgroup
+  const int e = blockIdx.x * 8 + cl;           // 2E is a multiple of 8
   const int which = e / E, c = e % E;
   float a = 0.f;
-  for (int b = rg; b < nblk; b += 8) a += part[((size_t)b * 2 + which) * E + c];
+  for (int b = rg; b < nblk; b += 32) a += part[((size_t)b * 2 + which) * E + c];
   red[rg][cl] = a;
   __syncthreads();
   if (rg == 0) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    for (int r = 0; r < 32; ++r) t += red[r][cl];
     float* o = (which == 0 ? dgamma : dbeta) + c;
     *o = accumulate ? (*o + t) : t;
   }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dpo
   }
 }
 
-constexpr int LN_BWD_BLOCKS = 512;
+constexpr int LN_BWD_BLOCKS = 512;   // 2 workgroups per CU
 
 template <typename T>
 int ln_fwd_t(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int E, float eps,
@@ -284,7 +284,7 @@ int ln_bwd_t(const void* dy, const void* x, const float* g, const float* mean, c
   else if (E == 384) hipLaunchKernelGGL((ln_bwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 32), dim3(256), 0, st, ws, dgamma, dbeta, grid, E, accumulate);
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 8), dim3(256), 0, st, ws, dgamma, dbeta, grid, E, accumulate);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
@@ -347,7 +347,7 @@ int rgbnm_head_pool_bwd(int dtype, const void* dpooled, const void* x, const flo
   else return RGBNM_EINVAL;
 #undef POOLB
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 32), dim3(256), 0, st, ws, dgamma, dbeta, B, E, accumulate);
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 8), dim3(256), 0, st, ws, dgamma, dbeta, B, E, accumulate);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

@@ -9,14 +9,18 @@ import sys
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    return name[:110]
+    return name[-110:] if ' g=' in name else name[:110]
 
 
-def main(path, out=None):
+def main(path, out=None, by_grid=False):
     con = sqlite3.connect(path)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
-    rows = cur.execute("select name, start, end from kernels").fetchall() if "name" in cols else []
+    gcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
+    if by_grid and gcol:
+        rows = cur.execute(f"select name || ' g=' || {gcol}, start, end from kernels").fetchall()
+    else:
+        rows = cur.execute("select name, start, end from kernels").fetchall() if "name" in cols else []
     agg = {}
     for name, s, e in rows:
         a = agg.setdefault(short(name), [0, 0.0, 1e30, 0.0])
@@ -37,4 +41,5 @@ def main(path, out=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    args = [a for a in sys.argv[1:] if a != "--by-grid"]
+    main(args[0], args[1] if len(args) > 1 else None, "--by-grid" in sys.argv)
