@@ -13,6 +13,7 @@
 // bank-conflict free (9*i mod 16 distinct).
 #include "common.h"
 #include "../../include/rgbnm.h"
+#include "internal.h"
 
 namespace {
 
@@ -504,6 +505,21 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   const bool nb3 = (p.Ki % 192 == 0);
   p.ctiles = nb3 ? p.Ki / 192 : cdiv(p.Ki, 128);
   const int tiles = p.rtiles * p.ctiles;
+  if constexpr (sizeof(T) == 2) {
+    if (rgbnm_get_option("tn_pipe")) {
+      int Sp = 0;
+      const int rc = rgbnm_launch_tn_pipe(p.dY, p.ldy, p.X, p.ldx, p.part, db ? p.bpart : nullptr, p.M, p.No, p.Ki,
+                                          &Sp, st);
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        const long long n = (long long)p.No * p.Ki + (db ? p.No : 0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(2048LL, cdivl(n, 256))), dim3(256), 0, st, p.part,
+                           db ? p.bpart : nullptr, dW, db, Sp, p.No, p.Ki, perm_heads, accumulate);
+        LAUNCH_CHECK();
+        return RGBNM_OK;
+      }
+    }
+  }
   // split the token axis so that ~512 workgroups exist; each split is a whole number of k-tiles
   int ktiles = cdiv(p.M, TK);
   int S = min(p.S, max(1, min(ktiles, cdiv(rgbnm_get_option("tn_wgs"), tiles))));

@@ -1,0 +1,215 @@
+// Weight-gradient GEMM, pipelined (bf16): part[s][No,Ki] = dY[tok range s, No]^T . X[tok range s, Ki]
+// (reference: the dW of every nn.Linear backward, models/plainvit.py:195,441,443,487,490).
+//
+// HBM-bound op (reads every activation once, output is tiny), so the design is a memory pipeline:
+//   * one 512-thread workgroup per CU, 128 x 192 output tile, 8 waves as 4(M) x 2(N), wave tile 32 x 96;
+//   * token tiles of 64 rows stream HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip) into a
+//     3-stage ring: two tiles (80 KB per CU, 20 MB chip-wide) are always in flight, one barrier per tile,
+//     counted vmcnt (never 0 in the steady state);
+//   * tiles keep their natural [token][feature] layout; fragments (reduction axis = tokens) come from
+//     ds_read_b64_tr_b16.  64-byte segments are XOR-swizzled through the *source* address (A: seg ^ (row&3),
+//     B: seg ^ ((row>>1)&1)) so the 4-row x 64-byte footprint of a 32-lane transpose read is bank-conflict free;
+//   * bias gradient (column sums of dY) rides on the MFMA pipe: one extra MFMA per chunk against a ones fragment.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TK = 64;                         // tokens per stage
+constexpr int A_ROW = 256, B_ROW = 384;        // bytes per token row (128 / 192 bf16 features)
+constexpr int A_STAGE = TK * A_ROW;            // 16 KB
+constexpr int B_STAGE = TK * B_ROW;            // 24 KB
+constexpr int STAGE = A_STAGE + B_STAGE;       // 40 KB
+constexpr int NSTAGE = 3;
+constexpr int SMEM = NSTAGE * STAGE;           // 120 KB
+
+struct TnPipe {
+  const bf16* dY; const bf16* X; float* part; float* bpart;
+  int ldy, ldx, M, No, Ki, S, kt_per_split, rtiles, ctiles;
+};
+
+__device__ __forceinline__ bf16x8 pack8(u32x2 lo, u32x2 hi) {
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// all 8 transpose reads of chunk C (16 tokens) for this wave: 1 A fragment + 3 B fragments
+template <int C>
+__device__ __forceinline__ void tr_chunk(unsigned aA, unsigned aB0, unsigned aB1, unsigned aB2, Frag<bf16>& fa,
+                                         Frag<bf16> (&fb)[3]) {
+  u32x2 al, ah, b0l, b0h, b1l, b1h, b2l, b2h;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %9 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:%15\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:%15\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(al), "=&v"(ah), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h), "=&v"(b2l), "=&v"(b2h)
+      : "v"(aA), "v"(aB0), "v"(aB1), "v"(aB2), "i"(C * 16 * A_ROW), "i"(C * 16 * A_ROW + 4 * A_ROW),
+        "i"(C * 16 * B_ROW), "i"(C * 16 * B_ROW + 4 * B_ROW)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  fa.v = pack8(al, ah);
+  fb[0].v = pack8(b0l, b0h);
+  fb[1].v = pack8(b1l, b1h);
+  fb[2].v = pack8(b2l, b2h);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnPipe p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntile = p.rtiles * p.ctiles;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int tile = jj % ntile, s = (jj / ntile) * 8 + xcd;
+  if (s >= p.S) return;
+  const int rt = tile / p.ctiles, ct = tile % p.ctiles;
+  const int r0 = rt * 128, c0 = ct * 192;
+  const int kt0 = s * p.kt_per_split;
+  const int T = min(p.kt_per_split, p.M / TK - kt0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  // ---- global source offsets (elements) of this wave's 5 LDS-DMA instructions per token tile ----
+  // A stage = 16 KB = 16 instructions of 1 KB (4 token rows each); B stage = 24 instructions (64/24 rows each).
+  int offA[2], offB[3];
+  const int vmaxA = (min(p.No - r0, 128) >> 3) - 1;     // clamp feature vectors of a ragged last row tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 4 * (w + 8 * j) + (lane >> 4), pv = lane & 15;
+    int v = (((pv >> 2) ^ (row & 3)) << 2) | (pv & 3);
+    v = v < vmaxA ? v : vmaxA;
+    offA[j] = row * p.ldy + r0 + v * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int pidx = (w + 8 * j) * 64 + lane;
+    const int row = pidx / 24, pv = pidx % 24;
+    const int v = (((pv >> 2) ^ ((row >> 1) & 1)) << 2) | (pv & 3);
+    offB[j] = row * p.ldx + c0 + v * 8;
+  }
+  const bf16* gA = p.dY + (size_t)kt0 * TK * p.ldy;
+  const bf16* gB = p.X + (size_t)kt0 * TK * p.ldx;
+  const size_t stepA = (size_t)TK * p.ldy, stepB = (size_t)TK * p.ldx;
+
+  auto issue = [&](int stage) {
+    unsigned char* st = smem + stage * STAGE + w * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gA + offA[j]), (lds_ptr)(st + j * 8192), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gB + offB[j]), (lds_ptr)(st + A_STAGE + j * 8192), 16, 0, 0);
+    gA += stepA;
+    gB += stepB;
+  };
+
+  // ---- per-lane LDS byte offsets of the transpose reads (stage base and chunk offset added later) ----
+  const int k = (lane >> 2) & 3;                              // row inside the 4-row group
+  const int within = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  const int kb = (k >> 1) & 1;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const unsigned oA = (8 * g + k) * A_ROW + ((wm ^ k) << 6) + within;
+  const unsigned oB0 = A_STAGE + (8 * g + k) * B_ROW + (((3 * wn + 0) ^ kb) << 6) + within;
+  const unsigned oB1 = A_STAGE + (8 * g + k) * B_ROW + (((3 * wn + 1) ^ kb) << 6) + within;
+  const unsigned oB2 = A_STAGE + (8 * g + k) * B_ROW + (((3 * wn + 2) ^ kb) << 6) + within;
+
+  f32x16 acc[3], accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; accb[r] = 0.f;
+  }
+  const bool do_bias = (p.bpart != nullptr) && (ct == 0) && (wn == 0);
+  Frag<bf16> ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.v[e] = (bf16)1.0f;
+
+  int st_issue = 0, st_comp = 0;
+  issue(0);
+  st_issue = 1;
+  if (T > 1) {
+    issue(1);
+    st_issue = 2;
+  }
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // tile t landed for every wave; every wave is done with tile t-1
+    if (t + 2 < T) {
+      issue(st_issue);
+      st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
+    }
+    const unsigned sb = lds0 + st_comp * STAGE;
+    st_comp = st_comp == NSTAGE - 1 ? 0 : st_comp + 1;
+    const unsigned aA = sb + oA, aB0 = sb + oB0, aB1 = sb + oB1, aB2 = sb + oB2;
+    Frag<bf16> fa, fb[3];
+#define CHUNK(C)                                   \
+    tr_chunk<C>(aA, aB0, aB1, aB2, fa, fb);        \
+    mma(acc[0], fa, fb[0]);                        \
+    mma(acc[1], fa, fb[1]);                        \
+    mma(acc[2], fa, fb[2]);                        \
+    if (do_bias) mma(accb, fa, ones);
+    CHUNK(0) CHUNK(1) CHUNK(2) CHUNK(3)
+#undef CHUNK
+  }
+
+  float* part = p.part + (size_t)s * p.No * p.Ki;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int col = c0 + wn * 96 + b * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + wm * 32 + acc_row(r, lane);
+      if (row < p.No) part[(size_t)row * p.Ki + col] = acc[b][r];
+    }
+  }
+  if (do_bias && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + wm * 32 + acc_row(r, lane);
+      if (row < p.No) p.bpart[(size_t)s * p.No + row] = accb[r];
+    }
+  }
+}
+
+}  // namespace
+
+int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
+                         int Ki, int* S_out, hipStream_t st) {
+  if (M % TK || Ki % 192 || No % 8 || ldy % 8 || ldx % 8 || M < TK) return 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr_set = true;
+  }
+  TnPipe p;
+  p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.part = part; p.bpart = bpart;
+  p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki;
+  p.rtiles = cdiv(No, 128);
+  p.ctiles = Ki / 192;
+  const int tiles = p.rtiles * p.ctiles;
+  const int ktiles = M / TK;
+  // one workgroup per CU (120 KB LDS): at most 256 workgroups so the grid is a single wave of the chip
+  int S = 256 / tiles;
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  if (S > ktiles) S = ktiles;
+  p.kt_per_split = cdiv(ktiles, S);
+  S = cdiv(ktiles, p.kt_per_split);
+  p.S = S;
+  *S_out = S;
+  hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(tiles * ((S + 7) / 8) * 8), dim3(512), SMEM, st, p);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}

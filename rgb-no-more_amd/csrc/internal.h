@@ -1,0 +1,8 @@
+// Cross-translation-unit launch helpers inside librgbnm.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+// Pipelined bf16 weight-gradient GEMM (gemm_tn_pipe.hip).  Returns RGBNM_OK, or 1 if the shape is not eligible
+// (caller falls back to the generic kernel), or a negative error.
+int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
+                         int Ki, int* S_out, hipStream_t st);

@@ -326,3 +326,12 @@ def test_gemm_tn_bf16_fragment_paths(option, tr):
     option("tn_tr", tr)
     for shp in [(1568, 576, 192, 3), (392, 192, 768, 0), (100, 1000, 192, 0), (260, 192, 384, 0)]:
         test_gemm_tn(torch.bfloat16, *shp)
+
+
+@pytest.mark.parametrize("pipe", [0, 1])
+def test_gemm_tn_bf16_pipelined_path(option, pipe):
+    """M % 64 == 0 shapes take the LDS-DMA pipelined kernel (tn_pipe=1); both paths must agree with the oracle."""
+    option("tn_pipe", pipe)
+    for shp in [(1024, 576, 192, 3), (64 * 49, 192, 768, 0), (64 * 49, 768, 192, 0), (256, 1000, 192, 0),
+                (64 * 7, 192, 384, 0), (64 * 100, 1152, 384, 6), (50176, 768, 192, 0)]:
+        test_gemm_tn(torch.bfloat16, *shp)
