@@ -14,6 +14,7 @@
 // Row-major operands (Q, K, V, dO rows) are read straight from global/L2 as 16-byte fragments.
 #include "common.h"
 #include "../../include/rgbnm.h"
+#include "internal.h"
 
 namespace {
 
@@ -387,6 +388,8 @@ extern "C" {
 int rgbnm_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int heads, float scale,
                         void* stream) {
   if (!qkv || !out || !lse || B <= 0 || heads <= 0 || N <= 0 || N > NPAD) return RGBNM_EINVAL;
+  if (dtype == DT_BF16 && rgbnm_get_option("attn_v2"))
+    return rgbnm_launch_attn2_fwd(qkv, out, lse, B, N, heads, scale, (hipStream_t)stream);
   if (dtype == DT_BF16) return attn_fwd_t<bf16>(qkv, out, lse, B, N, heads, scale, (hipStream_t)stream);
   if (dtype == DT_F32) return attn_fwd_t<float>(qkv, out, lse, B, N, heads, scale, (hipStream_t)stream);
   return RGBNM_EINVAL;
@@ -395,6 +398,8 @@ int rgbnm_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B
 int rgbnm_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                         int B, int N, int heads, float scale, void* stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || heads <= 0 || N <= 0 || N > NPAD) return RGBNM_EINVAL;
+  if (dtype == DT_BF16 && rgbnm_get_option("attn_v2"))
+    return rgbnm_launch_attn2_bwd(qkv, out, dout, lse, dqkv, B, N, heads, scale, (hipStream_t)stream);
   if (dtype == DT_BF16) return attn_bwd_t<bf16>(qkv, out, dout, lse, dqkv, B, N, heads, scale, (hipStream_t)stream);
   if (dtype == DT_F32) return attn_bwd_t<float>(qkv, out, dout, lse, dqkv, B, N, heads, scale, (hipStream_t)stream);
   return RGBNM_EINVAL;

@@ -1,0 +1,401 @@
+// bf16 attention, second generation (reference: MultiHeadAttention.forward, models/plainvit.py:445-464).
+// Same math and register orientation as attention.hip (S^T = K.Q^T, a lane owns one query / one key); what changes
+// is the memory system:
+//   * Q/K/V/dO tiles of one (image, head) arrive by LDS-DMA (global_load_lds, 16 B/lane) in their natural
+//     [token][64] layout -- one bulk transfer per workgroup instead of per-wave fragment loads from L2;
+//   * one XOR swizzle of the 16-byte chunk index, f(row) = rot3((row>>1)&7), makes BOTH access patterns bank-conflict
+//     free: ds_read_b128 of 32 token rows (MFMA operands with the head dim as reduction axis) and
+//     ds_read_b64_tr_b16 of 4 rows x 64 B (operands with tokens as reduction axis: V^T, K^T, Q^T, dO^T), so no
+//     transposed copies are staged at all;
+//   * backward is ONE kernel (phase A: wave = 32 queries -> dQ and D; phase B: wave = 32 keys -> dK, dV) sharing the
+//     four LDS tiles.
+#include "common.h"
+#include <type_traits>
+#include "internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 64;
+constexpr int NTILE = 7;
+constexpr int NPAD = NTILE * 32;          // 224 token rows per LDS array
+constexpr int ROWB = 128;                 // bytes per token row
+constexpr int ARR = NPAD * ROWB;          // 28 KB
+constexpr int NTHREADS = NTILE * 64;
+
+__device__ __forceinline__ int fswz(int row) {
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+}
+
+// LDS-DMA one [N][64] bf16 matrix (row stride ld elements): 28 instructions of 1 KB (8 rows); wave w issues
+// w, w+7, w+14, w+21.  Rows >= N replicate row N-1 (finite data; their probabilities are masked to zero).
+__device__ __forceinline__ void dma_matrix(const bf16* __restrict__ src, int ld, int N, unsigned char* dst, int w,
+                                           int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = w + 7 * j;
+    const int row = 8 * i + (lane >> 3), pc = lane & 7;
+    const int lc = pc ^ fswz(row);
+    const int srow = row < N ? row : N - 1;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)srow * ld + lc * 8), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+  }
+}
+
+// MFMA operand with the head dim as reduction axis: lane <-> token row (32t + l31), 32-byte chunk c, half g.
+__device__ __forceinline__ Frag<bf16> rowfrag(const unsigned char* arr, int t, int l31, int c, int g, int fl) {
+  Frag<bf16> f;
+  f.v = *reinterpret_cast<const bf16x8*>(arr + (32 * t + l31) * ROWB + (((2 * c + g) ^ fl) << 4));
+  return f;
+}
+
+__device__ __forceinline__ bf16x8 pack8(u32x2 lo, u32x2 hi) {
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// Transposed operands (tokens as reduction axis) of tile T, fragment FI, for both 32-wide d tiles:
+// a0 = per-lane LDS address for (dt=0, rd=0); dt=1 flips address bit 6, rd=1 flips bit 5 and adds 8 rows.
+template <int T, int FI>
+__device__ __forceinline__ void tfrag2(unsigned a0, Frag<bf16>& f0, Frag<bf16>& f1) {
+  u32x2 x0, x1, y0, y1;
+  const unsigned a00 = a0, a01 = (a0 ^ 32u) + 1024u, a10 = a0 ^ 64u, a11 = (a0 ^ 96u) + 1024u;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %1, %5 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %2, %6 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %3, %7 offset:%8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(x0), "=&v"(x1), "=&v"(y0), "=&v"(y1)
+      : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "i"(T * 4096 + FI * 2048)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  f0.v = pack8(x0, x1);
+  f1.v = pack8(y0, y1);
+}
+
+__device__ __forceinline__ Frag<bf16> pfrag(const float (&p)[16], int fi) {
+  Frag<bf16> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (bf16)p[fi * 8 + j];
+  return f;
+}
+
+struct LaneGeo {
+  int lane, l31, g, fl;
+  unsigned tr0;    // byte offset inside an array of the (t=0, fi=0, dt=0, rd=0) transpose read
+};
+__device__ __forceinline__ LaneGeo lane_geo() {
+  LaneGeo L;
+  L.lane = threadIdx.x & 63;
+  L.l31 = L.lane & 31;
+  L.g = L.lane >> 5;
+  L.fl = fswz(L.l31);
+  const int k = (L.lane >> 2) & 3, G1 = (L.lane >> 4) & 1, l3 = L.lane & 3;
+  const int pc = (2 * G1 + (l3 >> 1)) ^ (((k >> 1) << 2) | L.g);
+  L.tr0 = (unsigned)((4 * L.g + k) * ROWB + pc * 16 + 8 * (l3 & 1));
+  return L;
+}
+
+template <int T> struct TileLoop {
+  template <typename F> static __device__ __forceinline__ void run(F&& f) {
+    TileLoop<T - 1>::run(f);
+    f(std::integral_constant<int, T - 1>{});
+  }
+};
+template <> struct TileLoop<0> {
+  template <typename F> static __device__ __forceinline__ void run(F&&) {}
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(NTHREADS) void attn2_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                             float* __restrict__ lse, int N, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + ARR;
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+  const int inner = heads * HD, ld = 3 * inner;
+  const bf16* Q = qkv + (size_t)b * N * ld + h * HD;
+  const bf16* K = Q + inner;
+  const bf16* V = Q + 2 * inner;
+  const LaneGeo L = lane_geo();
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  dma_matrix(K, ld, N, Ks, w, L.lane);
+  dma_matrix(V, ld, N, Vs, w, L.lane);
+
+  const int q = w * 32 + L.l31;
+  const int qc = q < N ? q : N - 1;
+  Frag<bf16> qf[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qf[c] = load_frag<bf16>(Q + (size_t)qc * ld + c * 16 + L.g * 8);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (w * 32 >= N) return;
+
+  float s[NTILE][16];
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mma(acc, rowfrag(Ks, t, L.l31, c, L.g, L.fl), qf[c]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = t * 32 + acc_row(r, L.lane);
+      s[t][r] = kk < N ? acc[r] : -INFINITY;
+      m = fmaxf(m, s[t][r]);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[t][r] = __expf((s[t][r] - m) * scale);
+      sum += s[t][r];
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  if (L.g == 0 && q < N) lse[(size_t)bh * N + q] = m * scale + __logf(sum);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  const unsigned vt = (unsigned)(size_t)Vs + L.tr0;
+  TileLoop<NTILE>::run([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[t][r] *= inv;
+    Frag<bf16> v0, v1;
+    tfrag2<t, 0>(vt, v0, v1);
+    Frag<bf16> pf = pfrag(s[t], 0);
+    mma(o[0], v0, pf);
+    mma(o[1], v1, pf);
+    tfrag2<t, 1>(vt, v0, v1);
+    pf = pfrag(s[t], 1);
+    mma(o[0], v0, pf);
+    mma(o[1], v1, pf);
+  });
+  if (q < N) {
+    bf16* orow = out + ((size_t)b * N + q) * inner + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 v = {o[dt][rq * 4 + 0], o[dt][rq * 4 + 1], o[dt][rq * 4 + 2], o[dt][rq * 4 + 3]};
+        store4<bf16>(orow + dt * 32 + rq * 8 + L.g * 4, v);
+      }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ dout,
+                                                             const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                                                             int N, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qs = smem;
+  unsigned char* Ks = smem + ARR;
+  unsigned char* Vs = smem + 2 * ARR;
+  unsigned char* Gs = smem + 3 * ARR;                       // dO
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * ARR);  // [NPAD]
+  float* D_s = lse_s + NPAD;                                // [NPAD]
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+  const int inner = heads * HD, ld = 3 * inner;
+  const bf16* Q = qkv + (size_t)b * N * ld + h * HD;
+  const bf16* K = Q + inner;
+  const bf16* V = Q + 2 * inner;
+  const bf16* O = out + (size_t)b * N * inner + h * HD;
+  const bf16* dO = dout + (size_t)b * N * inner + h * HD;
+  const LaneGeo L = lane_geo();
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  dma_matrix(Q, ld, N, Qs, w, L.lane);
+  dma_matrix(K, ld, N, Ks, w, L.lane);
+  dma_matrix(V, ld, N, Vs, w, L.lane);
+  dma_matrix(dO, inner, N, Gs, w, L.lane);
+  for (int i = threadIdx.x; i < NPAD; i += NTHREADS) lse_s[i] = i < N ? lse[(size_t)bh * N + i] : 0.f;
+
+  const int row = w * 32 + L.l31;            // this lane's query (phase A) / key (phase B)
+  const int rc = row < N ? row : N - 1;
+  // O fragment of this lane's query for D = rowsum(dO * O): issued before the wait so it overlaps the DMA
+  Frag<bf16> of[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) of[c] = load_frag<bf16>(O + (size_t)rc * inner + c * 16 + L.g * 8);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const bool active = w * 32 < N;
+
+  // ================= phase A: wave = 32 queries -> dQ, D =================
+  if (active) {
+    Frag<bf16> qf[4], gf[4];
+    float Dq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      qf[c] = rowfrag(Qs, w, L.l31, c, L.g, L.fl);
+      gf[c] = rowfrag(Gs, w, L.l31, c, L.g, L.fl);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Dq += (float)gf[c].v[e] * (float)of[c].v[e];
+    }
+    Dq += __shfl_xor(Dq, 32, 64);
+    if (L.g == 0) D_s[row] = Dq;
+    const float lq = lse_s[row];
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    const unsigned kt = (unsigned)(size_t)Ks + L.tr0;
+    TileLoop<NTILE>::run([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if (t * 32 < N) {
+        f32x16 sa, da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          mma(sa, rowfrag(Ks, t, L.l31, c, L.g, L.fl), qf[c]);
+          mma(da, rowfrag(Vs, t, L.l31, c, L.g, L.fl), gf[c]);
+        }
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = t * 32 + acc_row(r, L.lane);
+          const float p = kk < N ? __expf(sa[r] * scale - lq) : 0.f;
+          ds[r] = p * (da[r] - Dq) * scale;
+        }
+        Frag<bf16> k0, k1;
+        tfrag2<t, 0>(kt, k0, k1);
+        Frag<bf16> sf = pfrag(ds, 0);
+        mma(dq[0], k0, sf);
+        mma(dq[1], k1, sf);
+        tfrag2<t, 1>(kt, k0, k1);
+        sf = pfrag(ds, 1);
+        mma(dq[0], k0, sf);
+        mma(dq[1], k1, sf);
+      }
+    });
+    if (row < N) {
+      bf16* drow = dqkv + ((size_t)b * N + row) * ld + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          f32x4 v = {dq[dt][rq * 4 + 0], dq[dt][rq * 4 + 1], dq[dt][rq * 4 + 2], dq[dt][rq * 4 + 3]};
+          store4<bf16>(drow + dt * 32 + rq * 8 + L.g * 4, v);
+        }
+    }
+  }
+  __syncthreads();   // D_s complete
+  if (!active) return;
+
+  // ================= phase B: wave = 32 keys -> dK, dV =================
+  Frag<bf16> kf[4], vf[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    kf[c] = rowfrag(Ks, w, L.l31, c, L.g, L.fl);
+    vf[c] = rowfrag(Vs, w, L.l31, c, L.g, L.fl);
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+  const unsigned qt_ = (unsigned)(size_t)Qs + L.tr0, gt_ = (unsigned)(size_t)Gs + L.tr0;
+  TileLoop<NTILE>::run([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if (t * 32 < N) {
+      f32x16 sa, da;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        mma(sa, rowfrag(Qs, t, L.l31, c, L.g, L.fl), kf[c]);   // rows = queries, cols = keys
+        mma(da, rowfrag(Gs, t, L.l31, c, L.g, L.fl), vf[c]);
+      }
+      float pp[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = t * 32 + acc_row(r, L.lane);
+        const float p = qq < N ? __expf(sa[r] * scale - lse_s[qq]) : 0.f;
+        pp[r] = p;
+        ds[r] = p * (da[r] - D_s[qq]) * scale;
+      }
+      Frag<bf16> a0, a1;
+      tfrag2<t, 0>(gt_, a0, a1);
+      Frag<bf16> f = pfrag(pp, 0);
+      mma(dv[0], a0, f);
+      mma(dv[1], a1, f);
+      tfrag2<t, 0>(qt_, a0, a1);
+      f = pfrag(ds, 0);
+      mma(dk[0], a0, f);
+      mma(dk[1], a1, f);
+      tfrag2<t, 1>(gt_, a0, a1);
+      f = pfrag(pp, 1);
+      mma(dv[0], a0, f);
+      mma(dv[1], a1, f);
+      tfrag2<t, 1>(qt_, a0, a1);
+      f = pfrag(ds, 1);
+      mma(dk[0], a0, f);
+      mma(dk[1], a1, f);
+    }
+  });
+  if (row < N) {
+    bf16* krow = dqkv + ((size_t)b * N + row) * ld + inner + h * HD;
+    bf16* vrow = krow + inner;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 a = {dk[dt][rq * 4 + 0], dk[dt][rq * 4 + 1], dk[dt][rq * 4 + 2], dk[dt][rq * 4 + 3]};
+        f32x4 c = {dv[dt][rq * 4 + 0], dv[dt][rq * 4 + 1], dv[dt][rq * 4 + 2], dv[dt][rq * 4 + 3]};
+        store4<bf16>(krow + dt * 32 + rq * 8 + L.g * 4, a);
+        store4<bf16>(vrow + dt * 32 + rq * 8 + L.g * 4, c);
+      }
+  }
+}
+
+constexpr int SMEM_FWD = 2 * ARR;
+constexpr int SMEM_BWD = 4 * ARR + 2 * NPAD * (int)sizeof(float);
+
+}  // namespace
+
+int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, float scale,
+                           hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn2_fwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_FWD, st, (const bf16*)qkv, (bf16*)out, lse,
+                     N, heads, scale);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                           int N, int heads, float scale, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn2_bwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out,
+                     (const bf16*)dout, lse, (bf16*)dqkv, N, heads, scale);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}

@@ -6,3 +6,9 @@
 // (caller falls back to the generic kernel), or a negative error.
 int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
                          int Ki, int* S_out, hipStream_t st);
+
+// bf16 attention with LDS-DMA tiles and transpose reads (attention_v2.hip)
+int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, float scale,
+                           hipStream_t st);
+int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                           int N, int heads, float scale, hipStream_t st);

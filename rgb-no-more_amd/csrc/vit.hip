@@ -15,7 +15,7 @@ static inline size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 #include <string.h>
 namespace {
 struct Opt { const char* name; int value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"trace", 0}, {"tn_wgs", 512}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1},{"trace", 0}, {"tn_wgs", 512}};
 }
 
 extern "C" {

@@ -335,3 +335,10 @@ def test_gemm_tn_bf16_pipelined_path(option, pipe):
     for shp in [(1024, 576, 192, 3), (64 * 49, 192, 768, 0), (64 * 49, 768, 192, 0), (256, 1000, 192, 0),
                 (64 * 7, 192, 384, 0), (64 * 100, 1152, 384, 6), (50176, 768, 192, 0)]:
         test_gemm_tn(torch.bfloat16, *shp)
+
+
+@pytest.mark.parametrize("v2", [0, 1])
+def test_attention_bf16_both_generations(option, v2):
+    option("attn_v2", v2)
+    for shp in [(3, 196, 3), (2, 196, 6), (2, 64, 3), (1, 100, 2), (2, 33, 3)]:
+        test_attention_fwd_bwd(torch.bfloat16, *shp)
