@@ -29,9 +29,9 @@ extern "C" {
 /* epilogues of rgbnm_gemm_nt */
 #define RGBNM_EPI_NONE 0   /* C = A.W^T (+bias)                                         */
 #define RGBNM_EPI_RES 1    /* C = A.W^T + bias + R            (ResidualAdd, plainvit.py:475-479)       */
-#define RGBNM_EPI_GELU 2   /* C2 = u = A.W^T + bias ; C = gelu_erf(u)   (FeedForwardBlock :487-488)    */
+#define RGBNM_EPI_GELU 2   /* u = A.W^T + bias ; C = gelu_erf(u), C2 = gelu_erf'(u)  (FeedForwardBlock :487-488) */
 #define RGBNM_EPI_POS 3    /* C = A.W^T + bias + pos[row % period]      (SinCosEmbedding :97-121)      */
-#define RGBNM_EPI_DGELU 4  /* C = (A.W^T) * gelu'(R)                                              */
+#define RGBNM_EPI_DGELU 4  /* C = (A.W^T) * R, R = the C2 (gelu') saved by RGBNM_EPI_GELU         */
 #define RGBNM_EPI_TANH 5   /* C = tanh(A.W^T + bias)                    (ClassificationHead :553-554)  */
 #define RGBNM_EPI_DTANH 6  /* C = (A.W^T) * (1 - R^2)                                             */
 
@@ -154,7 +154,7 @@ typedef struct rgbnm_block_acts {        /* saved for backward; caller-owned */
   void* x_mid;  /* [M,E]   after attention residual        */
   void* xn2;    /* [M,E]                                   */
   float *mean2, *rstd2;
-  void* u;      /* [M,4E]  fc1 pre-activation              */
+  void* u;      /* [M,4E]  gelu'(fc1 pre-activation)       */
   void* gl;     /* [M,4E]  gelu(u)                         */
   void* x_out;  /* [M,E]                                   */
 } rgbnm_block_acts;

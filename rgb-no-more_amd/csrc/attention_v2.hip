@@ -77,6 +77,65 @@ __device__ __forceinline__ void tfrag2(unsigned a0, Frag<bf16>& f0, Frag<bf16>& 
   f1.v = pack8(y0, y1);
 }
 
+// Both fragments (FI = 0, 1) x both d tiles of tile T from ONE array: 8 reads, one wait.
+template <int T>
+__device__ __forceinline__ void tfrag4(unsigned a0, Frag<bf16> (&f)[4]) {
+  u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+  const unsigned a00 = a0, a01 = (a0 ^ 32u) + 1024u, a10 = a0 ^ 64u, a11 = (a0 ^ 96u) + 1024u;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "i"(T * 4096), "i"(T * 4096 + 2048)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  f[0].v = pack8(r0, r1);   // fi=0, dt=0
+  f[1].v = pack8(r2, r3);   // fi=0, dt=1
+  f[2].v = pack8(r4, r5);   // fi=1, dt=0
+  f[3].v = pack8(r6, r7);   // fi=1, dt=1
+}
+
+// The same for TWO arrays (phase B of backward: dO^T and Q^T): 16 reads, one wait.
+template <int T>
+__device__ __forceinline__ void tfrag8(unsigned a0, unsigned b0, Frag<bf16> (&fa)[4], Frag<bf16> (&fb)[4]) {
+  u32x2 r0, r1, r2, r3, r4, r5, r6, r7, q0, q1, q2, q3, q4, q5, q6, q7;
+  const unsigned a00 = a0, a01 = (a0 ^ 32u) + 1024u, a10 = a0 ^ 64u, a11 = (a0 ^ 96u) + 1024u;
+  const unsigned b00 = b0, b01 = (b0 ^ 32u) + 1024u, b10 = b0 ^ 64u, b11 = (b0 ^ 96u) + 1024u;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %1, %17 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %2, %18 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %3, %19 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %4, %16 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %5, %17 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %6, %18 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %7, %19 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %8, %20 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %9, %21 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %10, %22 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %11, %23 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %12, %20 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %13, %21 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %14, %22 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %15, %23 offset:%25\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(q0), "=&v"(q1),
+        "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+      : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11), "i"(T * 4096),
+        "i"(T * 4096 + 2048)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  fa[0].v = pack8(r0, r1); fa[1].v = pack8(r2, r3); fa[2].v = pack8(r4, r5); fa[3].v = pack8(r6, r7);
+  fb[0].v = pack8(q0, q1); fb[1].v = pack8(q2, q3); fb[2].v = pack8(q4, q5); fb[3].v = pack8(q6, q7);
+}
+
 __device__ __forceinline__ Frag<bf16> pfrag(const float (&p)[16], int fi) {
   Frag<bf16> f;
 #pragma unroll
@@ -176,15 +235,14 @@ __global__ __launch_bounds__(NTHREADS) void attn2_fwd_kernel(const bf16* __restr
     constexpr int t = decltype(tc)::value;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[t][r] *= inv;
-    Frag<bf16> v0, v1;
-    tfrag2<t, 0>(vt, v0, v1);
+    Frag<bf16> vv[4];
+    tfrag4<t>(vt, vv);
     Frag<bf16> pf = pfrag(s[t], 0);
-    mma(o[0], v0, pf);
-    mma(o[1], v1, pf);
-    tfrag2<t, 1>(vt, v0, v1);
+    mma(o[0], vv[0], pf);
+    mma(o[1], vv[1], pf);
     pf = pfrag(s[t], 1);
-    mma(o[0], v0, pf);
-    mma(o[1], v1, pf);
+    mma(o[0], vv[2], pf);
+    mma(o[1], vv[3], pf);
   });
   if (q < N) {
     bf16* orow = out + ((size_t)b * N + q) * inner + h * HD;
@@ -276,15 +334,14 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
           const float p = kk < N ? __expf(sa[r] * scale - lq) : 0.f;
           ds[r] = p * (da[r] - Dq) * scale;
         }
-        Frag<bf16> k0, k1;
-        tfrag2<t, 0>(kt, k0, k1);
+        Frag<bf16> kk[4];
+        tfrag4<t>(kt, kk);
         Frag<bf16> sf = pfrag(ds, 0);
-        mma(dq[0], k0, sf);
-        mma(dq[1], k1, sf);
-        tfrag2<t, 1>(kt, k0, k1);
+        mma(dq[0], kk[0], sf);
+        mma(dq[1], kk[1], sf);
         sf = pfrag(ds, 1);
-        mma(dq[0], k0, sf);
-        mma(dq[1], k1, sf);
+        mma(dq[0], kk[2], sf);
+        mma(dq[1], kk[3], sf);
       }
     });
     if (row < N) {
@@ -333,23 +390,20 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
         pp[r] = p;
         ds[r] = p * (da[r] - D_s[qq]) * scale;
       }
-      Frag<bf16> a0, a1;
-      tfrag2<t, 0>(gt_, a0, a1);
+      Frag<bf16> gg[4], qq4[4];
+      tfrag8<t>(gt_, qt_, gg, qq4);
       Frag<bf16> f = pfrag(pp, 0);
-      mma(dv[0], a0, f);
-      mma(dv[1], a1, f);
-      tfrag2<t, 0>(qt_, a0, a1);
-      f = pfrag(ds, 0);
-      mma(dk[0], a0, f);
-      mma(dk[1], a1, f);
-      tfrag2<t, 1>(gt_, a0, a1);
+      mma(dv[0], gg[0], f);
+      mma(dv[1], gg[1], f);
       f = pfrag(pp, 1);
-      mma(dv[0], a0, f);
-      mma(dv[1], a1, f);
-      tfrag2<t, 1>(qt_, a0, a1);
+      mma(dv[0], gg[2], f);
+      mma(dv[1], gg[3], f);
+      f = pfrag(ds, 0);
+      mma(dk[0], qq4[0], f);
+      mma(dk[1], qq4[1], f);
       f = pfrag(ds, 1);
-      mma(dk[0], a0, f);
-      mma(dk[1], a1, f);
+      mma(dk[0], qq4[2], f);
+      mma(dk[1], qq4[3], f);
     }
   });
   if (row < N) {

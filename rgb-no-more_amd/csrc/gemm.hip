@@ -177,8 +177,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
       const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(Cs + row * CP + vec * 8);
       const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(Cs + row * CP + vec * 8 + 4);
       bf16x8 cv = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-      if (EPI == EPI_GELU) *reinterpret_cast<bf16x8*>(C2 + (size_t)gm * p.ldc2 + gn) = cv;
-      if (EPI != EPI_NONE && EPI != EPI_POS) {
+      if (EPI == EPI_GELU) {
+        // one erf/exp evaluation yields gelu(u) (-> C) and gelu'(u) (-> C2, consumed by EPI_DGELU in backward)
+        bf16x8 dv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float u = (float)cv[e];
+          float cdf, px;
+          gelu_parts_fast(u, cdf, px);
+          dv[e] = (bf16)(cdf + px);
+          cv[e] = (bf16)(u * cdf);
+        }
+        *reinterpret_cast<bf16x8*>(C2 + (size_t)gm * p.ldc2 + gn) = dv;
+      }
+      if (EPI != EPI_NONE && EPI != EPI_POS && EPI != EPI_GELU) {
         bf16x8 rv;
         if (EPI == EPI_RES || EPI == EPI_DGELU || EPI == EPI_DTANH)
           rv = *reinterpret_cast<const bf16x8*>(R + (size_t)gm * p.ldr + gn);
@@ -186,8 +198,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         for (int e = 0; e < 8; ++e) {
           float v = (float)cv[e];
           if (EPI == EPI_RES) v += (float)rv[e];
-          if (EPI == EPI_GELU) v = gelu_fast(v);
-          if (EPI == EPI_DGELU) v *= dgelu_fast((float)rv[e]);
+          if (EPI == EPI_DGELU) v *= (float)rv[e];
           if (EPI == EPI_TANH) v = tanhf(v);
           if (EPI == EPI_DTANH) {
             const float h = (float)rv[e];
@@ -220,11 +231,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         float v = acc[a][b][r] + bv;
         if (EPI == EPI_RES) v += to_f32(R[(size_t)row * p.ldr + col]);
         if (EPI == EPI_GELU) {
-          C2[(size_t)row * p.ldc2 + col] = from_f32<T>(v);
-          v = gelu_f(to_f32(from_f32<T>(v)));  // GELU of the value as stored (what backward will see)
+          const float u = to_f32(from_f32<T>(v));   // pre-activation at the activation dtype's precision
+          C2[(size_t)row * p.ldc2 + col] = from_f32<T>(dgelu_f(u));
+          v = gelu_f(u);
         }
         if (EPI == EPI_POS) v += p.pos[(size_t)(row % p.pos_period) * p.N + col];
-        if (EPI == EPI_DGELU) v *= dgelu_f(to_f32(R[(size_t)row * p.ldr + col]));
+        if (EPI == EPI_DGELU) v *= to_f32(R[(size_t)row * p.ldr + col]);
         if (EPI == EPI_TANH) v = tanhf(v);
         if (EPI == EPI_DTANH) {
           const float h = to_f32(R[(size_t)row * p.ldr + col]);
@@ -476,23 +488,38 @@ __device__ __forceinline__ int qkv_row(int n, int heads) {
 __global__ void reduce_partials_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
                                        float* __restrict__ out, float* __restrict__ bout, int S, int rows, int cols,
                                        int perm_heads, int accumulate) {
+  // 64 elements x 4 partial-groups per workgroup: 4x the loads in flight of a one-thread-per-element sum;
+  // the 4 group sums are combined in a fixed order (deterministic).
+  __shared__ float red[4][64];
   const long long n = (long long)rows * cols;
   const long long nt = n + (bpart ? rows : 0);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nt; i += (long long)gridDim.x * blockDim.x) {
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  for (long long base = blockIdx.x * 64LL; base < nt; base += (long long)gridDim.x * 64) {
+    const long long i = base + el;
     float a = 0.f;
     if (i < n) {
 #pragma unroll 4
-      for (int s = 0; s < S; ++s) a += part[(size_t)s * n + i];
-      const int r = (int)(i / cols), c = (int)(i % cols);
-      const int orow = perm_heads > 0 ? qkv_row(r, perm_heads) : r;
-      float* o = out + (size_t)orow * cols + c;
-      *o = accumulate ? (*o + a) : a;
-    } else {
+      for (int s = sg; s < S; s += 4) a += part[(size_t)s * n + i];
+    } else if (i < nt) {
       const int r = (int)(i - n);
-      for (int s = 0; s < S; ++s) a += bpart[(size_t)s * rows + r];
-      float* o = bout + (perm_heads > 0 ? qkv_row(r, perm_heads) : r);
-      *o = accumulate ? (*o + a) : a;
+      for (int s = sg; s < S; s += 4) a += bpart[(size_t)s * rows + r];
     }
+    red[sg][el] = a;
+    __syncthreads();
+    if (sg == 0 && i < nt) {
+      const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+      if (i < n) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const int orow = perm_heads > 0 ? qkv_row(r, perm_heads) : r;
+        float* o = out + (size_t)orow * cols + c;
+        *o = accumulate ? (*o + t) : t;
+      } else {
+        const int r = (int)(i - n);
+        float* o = bout + (perm_heads > 0 ? qkv_row(r, perm_heads) : r);
+        *o = accumulate ? (*o + t) : t;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -513,7 +540,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
       if (rc < 0) return rc;
       if (rc == 0) {
         const long long n = (long long)p.No * p.Ki + (db ? p.No : 0);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(2048LL, cdivl(n, 256))), dim3(256), 0, st, p.part,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(4096LL, cdivl(n, 64))), dim3(256), 0, st, p.part,
                            db ? p.bpart : nullptr, dW, db, Sp, p.No, p.Ki, perm_heads, accumulate);
         LAUNCH_CHECK();
         return RGBNM_OK;
@@ -541,7 +568,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   }
   LAUNCH_CHECK();
   const long long n = (long long)p.No * p.Ki + (db ? p.No : 0);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(2048LL, cdivl(n, 256))), dim3(256), 0, st, p.part,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(4096LL, cdivl(n, 64))), dim3(256), 0, st, p.part,
                      db ? p.bpart : nullptr, dW, db, S, p.No, p.Ki, perm_heads, accumulate);
   LAUNCH_CHECK();
   return RGBNM_OK;

@@ -84,17 +84,18 @@ def test_gemm_nt_epilogues(dt):
     t_hi = tol(dt, 5e-6, 6e-3)
     out, _ = gemm_nt(dt, L.EPI_RES, A, W, b, R=R)
     assert relerr(out, base + b + R.float()) < t_hi
-    out, u = gemm_nt(dt, L.EPI_GELU, A, W, b)
-    assert relerr(u, base + b) < t_hi
-    assert relerr(out, torch.nn.functional.gelu(u.float())) < tol(dt, 2e-6, 4e-3)
+    out, dg = gemm_nt(dt, L.EPI_GELU, A, W, b)
+    u = (base + b).to(dt).float().requires_grad_(True)      # pre-activation at the activation dtype's precision
+    gref = torch.nn.functional.gelu(u)
+    gref.sum().backward()
+    assert relerr(out, gref) < tol(dt, 2e-6, 4e-3)
+    assert relerr(dg, u.grad) < tol(dt, 2e-6, 4e-3)          # C2 = gelu'(u), consumed by EPI_DGELU
     pos = dev(detfill.uniform((196, N), 15))
     out, _ = gemm_nt(dt, L.EPI_POS, A, W, b, pos=pos, period=196)
     rows = torch.arange(M, device=DEV) % 196
     assert relerr(out, base + b + pos[rows]) < t_hi
-    x = R.float().clone().requires_grad_(True)
-    torch.nn.functional.gelu(x).sum().backward()
     out, _ = gemm_nt(dt, L.EPI_DGELU, A, W, None, R=R)
-    assert relerr(out, base * x.grad) < t_hi
+    assert relerr(out, base * R.float()) < t_hi
     out, _ = gemm_nt(dt, L.EPI_TANH, A, W, b)
     assert relerr(out, torch.tanh(base + b)) < t_hi
     h = torch.tanh(R.float()).to(dt)
