@@ -110,6 +110,49 @@ int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void*
                          void* feat, int B, int Hb, int Wb, int transpose_a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DCT-domain data path: replaces, per batch and on device, what the reference does per sample
+ * on the CPU inside DataLoader workers: dequantise+clamp (datasets.py:288-293), RandomResizedCrop_DCT
+ * (custom_transforms.py:631-663 -> dct_ops.py crop :584-599, resize :529-580), RandomFlip_DCT (:926-942),
+ * RandAugment_dct / _apply_op_dct (:944-1127), ToRange (:436-454).  All random draws are made by the caller.
+ * ------------------------------------------------------------------------------------------- */
+#define RGBNM_OP_IDENTITY 0
+#define RGBNM_OP_AUTOCONTRAST 1    /* autocontrast_dct on Y                 (dct_ops.py:862-887)  */
+#define RGBNM_OP_POSTERIZE 2       /* iarg0 = bit offset, iarg1 = table length round(2040/2^b)+1 (:889-914) */
+#define RGBNM_OP_SOLARIZEADD 3     /* iarg0 = addition                      (:653-679)            */
+#define RGBNM_OP_COLOR 4           /* contrast_dct on CbCr, fmag = factor   (:839-860)            */
+#define RGBNM_OP_CONTRAST 5        /* contrast_dct on Y, fmag = factor                            */
+#define RGBNM_OP_BRIGHTNESS 6      /* fmag = factor - 1                     (:817-837)            */
+#define RGBNM_OP_MIDFREQAUG 7      /* iarg0 = index of the 8x8 fp32 multiplier in `filters` (:710-746) */
+#define RGBNM_OP_CUTOUT 8          /* iarg0 = pad (luma, even), iarg1/iarg2 = centre h/w (luma blocks) (:776-815) */
+#define RGBNM_OP_TRANSLATEX 9      /* iarg0 = luma block shift int(m - m%2) (:748-774)            */
+#define RGBNM_OP_TRANSLATEY 10
+#define RGBNM_OP_ROTATE90 11       /* iarg0 = +1 counter-clockwise / -1 clockwise (:99-130)       */
+#define RGBNM_OP_AUTOSATURATION 12 /* autocontrast_dct on CbCr jointly                            */
+#define RGBNM_OP_GRAYSCALE 13      /* CbCr *= 0                             (custom_transforms.py:1004-1005) */
+#define RGBNM_OP_CHROMADROP 14     /* iarg0 != 0 drops Cb, else Cr          (:1011-1015)          */
+#define RGBNM_OP_SHARPNESS 15      /* sharpblur_dct, iarg0 = filter index   (dct_ops.py:681-708)  */
+
+typedef struct rgbnm_aug_params {
+  int crop_i, crop_j, crop_h, crop_w; /* luma blocks; chroma box = luma box / 2 (custom_transforms.py:647-652) */
+  int flip;                           /* horizontal flip after the resize */
+  int op[2];
+  float fmag[2];
+  int iarg0[2], iarg1[2], iarg2[2];
+} rgbnm_aug_params;
+
+size_t rgbnm_dct_augment_workspace(int B);
+/* Yq [B,1,Hy,Wy,8,8], CbCrq [B,2,Hc,Wc,8,8] (NULL: grayscale -> zero chroma), quant [B,3,8,8]: int16 as returned by
+ * read_coefficients.  crop_w must be 56, 28 or 14 (resize /2, identity, x2 -> 28x28 luma / 14x14 chroma blocks).
+ * params are needed twice: on the device (kernels) and on the host (validated before launch).
+ * conv16: A(8,2) 16x16 fp32; filters: [n][64] fp32 multipliers for MIDFREQAUG/SHARPNESS (may be NULL if unused).
+ * outY [B,1,28,28,8,8], outC [B,2,14,14,8,8] in out_dtype, after ToRange(-1,1; -1024,1016).
+ * entry_clamp: clamp before the first op (RandAugment_dct.forward, :1106-1108); nops in {0,1,2}. */
+int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* quant, const rgbnm_aug_params* params_dev,
+                      const rgbnm_aug_params* params_host, const float* conv16, const float* filters, void* outY,
+                      void* outC, int out_dtype, int B, int Hy, int Wy, int Hc, int Wc, int entry_clamp, int nops,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Train-step tail
  * ------------------------------------------------------------------------------------------- */
 /* CrossEntropyLoss (pipeline_utils.py:535) with soft [B,C] fp32 or hard int64 [B] targets (exactly one non-NULL).

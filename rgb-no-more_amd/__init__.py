@@ -8,3 +8,5 @@ Host-side modules mirror the reference's operator surface for this path:
 from . import detfill  # noqa: F401
 from . import lib, dct_ops, plainvit, cls_transforms, custom_optims  # noqa: F401,E402
 from .plainvit import ViT  # noqa: F401,E402
+from . import custom_transforms  # noqa: F401,E402
+from . import dct_manip  # noqa: F401,E402

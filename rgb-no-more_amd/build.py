@@ -60,7 +60,7 @@ def build_reader(force=False):
         return None
     if force or _stale(READER_LIB, [src]):
         cmd = ["gcc", "-O2", "-fPIC", "-shared", "-I/opt/conda/include", src, "-o", READER_LIB,
-               "-L/opt/conda/lib", "-ljpeg", "-Wl,-rpath,/opt/conda/lib"]
+               "-L/opt/conda/lib", "-ljpeg", "-lpthread", "-Wl,-rpath,/opt/conda/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"gcc failed for reader.c:\n{r.stderr}")

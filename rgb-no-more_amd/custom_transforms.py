@@ -1,0 +1,280 @@
+"""Mirror of the DCT half of the reference's `utils/custom_transforms.py` (:378-1196) for BATCHED device tensors.
+
+The reference composes per-sample CPU transforms inside DataLoader workers (datasets.py:354-366):
+    RandomResizedCrop_DCT(28, scale=(0.05,1), ratio=(1,1)) -> RandomFlip_DCT(0.5) -> RandAugment_dct(2, 3, 11, ops)
+    -> ToRange(-1, 1, -1024, 1016)
+Here the same chain runs as two HIP kernels per batch (csrc/augment.hip) on the raw int16 coefficients that
+`dct_manip.read_coefficients` returns.  Random parameters are drawn on the host with the reference's distributions
+(`sample_params`, class names / argument meaning kept) or supplied explicitly (parity tests pin them).
+
+    aug = TrainTransform_DCT(size=28, ops_list=cfg.TRAIN.AUGLIST, num_ops=2, magnitude=3)
+    Y, CbCr = aug(Yq, CbCrq, quant)            # (B,1,28,28,8,8), (B,2,14,14,8,8) in [-1, 1]
+"""
+import ctypes as C
+import itertools
+import math
+
+import numpy as np
+import torch
+
+from . import dct_ops as dops
+from . import lib as L
+
+OPS = {"Identity": 0, "AutoContrast": 1, "Posterize": 2, "SolarizeAdd": 3, "Color": 4, "Contrast": 5, "Brightness": 6,
+       "MidfreqAug": 7, "Cutout": 8, "TranslateX": 9, "TranslateY": 10, "Rotate90": 11, "AutoSaturation": 12,
+       "Grayscale": 13, "ChromaDrop": 14, "Sharpness": 15}
+CHROMA_OPS = {"Grayscale", "Color", "AutoSaturation", "ChromaDrop"}
+# default vitti list (utils/configs.py:93)
+VITTI_OPS = ("AutoContrast,Posterize,SolarizeAdd,Color,Contrast,Brightness,MidfreqAug,Cutout,TranslateX,TranslateY,"
+             "Rotate90,AutoSaturation,Grayscale,ChromaDrop").split(",")
+
+
+class AugParams(C.Structure):
+    _fields_ = [("crop_i", C.c_int), ("crop_j", C.c_int), ("crop_h", C.c_int), ("crop_w", C.c_int), ("flip", C.c_int),
+                ("op", C.c_int * 2), ("fmag", C.c_float * 2), ("iarg0", C.c_int * 2), ("iarg1", C.c_int * 2),
+                ("iarg2", C.c_int * 2)]
+
+
+def _factors(n):
+    return sorted(itertools.chain.from_iterable((i, n // i) for i in range(1, int(n ** 0.5) + 1) if n % i == 0))
+
+
+def even_size_choices(size):
+    return [c for c in _factors(size) if c % 2 == 0]
+
+
+def _choose_closest(val, choices, maxval):
+    """custom_transforms.py:571-578."""
+    if val <= choices[-1]:
+        return choices[int(np.argmin([abs(c - val) for c in choices]))]
+    closest = float(np.rint(np.float32(val) / np.float32(choices[-1]))) * choices[-1]
+    if closest > maxval:
+        closest -= choices[-1]
+    return closest
+
+
+class RandomResizedCrop_DCT:
+    """Parameter sampler with the reference's semantics (custom_transforms.py:527-629), ratio == (1, 1)."""
+
+    def __init__(self, size, scale=(0.05, 1.0), ratio=(1, 1), chroma_scale=2):
+        if tuple(ratio) != (1, 1):
+            raise NotImplementedError("the DCT pipelines use ratio=(1,1) (datasets.py:356,373)")
+        self.size, self.scale, self.chroma_scale = size, scale, chroma_scale
+        self.even_size_choices = even_size_choices(size)
+
+    def get_params(self, height, width, rng=torch):
+        area = height * width
+        for _ in range(10):
+            target_area = area * torch.empty(1).uniform_(self.scale[0], self.scale[1]).item()
+            w = int(round(math.sqrt(target_area)))
+            w = _choose_closest(w, self.even_size_choices, width)
+            w = int(max(2, w))
+            h = w
+            if w <= width and h <= height:
+                i = int(torch.randint(0, height - h + 1, size=(1,)).item() // self.chroma_scale * self.chroma_scale)
+                j = int(torch.randint(0, width - w + 1, size=(1,)).item() // self.chroma_scale * self.chroma_scale)
+                return i, j, h, w
+        w = int(_choose_closest(width, self.even_size_choices, width))
+        h = int(_choose_closest(height, self.even_size_choices, height))
+        i = (height - h) // 2 // self.chroma_scale * self.chroma_scale
+        j = (width - w) // 2 // self.chroma_scale * self.chroma_scale
+        return i, j, max(1, h), max(1, w)
+
+
+class ResizedCenterCrop_DCT:
+    """Eval crop box (custom_transforms.py:819-882): crop size_crop/size_resize of the grid, centred, even offsets."""
+
+    def __init__(self, size_resize, size_crop, chroma_scale=2):
+        self.size_resize, self.size_crop, self.chroma_scale = size_resize, size_crop, chroma_scale
+        self.size = size_crop
+        self.even_size_choices = even_size_choices(size_crop)
+
+    def get_params(self, height, width):
+        ratio = self.size_crop / self.size_resize
+        w = _choose_closest(round(ratio * width), self.even_size_choices, width)
+        h = _choose_closest(round(ratio * height), self.even_size_choices, height)
+        i = (height - int(h)) // 2 // self.chroma_scale * self.chroma_scale
+        j = (width - int(w)) // 2 // self.chroma_scale * self.chroma_scale
+        return int(i), int(j), int(max(1, h)), int(max(1, w))
+
+
+def magnitude_table(num_bins=11, image_size=(28, 28)):
+    """RandAugment_dct._augmentation_space (custom_transforms.py:1066-1092): op -> (magnitudes, signed)."""
+    ls = lambda a, b: torch.linspace(a, b, num_bins)  # noqa: E731
+    z = torch.tensor(0.0)
+    return {"Identity": (z, False), "AutoContrast": (z, False), "Posterize": (ls(0.0, 5.0).round().int(), False),
+            "SolarizeAdd": (ls(0, 883), False), "Color": (ls(0.0, 0.9), True), "Contrast": (ls(0.0, 0.9), True),
+            "Brightness": (ls(0.0, 0.9), True), "Sharpness": (ls(0.0, 0.9), True), "Cutout": (ls(0, 6), False),
+            "TranslateX": (ls(0.0, 150.0 / 336.0 * image_size[1]), True),
+            "TranslateY": (ls(0.0, 150.0 / 336.0 * image_size[0]), True), "Rotate90": (torch.tensor(1), True),
+            "AutoSaturation": (z, False), "Grayscale": (z, False), "MidfreqAug": (ls(0.0, 0.9), True),
+            "ChromaDrop": (z, False)}
+
+
+class _FilterBank:
+    """8x8 fp32 multiplier tables of MidfreqAug / Sharpness, one per distinct magnitude, computed on the host exactly
+    as the reference does (dct_ops.py:696-699, 725-737) and cached on the device."""
+
+    def __init__(self):
+        self.keys, self.tables, self.dev = {}, [], None
+
+    def index(self, kind, mag):
+        k = (kind, float(mag))
+        if k not in self.keys:
+            if kind == "MidfreqAug":
+                F = dops.midfreq_filter(mag)
+            else:
+                fh = torch.linspace(1, 1 + 2 * mag, 8, dtype=torch.float32).unsqueeze(1).clamp(min=0)
+                fw = torch.linspace(1, 1 + 2 * mag, 8, dtype=torch.float32).unsqueeze(0).clamp(min=0)
+                F = fh.mm(fw)
+            self.keys[k] = len(self.tables)
+            self.tables.append(F.reshape(64).contiguous())
+            self.dev = None
+        return self.keys[k]
+
+    def device_tensor(self, device):
+        if not self.tables:
+            return None
+        if self.dev is None or self.dev.device != torch.device(device):
+            self.dev = torch.stack(self.tables).to(device).contiguous()
+        return self.dev
+
+
+def encode_op(name, magnitude, aux, bank, grid=28):
+    """_apply_op_dct (custom_transforms.py:944-1017) argument handling -> (op id, fmag, iarg0, iarg1, iarg2)."""
+    if name not in OPS:
+        raise ValueError(f"The provided operator {name} is not recognized.")
+    op, f, a0, a1, a2 = OPS[name], 0.0, 0, 0, 0
+    if name in ("TranslateX", "TranslateY"):
+        a0 = int(magnitude - (magnitude % 2))                 # python modulo: -3.75 -> -4, +3.75 -> +2
+        if abs(a0) >= grid:
+            raise AssertionError("You cannot translate more than the image's size")
+    elif name == "Brightness":
+        f = float(np.float32((1.0 + magnitude) - 1))
+    elif name in ("Color", "Contrast"):
+        f = float(np.float32(1.0 + magnitude))
+        assert 0 <= 1.0 + magnitude <= 3, "Contrast adjustment factor should be in range [0,3]"
+    elif name == "Posterize":
+        a0 = int(magnitude)
+        a1 = round(2040 / (2 ** a0)) + 1
+    elif name == "SolarizeAdd":
+        a0 = int(magnitude)
+    elif name == "Cutout":
+        cs = round(magnitude)
+        a0 = int(cs - (cs % 2))
+        a1, a2 = int(aux[0]), int(aux[1])
+    elif name == "Rotate90":
+        a0 = int(magnitude)
+        if a0 not in (1, -1):
+            raise NotImplementedError("Rotate90 magnitude is +-1 in RandAugment_dct (custom_transforms.py:1086)")
+    elif name == "ChromaDrop":
+        a0 = int(bool(aux))
+    elif name in ("MidfreqAug", "Sharpness"):
+        assert -1 <= magnitude <= 1, "Intensity should be within the range of [-1, 1]"
+        a0 = bank.index(name, magnitude)
+    return op, f, a0, a1, a2
+
+
+class TrainTransform_DCT(torch.nn.Module):
+    """Batched device version of get_transform('imagenet_dct', 'train') (datasets.py:354-361)."""
+
+    def __init__(self, size=28, scale=(0.05, 1.0), flip_p=0.5, num_ops=2, magnitude=3, num_magnitude_bins=11,
+                 ops_list=None, out_dtype=torch.float32, eval_mode=False, size_resize=32):
+        super().__init__()
+        if size != 28:
+            raise NotImplementedError("HIP augment path is built for the 28x28-block ViT pipelines (imagenet_dct)")
+        self.size, self.flip_p, self.num_ops, self.magnitude = size, flip_p, num_ops, magnitude
+        self.num_magnitude_bins = num_magnitude_bins
+        self.ops_list = list(VITTI_OPS if ops_list is None else ops_list)
+        self.out_dtype = out_dtype
+        self.eval_mode = eval_mode
+        self.rrc = RandomResizedCrop_DCT(size, scale=scale, ratio=(1, 1))
+        self.rcc = ResizedCenterCrop_DCT(size_resize, size)
+        self.bank = _FilterBank()
+        self._conv16 = None
+        self._ws = None
+
+    # ---- parameter sampling with the reference distributions -------------------------------------------
+    def sample_params(self, B, height, width):
+        """One dict per sample: box, flip, ops=[(name, magnitude, aux)] (custom_transforms.py:589-610, 934, 1109-1123).
+        The reference's `list(set(...))` reordering (:1117-1119) makes its op stream irreproducible from a seed; the
+        distribution is kept (uniform over the remaining list), the order of the list is not."""
+        out = []
+        meta = magnitude_table(self.num_magnitude_bins, (self.size, self.size))
+        for _ in range(B):
+            if self.eval_mode:
+                out.append(dict(box=self.rcc.get_params(height, width), flip=False, ops=[]))
+                continue
+            box = self.rrc.get_params(height, width)
+            flip = not (torch.rand(1).item() > self.flip_p)
+            ops, ops_list = [], list(self.ops_list)
+            for _k in range(self.num_ops if ops_list else 0):
+                name = ops_list[int(torch.randint(len(ops_list), (1,)).item())]
+                if name in CHROMA_OPS:
+                    if name == "Grayscale":
+                        ops_list = [o for o in ops_list if o not in CHROMA_OPS]
+                    else:
+                        ops_list = [o for o in ops_list if o != "Grayscale"]
+                mags, signed = meta[name]
+                mag = float(mags[self.magnitude].item()) if mags.ndim > 0 else float(mags.item())
+                if signed and int(torch.randint(2, (1,)).item()):
+                    mag *= -1.0
+                aux = None
+                if name == "Cutout":
+                    aux = ((torch.randint(0, self.size, (1,)).item()) // 2 * 2, (torch.randint(0, self.size, (1,)).item()) // 2 * 2)
+                elif name == "ChromaDrop":
+                    aux = torch.rand(1).item() > 0.5
+                ops.append((name, mag, aux))
+            out.append(dict(box=box, flip=flip, ops=ops))
+        return out
+
+    def pack(self, params):
+        B = len(params)
+        arr = (AugParams * B)()
+        nops = max([len(p["ops"]) for p in params] + [0])
+        for b, p in enumerate(params):
+            i, j, h, w = p["box"]
+            a = arr[b]
+            a.crop_i, a.crop_j, a.crop_h, a.crop_w, a.flip = int(i), int(j), int(h), int(w), int(bool(p["flip"]))
+            for s in range(2):
+                if s < len(p["ops"]):
+                    name, mag, aux = p["ops"][s]
+                    a.op[s], a.fmag[s], a.iarg0[s], a.iarg1[s], a.iarg2[s] = encode_op(name, mag, aux, self.bank, self.size)
+                else:
+                    a.op[s] = 0
+        return arr, nops
+
+    def forward(self, Yq, CbCrq, quant, params=None):
+        """Yq (B,1,Hy,Wy,8,8) int16, CbCrq (B,2,Hc,Wc,8,8) int16 or None, quant (B,3,8,8) int16 -- device tensors."""
+        L.require_cuda(Yq, CbCrq, quant)
+        if Yq.dtype != torch.int16 or quant.dtype != torch.int16 or (CbCrq is not None and CbCrq.dtype != torch.int16):
+            raise TypeError("coefficients and quantisation tables must be int16 (dct_manip.read_coefficients layout)")
+        B, _, Hy, Wy, _, _ = Yq.shape
+        Hc, Wc = (CbCrq.shape[2], CbCrq.shape[3]) if CbCrq is not None else (Hy // 2, Wy // 2)
+        if params is None:
+            params = self.sample_params(B, Hy, Wy)
+        arr, nops = self.pack(params)
+        dev = Yq.device
+        pdev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev, non_blocking=True)
+        if self._conv16 is None or self._conv16.device != dev:
+            self._conv16 = dops.generate_conversion_matrix(8, 2).to(dev).contiguous()
+        filt = self.bank.device_tensor(dev)
+        wsb = L.lib().rgbnm_dct_augment_workspace(B)
+        if self._ws is None or self._ws.numel() < wsb or self._ws.device != dev:
+            self._ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        oy = torch.empty(B, 1, 28, 28, 8, 8, device=dev, dtype=self.out_dtype)
+        oc = torch.empty(B, 2, 14, 14, 8, 8, device=dev, dtype=self.out_dtype)
+        rc = L.lib().rgbnm_dct_augment(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
+                                       C.cast(arr, C.c_void_p), self._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),
+                                       oc.data_ptr(), L.dt_of(self.out_dtype), B, Hy, Wy, Hc, Wc,
+                                       0 if self.eval_mode else 1, nops, self._ws.data_ptr(), self._ws.numel(), L.stream())
+        if rc == -1:
+            raise L.RgbnmError("dct_augment: invalid parameters (crop side must be 14/28/56 luma blocks with even "
+                               "offsets inside the coefficient grid: 512x512 inputs; see include/rgbnm.h)")
+        L.check(rc, "dct_augment")
+        return oy, oc
+
+
+def EvalTransform_DCT(**kw):
+    """get_transform('imagenet_dct', 'val'|'test') (datasets.py:362-366): ResizedCenterCrop_DCT(32, 28) + ToRange."""
+    return TrainTransform_DCT(eval_mode=True, **kw)

@@ -1,0 +1,116 @@
+"""Drop-in for the reference's `dct_manip` extension module on this path: `read_coefficients(path)` with the same
+return contract (dct_manip/dct_manip.cpp:152-178), implemented by the host C library librgbnm_reader.so
+(csrc/reader.c, include/rgbnm_reader.h) through ctypes -- no libtorch / pybind11 in the native part.
+
+    dim, quant, Y, CbCr = dct_manip.read_coefficients("img.jpg")
+    dim int32 (C,2); quant int16 (C,8,8); Y int16 (1,Hb,Wb,8,8); CbCr int16 (2,Hb/2,Wb/2,8,8) or None (grayscale)
+
+`read_coefficients_batch` decodes many same-shaped files with a pthread pool into pinned batch tensors ready for one
+H2D copy (replaces per-sample tensors + default collate, datasets.py:274-297,542-546).
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librgbnm_reader.so")
+_lib = None
+_ERRLEN = 512
+
+
+class libjpeg_exception(Exception):
+    """mirrors dct_manip.cpp:24-41 (libjpeg's formatted message)."""
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"host reader missing: {LIB_PATH} (run __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.rgbnm_reader_abi_version.restype = C.c_int
+        L.rgbnm_jpeg_info.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.rgbnm_jpeg_info_mem.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_char_p, C.c_int]
+        L.rgbnm_read_coefficients.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.rgbnm_read_coefficients_mem.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_char_p, C.c_int]
+        L.rgbnm_read_coefficients_batch.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        for f in ("rgbnm_jpeg_info", "rgbnm_jpeg_info_mem", "rgbnm_read_coefficients", "rgbnm_read_coefficients_mem",
+                  "rgbnm_read_coefficients_batch"):
+            getattr(L, f).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _raise(rc, err):
+    msg = err.value.decode(errors="replace")
+    if rc == -1:
+        raise RuntimeError(msg)                      # "Unable to open file for reading: ..."
+    if rc == -2:
+        raise libjpeg_exception(msg)
+    raise RuntimeError(f"read_coefficients failed ({rc}) {msg}")
+
+
+def _read(path=None, data=None):
+    L = lib()
+    err = C.create_string_buffer(_ERRLEN)
+    info = (C.c_int32 * 17)()
+    if data is None:
+        p = os.fsencode(path)
+        rc = L.rgbnm_jpeg_info(p, info, err, _ERRLEN)
+    else:
+        rc = L.rgbnm_jpeg_info_mem(data, len(data), info, err, _ERRLEN)
+    if rc:
+        _raise(rc, err)
+    nc = info[0]
+    hb, wb = info[1], info[2]
+    dim = torch.empty((nc, 2), dtype=torch.int32)
+    quant = torch.empty((nc, 8, 8), dtype=torch.int16)
+    Y = torch.empty((1, hb, wb, 8, 8), dtype=torch.int16)
+    CbCr = None
+    if nc > 1:
+        CbCr = torch.empty((2, info[5], info[6], 8, 8), dtype=torch.int16)
+    cptr = CbCr.data_ptr() if CbCr is not None else None
+    if data is None:
+        rc = L.rgbnm_read_coefficients(p, dim.data_ptr(), quant.data_ptr(), Y.data_ptr(), cptr, err, _ERRLEN)
+    else:
+        rc = L.rgbnm_read_coefficients_mem(data, len(data), dim.data_ptr(), quant.data_ptr(), Y.data_ptr(), cptr, err, _ERRLEN)
+    if rc:
+        _raise(rc, err)
+    return dim, quant, Y, CbCr
+
+
+def read_coefficients(path: str):
+    """(dim, quant, Y, CbCr|None) -- reference: dct_manip.read_coefficients (dct_manip.cpp:152-178)."""
+    return _read(path=path)
+
+
+def read_coefficients_bytes(data: bytes):
+    """Same, from an in-memory JPEG."""
+    return _read(data=bytes(data))
+
+
+def read_coefficients_batch(paths, threads=8, grid=(64, 64), pin_memory=False):
+    """Decode len(paths) JPEGs of one coefficient grid (default 512x512 4:2:0 -> 64x64 luma blocks) in parallel.
+    Returns Y (B,1,Hb,Wb,8,8), CbCr (B,2,Hb/2,Wb/2,8,8), quant (B,3,8,8) int16 CPU tensors (optionally pinned)."""
+    L = lib()
+    n = len(paths)
+    hb, wb = grid
+    hbc, wbc = (hb + 1) // 2, (wb + 1) // 2
+    kw = dict(dtype=torch.int16, pin_memory=pin_memory)
+    Y = torch.empty((n, 1, hb, wb, 8, 8), **kw)
+    CbCr = torch.empty((n, 2, hbc, wbc, 8, 8), **kw)
+    quant = torch.empty((n, 3, 8, 8), **kw)
+    status = torch.zeros(n, dtype=torch.int32)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    bad = L.rgbnm_read_coefficients_batch(arr, n, int(threads), hb, wb, hbc, wbc, Y.data_ptr(), CbCr.data_ptr(),
+                                          quant.data_ptr(), status.data_ptr())
+    if bad:
+        i = int((status != 0).nonzero()[0])
+        code = int(status[i])
+        if code == -1:
+            raise RuntimeError(f"Unable to open file for reading: {paths[i]}")
+        raise libjpeg_exception(f"{paths[i]}: reader error {code} ({bad} of {n} files failed)")
+    return Y, CbCr, quant
