@@ -1,14 +1,21 @@
 #!/usr/bin/env python
-"""bench.py -- images/sec of the JPEG-Ti DCT train step on N MI355X (one process per GPU, RCCL).
+"""bench.py -- images/sec of the JPEG-Ti DCT train step on N MI355X (one process per GPU, RCCL over xGMI).
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run.
-One "step" = one pass of the hot path over one per-GPU batch of synthetic input resident in HBM:
-  mixup -> ViT forward (HIP) -> soft-label cross entropy -> backward (HIP) [-> DDP all-reduce over RCCL]
-  -> global-norm clip + AdamW + WeightDecay (HIP), i.e. the reference's `Model F/B pass` benchmark
-  (benchmark.py:125-197) with the train-loop optimizer tail (train.py:153-176).
-Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one per-GPU batch of synthetic input already resident in HBM
+(BASELINE.json config 2: JPEG-Ti --domain DCT bf16, batch 256 per GPU):
+
+  raw int16 DCT coefficients of 512x512 4:2:0 images (S-coef)
+    -> HIP dequant/crop/resize/flip/RandAugment/ToRange   (reference: datasets.py:286-293,354-361 on CPU workers)
+    -> HIP mixup                                           (cls_transforms.py:163-176)
+    -> HIP ViT forward, soft-label CE, backward            (models/plainvit.py; train.py:153-170)
+    -> [DDP gradient all-reduce over RCCL, N > 1]          (train.py:137)
+    -> HIP global-norm clip + AdamW + WeightDecay          (train.py:163-165, custom_optims.py:37-42)
+
+Prints ONE JSON line on rank 0 (metric/value/.../roofline/cpu_baseline).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -17,45 +24,98 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_IMG = {"vitti": 7.4025e9, "vits": 27.2813e9}   # train step = 3x forward
+FLOP_PER_IMG = {"vitti": 7.4025e9, "vits": 27.2813e9}   # train step = 3x forward FLOPs
 ARCH = {"vitti": (192, 3), "vits": (384, 6)}
-MFMA_PEAK_BF16 = 2500.0   # TFLOP/s dense, MI355X_MICROARCH.md
-MFMA_PEAK_F32 = 157.3
+MFMA_PEAK = {"bf16": 2500.0, "fp32": 157.3}             # dense TFLOP/s, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+Q90_LUMA = [3, 2, 2, 3, 5, 8, 10, 12, 2, 2, 3, 4, 5, 12, 12, 11, 3, 3, 3, 5, 8, 11, 14, 11, 3, 3, 4, 6, 10, 17, 16, 12, 4, 4,
+            7, 11, 14, 22, 21, 15, 5, 7, 11, 13, 16, 21, 23, 18, 10, 13, 16, 17, 21, 24, 24, 20, 14, 18, 19, 20, 22, 20, 21, 20]
+Q90_CHROMA = [3, 4, 5, 9, 20, 20, 20, 20, 4, 4, 5, 13, 20, 20, 20, 20, 5, 5, 11, 20, 20, 20, 20, 20, 9, 13, 20, 20, 20, 20,
+              20, 20] + [20] * 32
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm-sec", type=float, default=2.0,
+                    help="untimed steps run for this long before the W warm-up steps so the GPU leaves its idle clocks")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config 2: 256)")
     ap.add_argument("--arch", default="vitti", choices=list(ARCH))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-augment", action="store_true", help="model-only step on S-randn inputs (benchmark.py:146-148)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-images", type=int, default=96)
-    ap.add_argument("--trace", action="store_true", help="per-kernel HIP-event timing of the timed region")
+    ap.add_argument("--cpu-baseline-images", type=int, default=64)
+    ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel HIP-event trace of the timed region")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B experiments)")
     return ap.parse_args()
 
 
-def cpu_baseline(arch, n_images, batch=8):
-    """The oracle (CPU port of the reference path, oracle/vit_torch.py) timed on this host: config-1 style
-    train step (fwd + soft-label CE + bwd + clip + AdamW + WeightDecay), fp32, batch 8."""
+def synth_coefficients(B, dev, seed):
+    """S-coef: de-quantised DC ~ N(0,300), AC[u,v] ~ Laplace(0, 60/(1+u+v)), clamped to [-1024,1016],
+    stored QUANTISED with the libjpeg quality-90 tables, int16, laid out like dct_manip.read_coefficients."""
     import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    u = torch.arange(8, device=dev).view(8, 1).float()
+    v = torch.arange(8, device=dev).view(1, 8).float()
+    scale = 60.0 / (1 + u + v)
+    ql = torch.tensor(Q90_LUMA, device=dev, dtype=torch.float32).view(8, 8)
+    qc = torch.tensor(Q90_CHROMA, device=dev, dtype=torch.float32).view(8, 8)
+
+    def plane(shape, q):
+        e1 = torch.empty(shape, device=dev).exponential_(1.0, generator=g)
+        e2 = torch.empty(shape, device=dev).exponential_(1.0, generator=g)
+        x = (e1 - e2) * scale
+        x[..., 0, 0] = torch.randn(shape[:-2], device=dev, generator=g) * 300.0
+        return (x.clamp(-1024, 1016) / q).round().to(torch.int16).contiguous()
+
+    Y = plane((B, 1, 64, 64, 8, 8), ql)
+    Cc = plane((B, 2, 32, 32, 8, 8), qc)
+    quant = torch.stack([ql, qc, qc]).to(torch.int16).unsqueeze(0).repeat(B, 1, 1, 1).contiguous()
+    return Y, Cc, quant
+
+
+def cpu_baseline(arch, n_images, batch=8):
+    """The oracle (CPU port of the reference path: oracle/dct_np.py + oracle/vit_torch.py) timed on this host on a
+    bounded sample of the same workload shape (BASELINE config 1 style: batch 8, fp32):
+    per image dequant+crop+resize+flip+2 RandAugment ops+ToRange (numpy, one thread), per batch mixup + JPEG-Ti
+    fwd + soft CE + bwd + clip + AdamW + WeightDecay (torch CPU, all intra-op threads)."""
+    import numpy as np
+    import torch
+    from oracle import dct_np as O
     from oracle import vit_torch as V
     from rgb_no_more_amd import detfill
+    from rgb_no_more_amd import custom_transforms as CT
     emb, heads = ARCH[arch]
     depth = 12
+    torch.set_num_threads(min(32, os.cpu_count() or 1))   # batch-8 fp32 GEMMs stop scaling well before 128 threads
     shapes = V.param_shapes(depth, emb, heads)
     p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in detfill.fill_state_dict(shapes, 1).items()}
     params = list(p.values())
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0, eps=1e-8)
     wd = [v for k, v in p.items() if (".weight" in k) and ("lrnorm" not in k)]
-    y = torch.randn(batch, 1, 28, 28, 8, 8)
-    c = torch.randn(batch, 2, 14, 14, 8, 8)
+    rng = np.random.default_rng(0)
+    uu, vv = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    ql = np.array(Q90_LUMA, dtype=np.int16).reshape(8, 8)
+    qc = np.array(Q90_CHROMA, dtype=np.int16).reshape(8, 8)
+    Yq = np.rint(rng.laplace(0, 1, (batch, 1, 64, 64, 8, 8)) * 60.0 / (1 + uu + vv) / ql).astype(np.int16)
+    Cq = np.rint(rng.laplace(0, 1, (batch, 2, 32, 32, 8, 8)) * 60.0 / (1 + uu + vv) / qc).astype(np.int16)
+    quant = np.stack([ql, qc, qc]).astype(np.int16)
+    t = CT.TrainTransform_DCT()
+    torch.manual_seed(0)
     oh = torch.nn.functional.one_hot(torch.randint(0, 999, (batch,)), 1000).float()
 
-    def step():
+    def data(step_params):
+        ys, cs = [], []
+        for b, sp in enumerate(step_params):
+            oy, oc = O.train_transform(Yq[b], Cq[b], quant, sp["box"], sp["flip"], sp["ops"])
+            ys.append(oy)
+            cs.append(oc)
+        return torch.from_numpy(np.stack(ys)), torch.from_numpy(np.stack(cs))
+
+    def model_step(y, c):
         opt.zero_grad()
         my, mc, mt = V.mixup(y, c, oh, 0.8, 0.2)
         loss = V.soft_xent(V.vit_forward(p, my, mc, depth, heads, emb), mt)
@@ -65,39 +125,52 @@ def cpu_baseline(arch, n_images, batch=8):
         with torch.no_grad():
             torch._foreach_mul_(wd, 1.0 - 1e-4)
 
-    step()
+    y, c = data(t.sample_params(batch, 64, 64))
+    model_step(y, c)   # warm-up
     nsteps = max(1, n_images // batch)
-    t0 = time.perf_counter()
+    t_data = t_model = 0.0
     for _ in range(nsteps):
-        step()
-    dt = time.perf_counter() - t0
-    return {"value": round(nsteps * batch / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{nsteps} steps x batch {batch}, fp32 torch-CPU oracle of the same train step "
-                                      f"(model part of BASELINE config 1), {arch}"}
+        sp = t.sample_params(batch, 64, 64)
+        t0 = time.perf_counter()
+        y, c = data(sp)
+        t1 = time.perf_counter()
+        model_step(y, c)
+        t_model += time.perf_counter() - t1
+        t_data += t1 - t0
+    n = nsteps * batch
+    return {"value": round(n / (t_data + t_model), 2), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n} synthetic 512x512 coefficient images, batch {batch}, fp32: numpy oracle data path "
+                      f"({1e3 * t_data / n:.2f} ms/img, 1 thread) + torch-CPU oracle train step "
+                      f"({1e3 * t_model / n:.2f} ms/img, {torch.get_num_threads()} threads); entropy decode excluded "
+                      f"(inputs are coefficients, as on the GPU side)"}
 
 
 def main():
     a = parse()
+    import numpy as np
     import torch
     import torch.distributed as dist
     import rgb_no_more_amd as rg
     from rgb_no_more_amd import lib as L
+    from rgb_no_more_amd import custom_transforms as CT
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world == 1 and a.gpus > 1:
+        raise SystemExit("for --gpus N>1 launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
 
+    lib = L.lib()
     for o in a.opt:
         k, v = o.split("=")
-        L.check(L.lib().rgbnm_set_option(k.encode(), int(v)), f"option {k}")
+        L.check(lib.rgbnm_set_option(k.encode(), int(v)), f"option {k}")
     emb, heads = ARCH[a.arch]
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(1234 + rank)
@@ -107,18 +180,28 @@ def main():
     net = model
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
-        net = DDP(model, device_ids=[local], output_device=local, bucket_cap_mb=8, gradient_as_bucket_view=False)
+        # several ~4 MB buckets so the all-reduce of late layers overlaps the backward of early ones
+        net = DDP(model, device_ids=[local], output_device=local, bucket_cap_mb=4, gradient_as_bucket_view=False)
     opt = rg.custom_optims.FusedClipAdamWWD(model, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
     mix = rg.cls_transforms.RandomMixup_DCT(1000, alpha=0.2)
     mix.out_dtype = cdt
     B = a.batch
-    # S-randn synthetic input of the reference benchmark (benchmark.py:146-148), resident in HBM
-    y = torch.randn(B, 1, 28, 28, 8, 8, device=dev)
-    c = torch.randn(B, 2, 14, 14, 8, 8, device=dev)
     lab = torch.randint(0, 999, (B,), device=dev)
+    if a.no_augment:
+        y_in = torch.randn(B, 1, 28, 28, 8, 8, device=dev)
+        c_in = torch.randn(B, 2, 14, 14, 8, 8, device=dev)
+    else:
+        Yq, Cq, quant = synth_coefficients(B, dev, 1234 + rank)
+        aug = CT.TrainTransform_DCT(out_dtype=cdt)
+        sampler = CT.FastParamSampler(aug, seed=1234 + rank)
 
     def step():
         opt.zero_grad(set_to_none=True)
+        if a.no_augment:
+            y, c = y_in, c_in
+        else:
+            packed, nops = sampler.sample(B, 64, 64)
+            y, c = CT.apply_packed(aug, Yq, Cq, quant, packed, nops)
         (my, mc), mt = mix((y, c), lab)
         logits = net(my, mc)
         loss = rg.cls_transforms.cross_entropy(logits, mt, grad_dtype=cdt)
@@ -132,12 +215,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < a.prewarm_sec:     # DVFS ramp: cold clocks cost up to 40 % on the first runs
+        step()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
+    TAG_NT = 1
+    trace_on = (not a.no_trace) and rank == 0
+    traced_steps = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        # HIP-event brackets around the dominant kernel class on every 8th timed step (keeps the probe's own cost,
+        # ~200 event records per traced step, below 1 % of the timed region)
+        tr = trace_on and (i % 8 == 0)
+        if tr:
+            lib.rgbnm_set_option(b"trace", 1 << TAG_NT)
+            traced_steps += 1
         loss = step()
+        if tr:
+            lib.rgbnm_set_option(b"trace", 0)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -146,24 +244,46 @@ def main():
         dt = t.item()
     ms = dt / a.steps * 1e3
     value = world * B * a.steps / dt
-    out = None
     if rank == 0:
-        peak = MFMA_PEAK_BF16 if a.dtype == "bf16" else MFMA_PEAK_F32
-        tfl = value / world * FLOP_PER_IMG[a.arch] / 1e12
+        lib.rgbnm_set_option(b"trace", 0)
+        peak = MFMA_PEAK[a.dtype]
+        step_tflops = value / world * FLOP_PER_IMG[a.arch] / 1e12
+        roof = None
+        if not a.no_trace:
+            tms, fl, by, cnt = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            L.check(lib.rgbnm_trace_collect(TAG_NT, C.byref(tms), C.byref(fl), C.byref(by), C.byref(cnt)))
+            if cnt.value:
+                sec = tms.value / 1e3
+                gbs, tfs = by.value / sec / 1e9, fl.value / sec / 1e12
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get("gemm_nt_bytes_per_launch")
+                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "kernel": "gemm_nt (all nn.Linear forward + dX GEMMs; largest share of step time)",
+                        "launches_per_step": cnt.value // max(1, traced_steps), "traced_steps": traced_steps,
+                        "avg_launch_us": round(1e3 * tms.value / cnt.value, 2),
+                        "algorithmic_bytes_per_launch": round(by.value / cnt.value),
+                        "algorithmic_flops_per_launch": round(fl.value / cnt.value),
+                        "kernel_tflops": round(tfs, 1), "kernel_mfma_frac": round(tfs / peak, 4)}
         out = {
             "metric": "images/sec JPEG-Ti DCT 512x512 train step" if a.arch == "vitti" else f"images/sec {a.arch} DCT train step",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"JPEG-{'Ti' if a.arch == 'vitti' else 'S'} --domain DCT {a.dtype}, HIP ViT fwd/bwd + mixup + "
-                                   f"soft-CE + clip/AdamW/WD, per-GPU batch {B} (BASELINE config 2), S-randn inputs in HBM",
+            "config": {"workload": ("JPEG-%s --domain DCT %s, per-GPU batch %d (BASELINE config 2): %s + mixup + HIP ViT "
+                                    "fwd/bwd + soft-CE + clip/AdamW/WD") %
+                                   ("Ti" if a.arch == "vitti" else "S", a.dtype, B,
+                                    "model-only on S-randn inputs" if a.no_augment else
+                                    "HIP DCT-augment of S-coef 512x512 coefficient batches resident in HBM"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "loss": round(float(loss.item()), 5)},
-            "roofline": {"bound": "mfma", "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(tfl / peak, 4), "traffic": None,
-                         "note": "whole train step: 3x forward FLOPs/img (SURVEY 8d) / step time, per GPU"},
+            "mfma_pct_whole_step": round(100 * step_tflops / peak, 2),
+            "step_tflops_per_gpu": round(step_tflops, 1),
+            "roofline": roof,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_baseline_images)
         print(json.dumps(out), flush=True)
     if world > 1:

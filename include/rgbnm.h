@@ -40,6 +40,10 @@ int rgbnm_abi_version(void);
  * "tn_tr" (ds_read_b64_tr_b16 fragment loads in the weight-gradient GEMM, default 1), "trace" (0). */
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
+/* With option "trace" = (1 << tag) the launchers bracket kernels of that class with HIP events recorded on the launch
+ * stream (tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd).  collect() synchronises those events and
+ * returns their summed elapsed ms plus the algorithmic FLOPs / bytes of the bracketed launches, then forgets them. */
+int rgbnm_trace_collect(int tag, double* ms_total, double* flops_total, double* bytes_total, int* count);
 /* human readable text for a negative return code */
 const char* rgbnm_strerror(int code);
 

@@ -434,8 +434,11 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
       return RGBNM_ELAUNCH;
     attr = true;
   }
+  const double bhn = (double)B * heads * N;
+  const int slot = rgbnm_trace_begin(TR_ATTN_FWD, 4.0 * bhn * N * HD, bhn * HD * 2.0 * 4.0, st);
   hipLaunchKernelGGL(attn2_fwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_FWD, st, (const bf16*)qkv, (bf16*)out, lse,
                      N, heads, scale);
+  rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
@@ -448,8 +451,11 @@ int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, c
       return RGBNM_ELAUNCH;
     attr = true;
   }
+  const double bhn = (double)B * heads * N;
+  const int slot = rgbnm_trace_begin(TR_ATTN_BWD, 10.0 * bhn * N * HD, bhn * HD * 2.0 * 8.0, st);
   hipLaunchKernelGGL(attn2_bwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out,
                      (const bf16*)dout, lse, (bf16*)dqkv, N, heads, scale);
+  rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

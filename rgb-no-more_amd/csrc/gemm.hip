@@ -252,12 +252,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 template <typename T, int NB, bool STAGED>
 int launch_nt_epi(const GemmNT& p, int epi, hipStream_t st) {
   const int grid = ((p.mtiles + 7) / 8) * 8 * p.ntiles;
+  const double esz = sizeof(T), mn = (double)p.M * p.N;
+  const int slot = rgbnm_trace_begin(TR_NT, 2.0 * mn * p.K,
+                                     ((double)p.M * p.K + (double)p.N * p.K) * esz + mn * (p.c_f32 ? 4.0 : esz) +
+                                         ((epi == EPI_RES || epi == EPI_DGELU || epi == EPI_DTANH || epi == EPI_GELU) ? mn * esz : 0.0),
+                                     st);
   switch (epi) {
 #define CASE(E) case E: hipLaunchKernelGGL((gemm_nt_kernel<T, NB, E, STAGED>), dim3(grid), dim3(256), 0, st, p); break;
     CASE(EPI_NONE) CASE(EPI_RES) CASE(EPI_GELU) CASE(EPI_POS) CASE(EPI_DGELU) CASE(EPI_TANH) CASE(EPI_DTANH)
 #undef CASE
     default: return RGBNM_EINVAL;
   }
+  rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

@@ -209,7 +209,9 @@ int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float*
   S = cdiv(ktiles, p.kt_per_split);
   p.S = S;
   *S_out = S;
+  const int slot = rgbnm_trace_begin(TR_TN, 2.0 * M * (double)No * Ki, ((double)M * No + (double)M * Ki) * 2.0 + (double)No * Ki * 4.0, st);
   hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(tiles * ((S + 7) / 8) * 8), dim3(512), SMEM, st, p);
+  rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

@@ -12,3 +12,8 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
                            hipStream_t st);
 int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
                            int N, int heads, float scale, hipStream_t st);
+
+// per-kernel HIP-event tracing (vit.hip); tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd
+enum { TR_NT = 1, TR_TN = 2, TR_ATTN_FWD = 3, TR_ATTN_BWD = 4 };
+int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st);
+void rgbnm_trace_end(int slot, hipStream_t st);

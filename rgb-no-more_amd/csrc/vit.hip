@@ -13,9 +13,29 @@
 static inline size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 #include <string.h>
+#include <vector>
+#include "internal.h"
 namespace {
+// ---- optional per-kernel timing with HIP events recorded on the launch stream (option "trace" = bit mask of tags)
+struct TraceRec { hipEvent_t a, b; int tag; double flops, bytes; };
+std::vector<TraceRec> g_recs;
 struct Opt { const char* name; int value; };
 Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1},{"trace", 0}, {"tn_wgs", 512}};
+}
+
+int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
+  int mask = 0;
+  for (auto& o : g_opts) if (!strcmp(o.name, "trace")) mask = o.value;
+  if (!((mask >> tag) & 1)) return -1;
+  TraceRec r;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+  r.tag = tag; r.flops = flops; r.bytes = bytes;
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
+}
+void rgbnm_trace_end(int slot, hipStream_t st) {
+  if (slot >= 0 && slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, st);
 }
 
 extern "C" {
@@ -31,6 +51,27 @@ int rgbnm_get_option(const char* name) {
   for (auto& o : g_opts)
     if (name && !strcmp(o.name, name)) return o.value;
   return -1;
+}
+
+int rgbnm_trace_collect(int tag, double* ms_total, double* flops_total, double* bytes_total, int* count) {
+  double ms = 0, fl = 0, by = 0;
+  int n = 0;
+  std::vector<TraceRec> keep;
+  for (auto& r : g_recs) {
+    if (r.tag != tag) { keep.push_back(r); continue; }
+    if (hipEventSynchronize(r.b) != hipSuccess) return RGBNM_ELAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return RGBNM_ELAUNCH;
+    ms += t; fl += r.flops; by += r.bytes; ++n;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_recs.swap(keep);
+  if (ms_total) *ms_total = ms;
+  if (flops_total) *flops_total = fl;
+  if (bytes_total) *bytes_total = by;
+  if (count) *count = n;
+  return RGBNM_OK;
 }
 
 const char* rgbnm_strerror(int code) {

@@ -278,3 +278,105 @@ class TrainTransform_DCT(torch.nn.Module):
 def EvalTransform_DCT(**kw):
     """get_transform('imagenet_dct', 'val'|'test') (datasets.py:362-366): ResizedCenterCrop_DCT(32, 28) + ToRange."""
     return TrainTransform_DCT(eval_mode=True, **kw)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Vectorised parameter sampling (numpy) with the same distributions as `sample_params`: the per-sample Python loop
+# costs ~50 us/sample, far more than the GPU spends on the sample; this one is ~0.1 ms per 256-sample batch.
+# ----------------------------------------------------------------------------------------------------------------
+AUG_DTYPE = np.dtype([("crop", "i4", 4), ("flip", "i4"), ("op", "i4", 2), ("fmag", "f4", 2), ("iarg0", "i4", 2),
+                      ("iarg1", "i4", 2), ("iarg2", "i4", 2)])
+assert AUG_DTYPE.itemsize == C.sizeof(AugParams)
+
+
+class FastParamSampler:
+    def __init__(self, transform: "TrainTransform_DCT", seed=0):
+        t = self.t = transform
+        self.rng = np.random.default_rng(seed)
+        meta = magnitude_table(t.num_magnitude_bins, (t.size, t.size))
+        names = list(t.ops_list)
+        self.names = names
+        enc = np.zeros((len(names), 2, 5), dtype=np.float64)        # [op][sign] -> (id, fmag, a0, a1, a2)
+        self.signed = np.zeros(len(names), dtype=bool)
+        for k, n in enumerate(names):
+            mags, signed = meta[n]
+            mag = float(mags[t.magnitude].item()) if mags.ndim > 0 else float(mags.item())
+            self.signed[k] = signed
+            for s, sg in enumerate((1.0, -1.0)):
+                aux = (0, 0) if n == "Cutout" else (False if n == "ChromaDrop" else None)
+                enc[k, s] = encode_op(n, mag * sg if signed else mag, aux, t.bank, t.size)
+        self.enc = enc
+        idx = np.arange(len(names))
+        is_chroma = np.array([n in CHROMA_OPS for n in names])
+        is_gray = np.array([n == "Grayscale" for n in names])
+        self.cand_all = idx
+        self.cand_after_gray = idx[~is_chroma]          # Grayscale first: no chroma op afterwards (:1116-1117)
+        self.cand_after_chroma = idx[~is_gray]          # chroma op first: no Grayscale afterwards (:1118-1119)
+        self.is_chroma, self.is_gray = is_chroma, is_gray
+        self.k_cut = names.index("Cutout") if "Cutout" in names else -1
+        self.k_drop = names.index("ChromaDrop") if "ChromaDrop" in names else -1
+        self.choices = np.array(t.rrc.even_size_choices)
+
+    def sample(self, B, H, W):
+        t, r = self.t, self.rng
+        out = np.zeros(B, dtype=AUG_DTYPE)
+        u = r.uniform(t.rrc.scale[0], t.rrc.scale[1], B).astype(np.float32).astype(np.float64)
+        w = np.rint(np.sqrt(H * W * u))
+        size = self.choices[-1]
+        small = w <= size
+        near = self.choices[np.abs(self.choices[None, :] - w[:, None]).argmin(1)]
+        big = np.rint((w.astype(np.float32) / np.float32(size))).astype(np.int64) * size
+        big = np.where(big > W, big - size, big)
+        w = np.maximum(2, np.where(small, near, big)).astype(np.int64)
+        out["crop"][:, 0] = r.integers(0, H - w + 1) // 2 * 2
+        out["crop"][:, 1] = r.integers(0, W - w + 1) // 2 * 2
+        out["crop"][:, 2] = w
+        out["crop"][:, 3] = w
+        out["flip"] = r.random(B) <= t.flip_p
+        nops = t.num_ops if self.names else 0
+        prev = None
+        for s in range(nops):
+            if s == 0:
+                k = self.cand_all[r.integers(0, len(self.cand_all), B)]
+            else:
+                ua = r.random(B)
+                k = np.where(self.is_gray[prev], self.cand_after_gray[(ua * len(self.cand_after_gray)).astype(int)],
+                             np.where(self.is_chroma[prev], self.cand_after_chroma[(ua * len(self.cand_after_chroma)).astype(int)],
+                                      self.cand_all[(ua * len(self.cand_all)).astype(int)]))
+            sg = np.where(self.signed[k], r.integers(0, 2, B), 0)
+            e = self.enc[k, sg]
+            out["op"][:, s] = e[:, 0]
+            out["fmag"][:, s] = e[:, 1]
+            out["iarg0"][:, s] = e[:, 2]
+            out["iarg1"][:, s] = e[:, 3]
+            out["iarg2"][:, s] = e[:, 4]
+            cut = k == self.k_cut
+            out["iarg1"][cut, s] = r.integers(0, t.size, cut.sum()) // 2 * 2
+            out["iarg2"][cut, s] = r.integers(0, t.size, cut.sum()) // 2 * 2
+            drop = k == self.k_drop
+            out["iarg0"][drop, s] = r.random(drop.sum()) > 0.5
+            prev = k
+        return out, nops
+
+
+def apply_packed(transform, Yq, CbCrq, quant, packed, nops):
+    """Run the augment kernels with an AUG_DTYPE array produced by FastParamSampler.sample()."""
+    t = transform
+    B, _, Hy, Wy, _, _ = Yq.shape
+    Hc, Wc = (CbCrq.shape[2], CbCrq.shape[3]) if CbCrq is not None else (Hy // 2, Wy // 2)
+    dev = Yq.device
+    host = np.ascontiguousarray(packed)
+    pdev = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
+    if t._conv16 is None or t._conv16.device != dev:
+        t._conv16 = dops.generate_conversion_matrix(8, 2).to(dev).contiguous()
+    filt = t.bank.device_tensor(dev)
+    wsb = L.lib().rgbnm_dct_augment_workspace(B)
+    if t._ws is None or t._ws.numel() < wsb or t._ws.device != dev:
+        t._ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    oy = torch.empty(B, 1, 28, 28, 8, 8, device=dev, dtype=t.out_dtype)
+    oc = torch.empty(B, 2, 14, 14, 8, 8, device=dev, dtype=t.out_dtype)
+    L.check(L.lib().rgbnm_dct_augment(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(), host.ctypes.data,
+                                      t._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(), oc.data_ptr(),
+                                      L.dt_of(t.out_dtype), B, Hy, Wy, Hc, Wc, 0 if t.eval_mode else 1, nops,
+                                      t._ws.data_ptr(), t._ws.numel(), L.stream()), "dct_augment")
+    return oy, oc

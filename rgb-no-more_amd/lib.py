@@ -63,6 +63,7 @@ PROTOTYPES = {
     "rgbnm_strerror": (C.c_char_p, [_i]),
     "rgbnm_set_option": (_i, [C.c_char_p, _i]),
     "rgbnm_get_option": (_i, [C.c_char_p]),
+    "rgbnm_trace_collect": (_i, [_i, _vp, _vp, _vp, _vp]),
     "rgbnm_gemm_nt": (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbnm_gemm_tn_workspace": (_sz, [_i, _i, _i]),
     "rgbnm_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
