@@ -51,15 +51,12 @@ class FusedClipAdamWWD(Optimizer):
             self._state_ready = True
 
     def _flat_grads(self):
-        """The flat fp32 gradient buffer: zero-copy when every .grad is the view the backward kernels wrote
-        (the normal case), otherwise gathered into a staging buffer."""
+        """The flat fp32 gradient buffer: zero-copy when every .grad is the view the backward kernels wrote (the
+        normal case, also after DDP's in-place all-reduce), otherwise gathered into a staging buffer."""
         m = self._m
-        first_name, first = next(iter(m._named.items()))
-        g0 = first.grad
-        if g0 is not None:
-            base = g0.data_ptr() - m._offs[first_name] * 4
-            if all(p.grad is not None and p.grad.data_ptr() == base + m._offs[n] * 4 for n, p in m._named.items()):
-                return base
+        base = m.flat_grad_base()
+        if base is not None:
+            return base
         if self._gather is None:
             self._gather = torch.zeros_like(m._flat)
         views, grads = [], []

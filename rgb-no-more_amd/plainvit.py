@@ -20,12 +20,7 @@ from torch import nn
 
 from . import dct_ops as dops
 from . import lib as L
-
-_SEG = 256  # every tensor starts on a 256-element boundary of the flat buffers
-
-
-def _align(n, a=_SEG):
-    return (n + a - 1) // a * a
+from .flatparams import FlatParamModule, align as _align
 
 
 # ------------------------------------------------------------------ parameter-holder module tree
@@ -211,7 +206,7 @@ class _HeadFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ the model
-class ViT(nn.Module):
+class ViT(FlatParamModule):
     """Vision Transformer on DCT coefficients -- same ctor as the reference `ViT` (plainvit.py:559-599)."""
 
     def __init__(self, in_channels: int = 3, patch_size: int = 16, emb_size: int = 768, input_embed: int = -1,
@@ -263,28 +258,11 @@ class ViT(nn.Module):
     def _flatten(self):
         """(Re)pack every parameter into one fp32 buffer (256-element aligned segments) and describe the
         Linear layers for rgbnm_prep_weights.  Called lazily; survives .to(), load_state_dict (in-place copy)."""
-        params = list(self.named_parameters())
-        dev = params[0][1].device
+        dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise L.RgbnmError("model parameters must live on a HIP device (no CPU fallback)")
-        offs, total = {}, 0
-        for n, p in params:
-            offs[n] = total
-            total += _align(p.numel())
-        flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        for n, p in params:
-            seg = flat[offs[n]:offs[n] + p.numel()].view(p.shape)
-            seg.copy_(p.data)
-            p.data = seg
-        self._flat, self._offs, self._total = flat, offs, total
-        self._shapes = {n: tuple(p.shape) for n, p in params}
-        self._gflat = torch.zeros(total, device=dev, dtype=torch.float32)
-        # weight-decay mask per 256-chunk following the reference's name filter (pipeline_utils.py:537)
-        flags = torch.zeros(total // _SEG, dtype=torch.uint8)
-        for n, p in params:
-            if (".weight" in n) and ("lrnorm" not in n):
-                flags[offs[n] // _SEG:(offs[n] + _align(p.numel())) // _SEG] = 1
-        self._wd_flags = flags.to(dev)
+        params = self._pack_parameters()
+        offs = self._offs
         # ---- Linear descriptors + shadow layout
         lin = [("pe", "patchembed.projection.0", 0)]
         for i in range(self.depth):
@@ -323,19 +301,6 @@ class ViT(nn.Module):
                             "classhead.ch_linear1.bias", "classhead.ch_linear2.weight", "classhead.ch_linear2.bias"]
         self._head_param_order = [n for n in self._names() if n.startswith("classhead.")]
         self._arenas = {}
-        self._named = dict(params)
-        self._probe_params = [params[0], params[len(params) // 2], params[-1]]
-
-    def _ensure_flat(self):
-        ok = self._flat is not None
-        if ok:
-            base, end = self._flat.data_ptr(), self._flat.data_ptr() + self._flat.numel() * 4
-            for n, p in self._probe_params:
-                if p.data_ptr() != base + self._offs[n] * 4:
-                    ok = False
-                    break
-        if not ok:
-            self._flatten()
 
     def _pptr(self, name):
         return self._flat.data_ptr() + self._offs[name] * 4
@@ -344,12 +309,6 @@ class ViT(nn.Module):
         sh = self._shadow[self._cur_dtype]
         ws, wst, _ = self._sh_off[key]
         return sh.data_ptr() + (ws if which == "ws" else wst) * sh.element_size()
-
-    def _gview(self, gbuf, name):
-        n = 1
-        for s in self._shapes[name]:
-            n *= s
-        return gbuf[self._offs[name]:self._offs[name] + n].view(self._shapes[name])
 
     def _prep(self, cdtype):
         """fp32 masters -> operand shadows (cast, qkv de-interleave, transposes) for this step."""
@@ -390,15 +349,6 @@ class ViT(nn.Module):
         pool = self._arenas.setdefault((arena.B, arena.cdtype, arena.need_grad), [])
         if len(pool) < 2:
             pool.append(arena)
-
-    def _grad_buffer(self):
-        """flat fp32 buffer the backward kernels write into; a fresh one if live .grad tensors still alias it
-        (gradient accumulation across several backward passes)."""
-        base, end = self._gflat.data_ptr(), self._gflat.data_ptr() + self._gflat.numel() * 4
-        for p in self.parameters():
-            if p.grad is not None and base <= p.grad.data_ptr() < end:
-                return torch.zeros_like(self._gflat)
-        return self._gflat
 
     # ---------------------------------------------------------------- forward
     def forward(self, x, cbcr=None):

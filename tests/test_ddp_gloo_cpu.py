@@ -1,0 +1,119 @@
+"""N > 1 path on CPU: world_size 2 over gloo (no GPU).  The data-parallel path of this framework is
+  per-rank shard of the batch (seed + rank)  ->  HIP forward/backward producing gradient VIEWS of one flat buffer
+  ->  torch DDP bucketed all-reduce (RCCL on the GPU box, gloo here)  ->  fused flat optimizer on every rank.
+What is HIP-free in that chain is exercised here with a toy module that uses the very same FlatParamModule machinery
+as rgb_no_more_amd.plainvit.ViT: gradient views survive DDP's in-place all-reduce (optimizer zero-copy path), ranks
+end with identical averaged gradients, and the max-over-ranks timing reduction of bench.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from rgb_no_more_amd.flatparams import FlatParamModule
+
+
+class _Fn(torch.autograd.Function):
+    """y = (x @ W^T + b) * g + s with ALL parameter gradients written into views of the module's flat gradient
+    buffer (exactly what the HIP backward kernels do)."""
+
+    @staticmethod
+    def forward(ctx, x, m, gbuf, w, b, g, s):
+        z = x @ w.t() + b
+        ctx.m, ctx.gbuf = m, gbuf
+        ctx.save_for_backward(x, w, z, g)
+        return z * g + s
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, z, g = ctx.saved_tensors
+        m, gbuf = ctx.m, ctx.gbuf
+        gw, gb = m._gview(gbuf, "lin.weight"), m._gview(gbuf, "lin.bias")
+        gg, gs = m._gview(gbuf, "x_lrnorm.weight"), m._gview(gbuf, "x_lrnorm.bias")
+        dz = dy * g
+        gw.copy_(dz.t() @ x)
+        gb.copy_(dz.sum(0))
+        gg.copy_((dy * z).sum(0))
+        gs.copy_(dy.sum(0))
+        return dz @ w, None, None, gw, gb, gg, gs
+
+
+class Toy(FlatParamModule):
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(5, 3)
+        self.x_lrnorm = nn.LayerNorm(3)      # only a parameter holder (scale / shift), like the holders in plainvit.ViT
+
+    def forward(self, x):
+        self._ensure_flat()
+        n = self._named
+        return _Fn.apply(x, self, self._grad_buffer(), n["lin.weight"], n["lin.bias"], n["x_lrnorm.weight"],
+                         n["x_lrnorm.bias"])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)                       # same init on every rank (DDP would broadcast rank 0 anyway)
+    m = Toy()
+    m._ensure_flat()
+    assert all(p.data_ptr() == m._flat.data_ptr() + m._offs[n] * 4 for n, p in m.named_parameters())
+    assert m._wd_flags.tolist() == [1, 0, 0, 0]          # name filter: only lin.weight decays
+    ddp = nn.parallel.DistributedDataParallel(m, bucket_cap_mb=1)
+    torch.manual_seed(1234 + rank)                       # per-rank data shard (train.py:119)
+    x = torch.randn(4, 5)
+    y = ddp(x)
+    y.square().mean().backward()
+    # gradients are still views of ONE flat buffer after DDP's all-reduce -> the fused optimizer takes its zero-copy path
+    base = m.flat_grad_base()
+    assert base is not None and base == m._gflat.data_ptr()
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    gathered = [torch.zeros_like(g) for _ in range(world)]
+    dist.all_gather(gathered, g)
+    assert torch.equal(gathered[0], gathered[1])         # every rank holds the same averaged gradient
+    # reference: average of the per-rank local gradients
+    m2 = Toy()
+    m2.load_state_dict(m.state_dict())
+    m2._ensure_flat()
+    m2(x).square().mean().backward()
+    local = torch.cat([p.grad.reshape(-1) for p in m2.parameters()])
+    ls = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(ls, local)
+    assert torch.allclose(g, (ls[0] + ls[1]) / 2, atol=1e-6)
+    # a second backward without zero_grad must accumulate, not clobber (fresh buffer because .grad aliases _gflat)
+    ddp(x).square().mean().backward()
+    g2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert torch.allclose(g2, 2 * g, atol=1e-5)
+    # bench.py's timing reduction: MAX over ranks
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == float(world)
+    dist.barrier()
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_ddp_world2_gloo_flat_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    assert q.get(timeout=5) == "ok"
