@@ -160,7 +160,6 @@ __global__ __launch_bounds__(256) void dct_resize_kernel(ResizeArgs a) {
 
 // ------------------------------------------------------------------------------------------------ kernel 2
 constexpr int AUG_THREADS = 1024;
-constexpr int EPT = (NIMG + AUG_THREADS - 1) / AUG_THREADS;   // 74 elements per thread
 
 struct Decoded { int pl, r, c, u, v, S, base; };
 __device__ __forceinline__ Decoded decode(int e) {
@@ -180,7 +179,7 @@ __device__ __forceinline__ float linspace_f32(float start, float end, int steps,
 }
 
 template <typename TO>
-__global__ __launch_bounds__(AUG_THREADS) void dct_randaug_kernel(const short* __restrict__ inter,
+__global__ __launch_bounds__(AUG_THREADS) void dct_randaug_kernel(short* inter,
                                                                   const rgbnm_aug_params* __restrict__ prm,
                                                                   const float* __restrict__ filt, TO* __restrict__ outY,
                                                                   TO* __restrict__ outC, int entry_clamp, int nops) {
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(AUG_THREADS) void dct_randaug_kernel(const short* _
   short* img = reinterpret_cast<short*>(smem_raw);                    // [NIMG]
   int* red = reinterpret_cast<int*>(smem_raw + NIMG * sizeof(short));  // [48]
   const int b = blockIdx.x, tid = threadIdx.x;
-  const rgbnm_aug_params p = prm[b];
+  const rgbnm_aug_params* pp = prm + b;   // indexed per slot straight from memory (a local copy would go to scratch)
   {
     const uint4* src = reinterpret_cast<const uint4*>(inter + (size_t)b * NIMG);
     uint4* dst = reinterpret_cast<uint4*>(img);
@@ -201,43 +200,44 @@ __global__ __launch_bounds__(AUG_THREADS) void dct_randaug_kernel(const short* _
   }
 
   for (int slot = 0; slot < nops; ++slot) {
-    const int op = p.op[slot];
-    const float fm = p.fmag[slot];
-    const int i0 = p.iarg0[slot], i1 = p.iarg1[slot], i2 = p.iarg2[slot];
+    const int op = pp->op[slot];
+    const float fm = pp->fmag[slot];
+    const int i0 = pp->iarg0[slot], i1 = pp->iarg1[slot], i2 = pp->iarg2[slot];
     if (op == RGBNM_OP_ROTATE90 || op == RGBNM_OP_TRANSLATEX || op == RGBNM_OP_TRANSLATEY) {
-      // geometric permutations: gather through registers, then write back (dct_ops.py:99-130, 748-774)
-      short regs[EPT];
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const int e = tid + AUG_THREADS * k;
-        short val = 0;
-        if (e < NIMG) {
-          const Decoded d = decode(e);
-          if (op == RGBNM_OP_ROTATE90) {
-            int sr, sc;
-            bool neg;
-            if (i0 > 0) { sr = d.c; sc = d.S - 1 - d.r; neg = d.u & 1; }        // counter-clockwise
-            else { sr = d.S - 1 - d.c; sc = d.r; neg = d.v & 1; }               // clockwise
-            val = img[d.base + ((sr * d.S + sc) << 6) + d.v * 8 + d.u];         // per-block transpose
-            if (neg) val = (short)-val;
-          } else {
-            const int sh = d.pl ? (i0 >= 0 ? i0 / 2 : -((-i0 + 1) / 2)) : i0;   // python floor division //2
-            if (op == RGBNM_OP_TRANSLATEX) {
-              const int sc = d.c - sh;
-              if (sc >= 0 && sc < d.S) val = img[d.base + ((d.r * d.S + sc) << 6) + d.u * 8 + d.v];
-            } else {
-              const int sr = d.r - sh;
-              if (sr >= 0 && sr < d.S) val = img[d.base + ((sr * d.S + d.c) << 6) + d.u * 8 + d.v];
-            }
+      // geometric permutations (dct_ops.py:99-130, 748-774): spill the current image to this image's slot of the
+      // intermediate buffer (150 KB, stays in L2), then gather it back permuted -- no register staging, no LDS copy.
+      short* gimg = inter + (size_t)b * NIMG;
+      {
+        uint4* dst = reinterpret_cast<uint4*>(gimg);
+        const uint4* src = reinterpret_cast<const uint4*>(img);
+        for (int i = tid; i < NIMG / 8; i += AUG_THREADS) dst[i] = src[i];
+      }
+      __syncthreads();      // workgroup-scope release/acquire: the same CU re-reads its own stores
+      for (int e = 2 * tid; e < NIMG; e += 2 * AUG_THREADS) {   // elements e, e+1: same block, row u, columns v, v+1
+        const Decoded d = decode(e);
+        short v0 = 0, v1 = 0;
+        if (op == RGBNM_OP_ROTATE90) {
+          int sr, sc;
+          if (i0 > 0) { sr = d.c; sc = d.S - 1 - d.r; }        // counter-clockwise
+          else { sr = d.S - 1 - d.c; sc = d.r; }               // clockwise
+          const short* sp = gimg + d.base + ((sr * d.S + sc) << 6) + d.v * 8 + d.u;   // per-block transpose
+          v0 = sp[0];
+          v1 = sp[8];
+          if (i0 > 0) { if (d.u & 1) { v0 = (short)-v0; v1 = (short)-v1; } }         // odd rows negated
+          else v1 = (short)-v1;                                                       // odd columns (v+1 is odd)
+        } else {
+          const int sh = d.pl ? (i0 >= 0 ? i0 / 2 : -((-i0 + 1) / 2)) : i0;           // python floor division //2
+          int sr = d.r, sc = d.c;
+          if (op == RGBNM_OP_TRANSLATEX) sc -= sh;
+          else sr -= sh;
+          if (sr >= 0 && sr < d.S && sc >= 0 && sc < d.S) {
+            const unsigned pr = *reinterpret_cast<const unsigned*>(gimg + d.base + ((sr * d.S + sc) << 6) + d.u * 8 + d.v);
+            v0 = (short)(pr & 0xffff);
+            v1 = (short)(pr >> 16);
           }
         }
-        regs[k] = val;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const int e = tid + AUG_THREADS * k;
-        if (e < NIMG) img[e] = clamp_s(regs[k]);
+        *reinterpret_cast<unsigned*>(img + e) =
+            (unsigned)(unsigned short)clamp_s(v0) | ((unsigned)(unsigned short)clamp_s(v1) << 16);
       }
     } else if (op == RGBNM_OP_CUTOUT || op == RGBNM_OP_GRAYSCALE || op == RGBNM_OP_CHROMADROP) {
       for (int e = tid; e < NIMG; e += AUG_THREADS) {
@@ -382,7 +382,7 @@ int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* qu
       if (hipFuncSetAttribute((const void*)dct_randaug_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return RGBNM_ELAUNCH;
       attr = true;
     }
-    hipLaunchKernelGGL((dct_randaug_kernel<float>), dim3(B), dim3(AUG_THREADS), smem, st, (const short*)workspace,
+    hipLaunchKernelGGL((dct_randaug_kernel<float>), dim3(B), dim3(AUG_THREADS), smem, st, (short*)workspace,
                        params_dev, filters, (float*)outY, (float*)outC, entry_clamp, nops);
   } else if (out_dtype == DT_BF16) {
     static bool attr = false;
@@ -390,7 +390,7 @@ int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* qu
       if (hipFuncSetAttribute((const void*)dct_randaug_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return RGBNM_ELAUNCH;
       attr = true;
     }
-    hipLaunchKernelGGL((dct_randaug_kernel<bf16>), dim3(B), dim3(AUG_THREADS), smem, st, (const short*)workspace,
+    hipLaunchKernelGGL((dct_randaug_kernel<bf16>), dim3(B), dim3(AUG_THREADS), smem, st, (short*)workspace,
                        params_dev, filters, (bf16*)outY, (bf16*)outC, entry_clamp, nops);
   } else return RGBNM_EINVAL;
   LAUNCH_CHECK();

@@ -19,6 +19,13 @@ namespace {
 // ---- optional per-kernel timing with HIP events recorded on the launch stream (option "trace" = bit mask of tags)
 struct TraceRec { hipEvent_t a, b; int tag; double flops, bytes; };
 std::vector<TraceRec> g_recs;
+std::vector<hipEvent_t> g_event_pool;     // events are created once and recycled (hipEventCreate costs ~10 us)
+hipEvent_t take_event() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
 struct Opt { const char* name; int value; };
 Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1},{"trace", 0}, {"tn_wgs", 512}};
 }
@@ -28,7 +35,9 @@ int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
   for (auto& o : g_opts) if (!strcmp(o.name, "trace")) mask = o.value;
   if (!((mask >> tag) & 1)) return -1;
   TraceRec r;
-  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+  r.a = take_event();
+  r.b = take_event();
+  if (!r.a || !r.b) return -1;
   r.tag = tag; r.flops = flops; r.bytes = bytes;
   (void)hipEventRecord(r.a, st);
   g_recs.push_back(r);
@@ -63,8 +72,8 @@ int rgbnm_trace_collect(int tag, double* ms_total, double* flops_total, double* 
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return RGBNM_ELAUNCH;
     ms += t; fl += r.flops; by += r.bytes; ++n;
-    (void)hipEventDestroy(r.a);
-    (void)hipEventDestroy(r.b);
+    g_event_pool.push_back(r.a);
+    g_event_pool.push_back(r.b);
   }
   g_recs.swap(keep);
   if (ms_total) *ms_total = ms;

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Build profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+HBM bytes per launch = 2 * FETCH_SIZE KB (gfx950: FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced reads,
+MI355X_MICROARCH.md section HBM; checked here: the dGELU GEMM must read >= 96 MB and reports 51.8 MB) + WRITE_SIZE KB."""
+import glob
+import json
+import os
+import sys
+
+import pandas as pd
+
+
+def load(d):
+    fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    return pd.concat([pd.read_csv(f) for f in fs])
+
+
+def main(fetch_dir, write_dir, out):
+    f, w = load(fetch_dir), load(write_dir)
+    res = {}
+    for key, pat in (("gemm_nt", "gemm_nt_kernel"), ("gemm_tn", "gemm_tn_pipe_kernel"), ("attn_fwd", "attn2_fwd_kernel"),
+                     ("attn_bwd", "attn2_bwd_kernel"), ("dct_resize", "dct_resize_kernel"), ("dct_randaug", "dct_randaug_kernel")):
+        ff = f[f.Kernel_Name.str.contains(pat) & (f.Counter_Name == "FETCH_SIZE")]
+        ww = w[w.Kernel_Name.str.contains(pat) & (w.Counter_Name == "WRITE_SIZE")]
+        if len(ff) == 0 or len(ww) == 0:
+            continue
+        fetch = 2.0 * 1024.0 * ff.Counter_Value.mean()
+        write = 1024.0 * ww.Counter_Value.mean()
+        res[key + "_bytes_per_launch"] = round(fetch + write)
+        res[key + "_fetch_bytes_per_launch_corrected_x2"] = round(fetch)
+        res[key + "_write_bytes_per_launch"] = round(write)
+        res[key + "_launches_sampled"] = int(ff.Dispatch_Id.nunique())
+    res["note"] = ("mean over all launches of the kernel class in `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
+                   "passes of `python bench.py --steps 3 --warmup 1 --prewarm-sec 0 --no-cpu-baseline --no-trace`; "
+                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 half-count of wide coalesced reads)")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])
