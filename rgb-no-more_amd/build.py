@@ -10,6 +10,7 @@ LIB = os.path.join(HERE, "librgbnm.so")
 READER_LIB = os.path.join(HERE, "librgbnm_reader.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS += os.environ.get("RGBNM_HIPCC_FLAGS", "").split()      # experiments only (e.g. -DWRES_EXP)
 
 
 def _stale(target, deps):

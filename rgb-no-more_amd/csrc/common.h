@@ -97,6 +97,36 @@ __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf_
   cdf = 0.5f * (1.0f + copysignf(erfa, x));
   pdf_x = 0.39894228040143267794f * e * x;            // x * phi(x)
 }
+// Two elements at a time so the FMA chain compiles to packed fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32): the GELU
+// epilogue of the fc1 GEMM is VALU bound (measured: 3x its MFMA phase).  Same A&S 7.1.26 erfc as above, constants
+// folded: z = |x| sqrt(log2 e / 2) so that exp(-x^2/2) = exp2(-z^2);  Q = erfc(|x|/sqrt2)/2.
+//   gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x), Phi = x >= 0 ? 1 - Q : Q.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_pair_fast(f32x2 x, f32x2& g, f32x2& dg) {
+  const float kz = 0.84932180028801904272f;                       // sqrt(log2(e) / 2)
+  const float kp = 0.3275911f * 0.70710678118654752440f / kz;     // p |x|/sqrt2 expressed in z
+  f32x2 z;
+  z[0] = fabsf(x[0]) * kz;
+  z[1] = fabsf(x[1]) * kz;
+  const f32x2 d = z * kp + 1.0f;
+  f32x2 t, e;
+  t[0] = __builtin_amdgcn_rcpf(d[0]);
+  t[1] = __builtin_amdgcn_rcpf(d[1]);
+  const f32x2 w = z * z;
+  e[0] = __builtin_amdgcn_exp2f(-w[0]);
+  e[1] = __builtin_amdgcn_exp2f(-w[1]);
+  f32x2 poly = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+  poly = poly * t + (0.5f * 1.421413741f);
+  poly = poly * t + (0.5f * -0.284496736f);
+  poly = poly * t + (0.5f * 0.254829592f);
+  const f32x2 q = (poly * t) * e;                                  // erfc(|x|/sqrt2) / 2
+  f32x2 cdf;
+  cdf[0] = x[0] >= 0.f ? 1.0f - q[0] : q[0];
+  cdf[1] = x[1] >= 0.f ? 1.0f - q[1] : q[1];
+  const f32x2 px = (e * 0.39894228040143267794f) * x;              // x phi(x)
+  g = x * cdf;
+  dg = cdf + px;
+}
 __device__ __forceinline__ float gelu_fast(float x) {
   float c, p;
   gelu_parts_fast(x, c, p);

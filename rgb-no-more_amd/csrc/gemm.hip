@@ -181,12 +181,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         // one erf/exp evaluation yields gelu(u) (-> C) and gelu'(u) (-> C2, consumed by EPI_DGELU in backward)
         bf16x8 dv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float u = (float)cv[e];
-          float cdf, px;
-          gelu_parts_fast(u, cdf, px);
-          dv[e] = (bf16)(cdf + px);
-          cv[e] = (bf16)(u * cdf);
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 u = {(float)cv[e], (float)cv[e + 1]};
+          f32x2 gv, dgv;
+          gelu_pair_fast(u, gv, dgv);
+          dv[e] = (bf16)dgv[0];
+          dv[e + 1] = (bf16)dgv[1];
+          cv[e] = (bf16)gv[0];
+          cv[e + 1] = (bf16)gv[1];
         }
         *reinterpret_cast<bf16x8*>(C2 + (size_t)gm * p.ldc2 + gn) = dv;
       }
@@ -273,6 +275,12 @@ int launch_nt_sel(const GemmNT& p, int epi, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     const bool ok = !p.c_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!p.R || p.ldr % 8 == 0) &&
                     (!p.C2 || p.ldc2 % 8 == 0) && rgbnm_get_option("nt_staged");
+    if (ok && !p.pos && rgbnm_get_option("nt_wres")) {
+      // K = 192 layers: persistent weight-resident kernel (gemm_nt_wres.hip); 1 = shape not eligible
+      const int rc = rgbnm_launch_nt_wres(epi, p.A, p.lda, p.W, p.ldw, p.C, p.ldc, p.bias, p.R, p.ldr, p.C2, p.ldc2,
+                                          p.M, p.N, p.K, st);
+      if (rc != 1) return rc;
+    }
     if (ok) return launch_nt_epi<T, NB, true>(p, epi, st);
   }
   return launch_nt_epi<T, NB, false>(p, epi, st);

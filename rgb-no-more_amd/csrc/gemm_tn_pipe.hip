@@ -201,7 +201,9 @@ int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float*
   const int tiles = p.rtiles * p.ctiles;
   const int ktiles = M / TK;
   // one workgroup per CU (120 KB LDS): at most 256 workgroups so the grid is a single wave of the chip
+  // (counting the padding of the XCD map: a 257th workgroup would wait for a whole first round and double the time)
   int S = 256 / tiles;
+  if (S >= 8) S = S / 8 * 8;
   if (S < 1) S = 1;
   if (S > 64) S = 64;
   if (S > ktiles) S = ktiles;

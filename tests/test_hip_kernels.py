@@ -343,3 +343,31 @@ def test_attention_bf16_both_generations(option, v2):
     option("attn_v2", v2)
     for shp in [(3, 196, 3), (2, 196, 6), (2, 64, 3), (1, 100, 2), (2, 33, 3)]:
         test_attention_fwd_bwd(torch.bfloat16, *shp)
+
+
+@pytest.mark.parametrize("M,N", [(4096, 576), (64 * 67, 768), (6400, 192), (64 * 263, 96), (50176, 768)])
+def test_gemm_nt_bf16_weight_resident_path(option, M, N):
+    """K = 192, M % 64 == 0, N % 96 == 0 shapes take the persistent weight-resident kernel (nt_wres=1): same bits as
+    the tile-per-workgroup kernel (identical accumulation and rounding order), and both agree with the fp32 product."""
+    dt, K = torch.bfloat16, 192
+    A = dev(detfill.normalish((M, K), 31), dt)
+    W = dev(detfill.uniform((N, K), 32, -0.1, 0.1), dt)
+    b = dev(detfill.uniform((N,), 33))
+    R = dev(detfill.normalish((M, N), 34), dt)
+    base = A.float() @ W.float().T
+    outs = {}
+    for wres in (0, 1):
+        option("nt_wres", wres)
+        outs[wres] = [gemm_nt(dt, L.EPI_NONE, A, W, b)[0], gemm_nt(dt, L.EPI_NONE, A, W, None)[0],
+                      gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], *gemm_nt(dt, L.EPI_GELU, A, W, b),
+                      gemm_nt(dt, L.EPI_DGELU, A, W, None, R=R)[0]]
+        sync()
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    assert relerr(outs[1][0], base + b) < 4e-3
+    assert relerr(outs[1][2], base + b + R.float()) < 6e-3
+    assert relerr(outs[1][5], base * R.float()) < 6e-3
+    # repeated launches are deterministic (no race between the DMA ring and the staging tile)
+    for _ in range(3):
+        again = gemm_nt(dt, L.EPI_GELU, A, W, b)
+        assert torch.equal(again[0], outs[1][3]) and torch.equal(again[1], outs[1][4])
