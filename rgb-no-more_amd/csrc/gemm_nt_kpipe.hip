@@ -1,0 +1,208 @@
+// Row-panel NT GEMM for the N = 192 Linear layers with a long reduction (fc2: K = 768 + bias + residual; the dX
+// GEMMs of fc1 and qkv: K = 768 / 576), bf16:   C[M,192] = epi(A[M,K] . W[192,K]^T).
+// These read 58-77 MB of activations to produce 19 MB: HBM-read bound.  One 448-thread workgroup per CU owns ONE
+// contiguous panel of rows (M / 256 = 196 tokens at B = 256: exactly one workgroup per CU, a single balanced round;
+// 7 waves x 32 rows, the last 28 rows are padding) and all 192 output columns, and streams the reduction through a
+// 3-stage LDS-DMA ring of 64-wide k-tiles (A panel 28 KB + W 24 KB per stage; two tiles = 104 KB in flight per CU,
+// hand-counted vmcnt, one raw s_barrier per k-tile).  Rows are 128 bytes in LDS; 16-byte chunks are XOR-swizzled
+// (chunk ^ rot3((row>>1)&7)) through the DMA source address so ds_read_b128 over 32 rows is conflict free.
+// Epilogue: accumulators (MFMA issued with swapped operands: a lane owns one token) -> bf16 staging tile in the ring
+// memory -> coalesced 16-byte row pieces, bias and the residual (prefetched into registers before the loop) fused.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+constexpr int BN = 192, TKB = 128;            // k-tile: 64 bf16 = 128 bytes per row
+constexpr int NWAVES = 7, NTHREADS = 64 * NWAVES, BM = 32 * NWAVES;   // 224 rows of LDS per panel
+constexpr int A_STAGE = BM * TKB;             // 28 KB
+constexpr int W_STAGE = BN * TKB;             // 24 KB
+constexpr int STAGE = A_STAGE + W_STAGE;      // 52 KB
+constexpr int NSTAGE = 3;
+constexpr int NDMA = 8;                       // DMA instructions per wave per k-tile: 56 slots for 52 KB (4 repeats)
+constexpr int CP = BN + 4;                    // staging pitch (elements)
+constexpr int BIAS_OFF = NSTAGE * STAGE;      // 192 floats behind the ring
+constexpr int SMEM = NSTAGE * STAGE + BN * 4; // 160,512 B
+constexpr int NVEC = (BM * (BN / 8) + NTHREADS - 1) / NTHREADS;      // 12 output vectors per thread
+static_assert(BM * CP * 2 <= NSTAGE * STAGE, "staging tile lives in the ring");
+static_assert(SMEM <= 160 * 1024, "LDS");
+
+enum { EPI_NONE = 0, EPI_RES = 1 };
+
+struct KpArgs {
+  const bf16* A; const bf16* W; bf16* C; const float* bias; const bf16* R;
+  int lda, ldw, ldc, ldr;
+  int M, K, rows_per_wg, npanels;
+};
+
+__device__ __forceinline__ int fswz(int row) {
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Bs = reinterpret_cast<float*>(smem + BIAS_OFF);
+  const int panel = blockIdx.x;
+  const int m0 = panel * p.rows_per_wg;
+  const int rows = min(p.rows_per_wg, p.M - m0);          // valid rows of this panel (<= 224)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+
+  // ---- residual rows of this panel, straight into registers (oldest loads: they never delay a k-tile wait)
+  bf16x8 rv[NVEC];
+  if (EPI == EPI_RES) {
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int idx = tid + NTHREADS * i, row = idx / (BN / 8), vec = idx % (BN / 8);
+      const int rr = row < rows ? row : rows - 1;
+      rv[i] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)(m0 + rr) * p.ldr + vec * 8);
+    }
+  }
+  if (w < BN / 64) {
+    if (p.bias) __builtin_amdgcn_global_load_lds((glb_ptr)(p.bias + 64 * w + lane), (lds_ptr)(Bs + 64 * w), 4, 0, 0);
+    else Bs[64 * w + lane] = 0.f;
+  }
+
+  // ---- DMA slots: instruction i (0..55, i mod 52) covers 8 rows x 128 B; i < 28: A rows, else W rows
+  const bf16* src[NDMA];
+  int dst[NDMA];
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    int i = w + NWAVES * j;
+    i = i < 52 ? i : i - 52;
+    const int r8 = (i < 28 ? i : i - 28) * 8 + (lane >> 3), pc = lane & 7;
+    const int lc = pc ^ fswz(r8);
+    if (i < 28) {
+      const int rr = r8 < rows ? r8 : rows - 1;
+      src[j] = p.A + (size_t)(m0 + rr) * p.lda + lc * 8;
+      dst[j] = i * 1024;
+    } else {
+      src[j] = p.W + (size_t)r8 * p.ldw + lc * 8;
+      dst[j] = A_STAGE + (i - 28) * 1024;
+    }
+  }
+  int k0 = 0;
+  auto issue = [&](int stage) {
+    unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) __builtin_amdgcn_global_load_lds((glb_ptr)(src[j] + k0), (lds_ptr)(st + dst[j]), 16, 0, 0);
+    k0 += 64;
+  };
+
+  // ---- fragment addresses inside a stage
+  const int fl = fswz(l31);
+  int foff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) foff[c] = l31 * TKB + (((2 * c + g) ^ fl) << 4);
+  const int a_row = 32 * w * TKB;
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  const int T = p.K / 64;
+  int st_issue = 0, st_comp = 0;
+  issue(0);
+  st_issue = 1;
+  if (T > 1) {
+    issue(1);
+    st_issue = 2;
+  }
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // k-tile t landed for every wave; every wave is done with k-tile t-1
+    if (t + 2 < T) {
+      issue(st_issue);
+      st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
+    }
+    const unsigned char* sA = smem + st_comp * STAGE + a_row;
+    const unsigned char* sW = smem + st_comp * STAGE + A_STAGE;
+    st_comp = st_comp == NSTAGE - 1 ? 0 : st_comp + 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Frag<bf16> fa, fb[6];
+      fa.v = *reinterpret_cast<const bf16x8*>(sA + foff[c]);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) fb[b].v = *reinterpret_cast<const bf16x8*>(sW + 32 * b * TKB + foff[c]);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) mma(acc[b], fb[b], fa);     // swapped: D rows <-> features, D cols <-> tokens
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();          // every wave is done reading the ring: it becomes the staging tile
+
+  // ---- pass 1: lane = token (32 w + l31), register quad = 4 consecutive features (+ bias) -> bf16 staging tile
+  bf16* Cs = reinterpret_cast<bf16*>(smem);
+  const int ml = 32 * w + l31;
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = 32 * b + 8 * q + 4 * g;
+      f32x4 v = {acc[b][4 * q + 0], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]};
+      v += *reinterpret_cast<const f32x4*>(Bs + nl);
+      store4<bf16>(Cs + ml * CP + nl, v);
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // ---- pass 2: valid rows x 24 vectors of 8 features, coalesced 384-byte rows
+#pragma unroll
+  for (int i = 0; i < NVEC; ++i) {
+    const int idx = tid + NTHREADS * i, row = idx / (BN / 8), vec = idx % (BN / 8);
+    if (row >= rows) continue;
+    const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(Cs + row * CP + vec * 8);
+    const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(Cs + row * CP + vec * 8 + 4);
+    bf16x8 cv = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+    if (EPI == EPI_RES) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cv[e] = (bf16)((float)cv[e] + (float)rv[i][e]);
+    }
+    *reinterpret_cast<bf16x8*>(p.C + (size_t)(m0 + row) * p.ldc + vec * 8) = cv;
+  }
+}
+
+template <int EPI>
+int launch(const KpArgs& p, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_kpipe_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+        hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kpipe_kernel<EPI>), dim3(p.npanels), dim3(NTHREADS), SMEM, st, p);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // namespace
+
+// returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
+int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
+                          const void* R, int ldr, int M, int N, int K, hipStream_t st) {
+  if (N != BN || K % 64 || K < 256 || lda % 8 || ldw % 8 || ldc % 8 || M < 8192) return 1;
+  if (epi != EPI_NONE && epi != EPI_RES) return 1;
+  if (epi == EPI_RES && (!R || ldr % 8)) return 1;
+  KpArgs p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)C; p.bias = bias; p.R = (const bf16*)R;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
+  // one panel per CU when it fits (M / 256 rows, at most 224); otherwise whole rounds of 224-row panels
+  int rows = cdiv(M, 256);
+  if (rows > BM) rows = BM;
+  p.rows_per_wg = rows;
+  p.npanels = cdiv(M, rows);
+  const double mn = (double)M * N;
+  const int slot = rgbnm_trace_begin(TR_NT, 2.0 * mn * K, ((double)M * K + (double)N * K) * 2.0 + mn * 2.0 +
+                                                              (epi != EPI_NONE ? mn * 2.0 : 0.0), st);
+  const int rc = epi == EPI_RES ? launch<EPI_RES>(p, st) : launch<EPI_NONE>(p, st);
+  rgbnm_trace_end(slot, st);
+  return rc;
+}

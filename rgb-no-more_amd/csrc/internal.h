@@ -18,5 +18,8 @@ enum { TR_NT = 1, TR_TN = 2, TR_ATTN_FWD = 3, TR_ATTN_BWD = 4 };
 // Weight-resident K = 192 bf16 NT GEMM (gemm_nt_wres.hip).  Returns RGBNM_OK / error, or 1 if the shape is not eligible.
 int rgbnm_launch_nt_wres(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                          const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st);
+// Row-panel N = 192 bf16 NT GEMM with a pipelined reduction (gemm_nt_kpipe.hip).  Same return convention.
+int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
+                          const void* R, int ldr, int M, int N, int K, hipStream_t st);
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st);
 void rgbnm_trace_end(int slot, hipStream_t st);

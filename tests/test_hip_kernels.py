@@ -371,3 +371,27 @@ def test_gemm_nt_bf16_weight_resident_path(option, M, N):
     for _ in range(3):
         again = gemm_nt(dt, L.EPI_GELU, A, W, b)
         assert torch.equal(again[0], outs[1][3]) and torch.equal(again[1], outs[1][4])
+
+
+@pytest.mark.parametrize("M,K", [(50176, 768), (50176, 576), (196 * 64, 768), (8192 + 40, 256), (224 * 300, 384)])
+def test_gemm_nt_bf16_row_panel_path(option, M, K):
+    """N = 192, K % 64 == 0, K >= 256 shapes take the row-panel kernel with the pipelined reduction (nt_kpipe=1):
+    same bits as the tile-per-workgroup kernel (same k order, same rounding points), both close to the fp32 product."""
+    dt, N = torch.bfloat16, 192
+    A = dev(detfill.normalish((M, K), 41), dt)
+    W = dev(detfill.uniform((N, K), 42, -0.1, 0.1), dt)
+    b = dev(detfill.uniform((N,), 43))
+    R = dev(detfill.normalish((M, N), 44), dt)
+    base = A.float() @ W.float().T
+    outs = {}
+    for kp in (0, 1):
+        option("nt_kpipe", kp)
+        outs[kp] = [gemm_nt(dt, L.EPI_NONE, A, W, None)[0], gemm_nt(dt, L.EPI_NONE, A, W, b)[0],
+                    gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0]]
+        sync()
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    assert relerr(outs[1][1], base + b) < 4e-3
+    assert relerr(outs[1][2], base + b + R.float()) < 6e-3
+    for _ in range(3):
+        assert torch.equal(gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], outs[1][2])
