@@ -12,6 +12,7 @@
 #include "common.h"
 #include <type_traits>
 #include "internal.h"
+#include "../../include/rgbnm.h"
 
 namespace {
 
@@ -257,6 +258,12 @@ __global__ __launch_bounds__(NTHREADS) void attn2_fwd_kernel(const bf16* __restr
 }
 
 // ----------------------------------------------------------------------------------------------- backward
+#ifdef ATTN_PROF
+__device__ unsigned long long g_attn_prof[768 * 8 * 8];
+#define APROF(i) do { if (L.lane == 0) g_attn_prof[(blockIdx.x * 8 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define APROF(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                              const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, bf16* __restrict__ dqkv,
@@ -278,6 +285,7 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
   const LaneGeo L = lane_geo();
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
+  APROF(0);
   dma_matrix(Q, ld, N, Qs, w, L.lane);
   dma_matrix(K, ld, N, Ks, w, L.lane);
   dma_matrix(V, ld, N, Vs, w, L.lane);
@@ -293,6 +301,7 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  APROF(1);
   const bool active = w * 32 < N;
 
   // ================= phase A: wave = 32 queries -> dQ, D =================
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
         mma(dq[1], kk[3], sf);
       }
     });
+    APROF(2);
     if (row < N) {
       bf16* drow = dqkv + ((size_t)b * N + row) * ld + h * HD;
 #pragma unroll
@@ -355,7 +365,9 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
         }
     }
   }
+  APROF(3);
   __syncthreads();   // D_s complete
+  APROF(4);
   if (!active) return;
 
   // ================= phase B: wave = 32 keys -> dK, dV =================
@@ -406,6 +418,7 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
       mma(dk[1], qq4[3], f);
     }
   });
+  APROF(5);
   if (row < N) {
     bf16* krow = dqkv + ((size_t)b * N + row) * ld + inner + h * HD;
     bf16* vrow = krow + inner;
@@ -419,9 +432,239 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
         store4<bf16>(vrow + dt * 32 + rq * 8 + L.g * 4, c);
       }
   }
+#ifdef ATTN_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  APROF(6);
+#endif
+}
+
+// ------------------------------------------------------------------------ backward, persistent (third generation)
+// Same math and LDS layout as attn2_bwd_kernel; what changes is the schedule.  Measured on attn2_bwd (B = 256, cycle
+// stamps): 23 % of a workgroup's life is the initial DMA wait and 8 % the store drain, with one workgroup per CU
+// (116 KB of LDS) nothing hides either.  Here each of (at most) 256 workgroups walks several (image, head) pairs and
+// the two LDS array pairs are refilled a full phase ahead:
+//     phase A(h) reads K,V (all rows)  + own Q,dO,O rows from REGISTERS (fragment loads issued after phase B(h-1))
+//     -- barrier -- K,V(h+1) DMA starts
+//     phase B(h) reads Q,dO (all rows) + own K,V rows (registers, taken from LDS before the barrier)
+//     -- barrier -- Q,dO(h+1) DMA starts
+// vmcnt retires in order, so every wait is "everything except the youngest DMA group".  The exponent is one FMA +
+// exp2 (log2 e folded into scale and lse), `scale` multiplies dQ/dK once at the end, lse/D rows are read as float4,
+// and the key/query mask is applied on the ragged last tile only.
+__global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ dout,
+                                                             const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                                                             int N, int heads, int nbh, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qs = smem;
+  unsigned char* Ks = smem + ARR;
+  unsigned char* Vs = smem + 2 * ARR;
+  unsigned char* Gs = smem + 3 * ARR;                       // dO
+  float* L2_s = reinterpret_cast<float*>(smem + 4 * ARR);   // [NPAD] lse * log2(e)
+  float* D_s = L2_s + NPAD;                                 // [NPAD] rowsum(dO * O)
+  const int inner = heads * HD, ld = 3 * inner;
+  const LaneGeo L = lane_geo();
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = w * 32 + L.l31;            // this lane's query (phase A) / key (phase B)
+  const int rc = row < N ? row : N - 1;
+  const bool active = w * 32 < N;
+  const float LOG2E = 1.4426950408889634f;
+  const float c2 = scale * LOG2E;
+  const bool ragged = (N & 31) != 0;
+
+  auto issue_kv = [&](int bh) {
+    const bf16* Q = qkv + (size_t)(bh / heads) * N * ld + (bh % heads) * HD;
+    dma_matrix(Q + inner, ld, N, Ks, w, L.lane);
+    dma_matrix(Q + 2 * inner, ld, N, Vs, w, L.lane);
+  };
+  auto issue_qg = [&](int bh) {
+    const bf16* Q = qkv + (size_t)(bh / heads) * N * ld + (bh % heads) * HD;
+    dma_matrix(Q, ld, N, Qs, w, L.lane);
+    dma_matrix(dout + (size_t)(bh / heads) * N * inner + (bh % heads) * HD, inner, N, Gs, w, L.lane);
+  };
+  Frag<bf16> qf[4], gf[4], of[4];
+  float lq = 0.f;
+  auto load_own = [&](int bh) {              // 13 loads per lane
+    const int b = bh / heads, h = bh % heads;
+    const bf16* Qr = qkv + ((size_t)b * N + rc) * ld + h * HD + L.g * 8;
+    const bf16* Gr = dout + ((size_t)b * N + rc) * inner + h * HD + L.g * 8;
+    const bf16* Or = out + ((size_t)b * N + rc) * inner + h * HD + L.g * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      qf[c] = load_frag<bf16>(Qr + c * 16);
+      gf[c] = load_frag<bf16>(Gr + c * 16);
+      of[c] = load_frag<bf16>(Or + c * 16);
+    }
+    lq = lse[(size_t)bh * N + rc];
+  };
+
+  int bh = blockIdx.x;
+  if (bh >= nbh) return;
+  issue_kv(bh);
+  issue_qg(bh);
+  load_own(bh);
+  bool first = true;
+  for (; bh < nbh; bh += gridDim.x) {
+    const int b = bh / heads, h = bh % heads;
+    const int nxt = bh + gridDim.x;
+    // K,V of this pair have landed once only the youngest DMA group (Q,dO: 8 per wave) is outstanding
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    first = false;
+    __builtin_amdgcn_s_barrier();
+
+    // ================= phase A: wave = 32 queries -> dQ, D =================
+    Frag<bf16> kf[4], vf[4];
+    if (active) {
+      f32x16 dq[2];
+      float Dq = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Dq += (float)gf[c].v[e] * (float)of[c].v[e];
+      Dq += __shfl_xor(Dq, 32, 64);
+      const float lq2 = lq * LOG2E;
+      if (L.g == 0) {
+        D_s[row] = Dq;
+        L2_s[row] = lq2;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+      const unsigned kt = (unsigned)(size_t)Ks + L.tr0;
+      TileLoop<NTILE>::run([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (t * 32 < N) {
+          f32x16 sa, da;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            mma(sa, rowfrag(Ks, t, L.l31, c, L.g, L.fl), qf[c]);
+            mma(da, rowfrag(Vs, t, L.l31, c, L.g, L.fl), gf[c]);
+          }
+          float ds[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lq2));
+            ds[r] = pr * (da[r] - Dq);
+          }
+          if (ragged && t * 32 + 32 > N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (t * 32 + acc_row(r, L.lane) >= N) ds[r] = 0.f;
+          }
+          Frag<bf16> kk[4];
+          tfrag4<t>(kt, kk);
+          Frag<bf16> sf = pfrag(ds, 0);
+          mma(dq[0], kk[0], sf);
+          mma(dq[1], kk[1], sf);
+          sf = pfrag(ds, 1);
+          mma(dq[0], kk[2], sf);
+          mma(dq[1], kk[3], sf);
+        }
+      });
+      if (row < N) {        // 8 store instructions per active wave (counted by the wait below)
+        bf16* drow = dqkv + ((size_t)b * N + row) * ld + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            f32x4 v = {dq[dt][rq * 4 + 0], dq[dt][rq * 4 + 1], dq[dt][rq * 4 + 2], dq[dt][rq * 4 + 3]};
+            store4<bf16>(drow + dt * 32 + rq * 8 + L.g * 4, v * scale);
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {          // own K,V rows for phase B, before the arrays are refilled
+        kf[c] = rowfrag(Ks, w, L.l31, c, L.g, L.fl);
+        vf[c] = rowfrag(Vs, w, L.l31, c, L.g, L.fl);
+      }
+    }
+    // Q,dO of this pair have landed once only this wave's 8 dQ stores (younger) are outstanding
+    if (active) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // D_s / L2_s complete; every wave is done with K,V
+    if (nxt < nbh) issue_kv(nxt);
+
+    // ================= phase B: wave = 32 keys -> dK, dV =================
+    if (active) {
+      f32x16 dk[2], dv[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+      const unsigned qt_ = (unsigned)(size_t)Qs + L.tr0, gt_ = (unsigned)(size_t)Gs + L.tr0;
+      TileLoop<NTILE>::run([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (t * 32 < N) {
+          f32x16 sa, da;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            mma(sa, rowfrag(Qs, t, L.l31, c, L.g, L.fl), kf[c]);   // rows = queries, cols = keys
+            mma(da, rowfrag(Gs, t, L.l31, c, L.g, L.fl), vf[c]);
+          }
+          float pp[16], ds[16];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {   // accumulator rows 4 q4 .. 4 q4 + 3 = queries t*32 + 8 q4 + 4 g + 0..3
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(L2_s + t * 32 + 8 * q4 + 4 * L.g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + t * 32 + 8 * q4 + 4 * L.g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * q4 + e;
+              const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -l4[e]));
+              pp[r] = pr;
+              ds[r] = pr * (da[r] - d4[e]);
+            }
+          }
+          if (ragged && t * 32 + 32 > N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (t * 32 + acc_row(r, L.lane) >= N) { pp[r] = 0.f; ds[r] = 0.f; }
+          }
+          Frag<bf16> gg[4];
+          tfrag4<t>(gt_, gg);
+          Frag<bf16> f = pfrag(pp, 0);
+          mma(dv[0], gg[0], f);
+          mma(dv[1], gg[1], f);
+          f = pfrag(pp, 1);
+          mma(dv[0], gg[2], f);
+          mma(dv[1], gg[3], f);
+          tfrag4<t>(qt_, gg);
+          f = pfrag(ds, 0);
+          mma(dk[0], gg[0], f);
+          mma(dk[1], gg[1], f);
+          f = pfrag(ds, 1);
+          mma(dk[0], gg[2], f);
+          mma(dk[1], gg[3], f);
+        }
+      });
+      if (row < N) {
+        bf16* krow = dqkv + ((size_t)b * N + row) * ld + inner + h * HD;
+        bf16* vrow = krow + inner;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            f32x4 a = {dk[dt][rq * 4 + 0], dk[dt][rq * 4 + 1], dk[dt][rq * 4 + 2], dk[dt][rq * 4 + 3]};
+            f32x4 c = {dv[dt][rq * 4 + 0], dv[dt][rq * 4 + 1], dv[dt][rq * 4 + 2], dv[dt][rq * 4 + 3]};
+            store4<bf16>(krow + dt * 32 + rq * 8 + L.g * 4, a * scale);
+            store4<bf16>(vrow + dt * 32 + rq * 8 + L.g * 4, c);
+          }
+      }
+    }
+    if (nxt < nbh) {
+      load_own(nxt);                         // (issuing these during phase B would spill: 256-register budget)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // every wave is done with Q,dO, D_s, L2_s
+      issue_qg(nxt);
+    }
+  }
 }
 
 constexpr int SMEM_FWD = 2 * ARR;
+#define ATTN_PROF_END 1
 constexpr int SMEM_BWD = 4 * ARR + 2 * NPAD * (int)sizeof(float);
 
 }  // namespace
@@ -453,9 +696,27 @@ int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, c
   }
   const double bhn = (double)B * heads * N;
   const int slot = rgbnm_trace_begin(TR_ATTN_BWD, 10.0 * bhn * N * HD, bhn * HD * 2.0 * 8.0, st);
-  hipLaunchKernelGGL(attn2_bwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out,
-                     (const bf16*)dout, lse, (bf16*)dqkv, N, heads, scale);
+  if (rgbnm_get_option("attn_persist")) {
+    static bool attr3 = false;
+    if (!attr3) {
+      if (hipFuncSetAttribute((const void*)attn3_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess)
+        return RGBNM_ELAUNCH;
+      attr3 = true;
+    }
+    const int nbh = B * heads;
+    hipLaunchKernelGGL(attn3_bwd_kernel, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv,
+                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, heads, nbh, scale);
+  } else {
+    hipLaunchKernelGGL(attn2_bwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out,
+                       (const bf16*)dout, lse, (bf16*)dqkv, N, heads, scale);
+  }
   rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
+
+#ifdef ATTN_PROF
+extern "C" int rgbnm_debug_attn_prof(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_prof), sizeof(unsigned long long) * 768 * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

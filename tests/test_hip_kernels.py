@@ -395,3 +395,12 @@ def test_gemm_nt_bf16_row_panel_path(option, M, K):
     assert relerr(outs[1][2], base + b + R.float()) < 6e-3
     for _ in range(3):
         assert torch.equal(gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], outs[1][2])
+
+
+@pytest.mark.parametrize("persist", [0, 1])
+def test_attention_bf16_backward_schedules(option, persist):
+    """attn_persist=1: persistent backward (several (image, head) pairs per workgroup, operands prefetched a phase
+    ahead); 0: one workgroup per pair.  Both against the oracle, including > 256 pairs (grid wrap) and ragged N."""
+    option("attn_persist", persist)
+    for shp in [(3, 196, 3), (100, 196, 3), (2, 64, 3), (1, 100, 2), (2, 33, 3), (50, 196, 6)]:
+        test_attention_fwd_bwd(torch.bfloat16, *shp)
