@@ -503,43 +503,15 @@ __device__ __forceinline__ int qkv_row(int n, int heads) {
   return h * 192 + d * 3 + s3;
 }
 
-// one launch reduces the weight partials [S][rows][cols] and (optionally) the bias partials [S][rows]
-__global__ void reduce_partials_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
-                                       float* __restrict__ out, float* __restrict__ bout, int S, int rows, int cols,
-                                       int perm_heads, int accumulate) {
-  // 64 elements x 4 partial-groups per workgroup: 4x the loads in flight of a one-thread-per-element sum;
-  // the 4 group sums are combined in a fixed order (deterministic).
-  __shared__ float red[4][64];
-  const long long n = (long long)rows * cols;
-  const long long nt = n + (bpart ? rows : 0);
-  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  for (long long base = blockIdx.x * 64LL; base < nt; base += (long long)gridDim.x * 64) {
-    const long long i = base + el;
-    float a = 0.f;
-    if (i < n) {
-#pragma unroll 4
-      for (int s = sg; s < S; s += 4) a += part[(size_t)s * n + i];
-    } else if (i < nt) {
-      const int r = (int)(i - n);
-      for (int s = sg; s < S; s += 4) a += bpart[(size_t)s * rows + r];
-    }
-    red[sg][el] = a;
-    __syncthreads();
-    if (sg == 0 && i < nt) {
-      const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-      if (i < n) {
-        const int r = (int)(i / cols), c = (int)(i % cols);
-        const int orow = perm_heads > 0 ? qkv_row(r, perm_heads) : r;
-        float* o = out + (size_t)orow * cols + c;
-        *o = accumulate ? (*o + t) : t;
-      } else {
-        const int r = (int)(i - n);
-        float* o = bout + (perm_heads > 0 ? qkv_row(r, perm_heads) : r);
-        *o = accumulate ? (*o + t) : t;
-      }
-    }
-    __syncthreads();
-  }
+// weight partials [S][No][Ki] and bias partials [S][No] -> two jobs of the batched reduction (reduce.hip)
+int submit_tn_reduce(const GemmTN& p, float* dW, float* db, int S, int perm_heads, int accumulate, hipStream_t st) {
+  RgbnmReduceJob j;
+  j.part = p.part; j.stride = (long long)p.No * p.Ki; j.out = dW; j.n = p.No * p.Ki; j.S = S; j.cols = p.Ki;
+  j.perm_heads = perm_heads; j.accumulate = accumulate; j.epw = 64;
+  const int rc = rgbnm_reduce_submit(j, st);
+  if (rc != RGBNM_OK || !db) return rc;
+  j.part = p.bpart; j.stride = p.No; j.out = db; j.n = p.No; j.cols = 1;
+  return rgbnm_reduce_submit(j, st);
 }
 
 template <typename T>
@@ -558,11 +530,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
                                           &Sp, st);
       if (rc < 0) return rc;
       if (rc == 0) {
-        const long long n = (long long)p.No * p.Ki + (db ? p.No : 0);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(4096LL, cdivl(n, 64))), dim3(256), 0, st, p.part,
-                           db ? p.bpart : nullptr, dW, db, Sp, p.No, p.Ki, perm_heads, accumulate);
-        LAUNCH_CHECK();
-        return RGBNM_OK;
+        return submit_tn_reduce(p, dW, db, Sp, perm_heads, accumulate, st);
       }
     }
   }
@@ -586,11 +554,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
     else hipLaunchKernelGGL((gemm_tn_kernel<T, 2, false>), dim3(tiles * ((S + 7) / 8) * 8), dim3(256), 0, st, p);
   }
   LAUNCH_CHECK();
-  const long long n = (long long)p.No * p.Ki + (db ? p.No : 0);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)min(4096LL, cdivl(n, 64))), dim3(256), 0, st, p.part,
-                     db ? p.bpart : nullptr, dW, db, S, p.No, p.Ki, perm_heads, accumulate);
-  LAUNCH_CHECK();
-  return RGBNM_OK;
+  return submit_tn_reduce(p, dW, db, S, perm_heads, accumulate, st);
 }
 
 // ------------------------------------------------------------------------------------------------

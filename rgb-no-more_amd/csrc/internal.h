@@ -21,5 +21,14 @@ int rgbnm_launch_nt_wres(int epi, const void* A, int lda, const void* W, int ldw
 // Row-panel N = 192 bf16 NT GEMM with a pipelined reduction (gemm_nt_kpipe.hip).  Same return convention.
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, int M, int N, int K, hipStream_t st);
+// Batched reduction of split partials (reduce.hip): out[map(i)] (+)= sum_s part[s * stride + i], i < n.
+// epw = elements per workgroup: 64 (4 partial-groups; S up to ~64) or 8 (32 partial-groups; S in the hundreds).
+struct RgbnmReduceJob {
+  const float* part; long long stride; float* out;
+  int n, S, cols, perm_heads, accumulate, epw;      // perm_heads > 0: row i / cols is a de-interleaved qkv row
+};
+void rgbnm_reduce_defer_begin();                     // queue the following submits ...
+int rgbnm_reduce_defer_flush(hipStream_t st);        // ... and run them as one launch
+int rgbnm_reduce_submit(const RgbnmReduceJob& job, hipStream_t st);
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st);
 void rgbnm_trace_end(int slot, hipStream_t st);

@@ -4,6 +4,7 @@
 // statistics in fp32 with a two-pass (mean, then centred variance) reduction held in registers.
 #include "common.h"
 #include "../../include/rgbnm.h"
+#include "internal.h"
 
 namespace {
 
@@ -127,24 +128,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// 32 columns per workgroup, 8 row-groups stride through the partial blocks (fixed order => deterministic)
-__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, int nblk, int E, int accumulate) {
-  __shared__ float red[32][9];
-  const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;   // 8 columns x 32 row groups per workgroup
-  const int e = blockIdx.x * 8 + cl;           // 2E is a multiple of 8
-  const int which = e / E, c = e % E;
-  float a = 0.f;
-  for (int b = rg; b < nblk; b += 32) a += part[((size_t)b * 2 + which) * E + c];
-  red[rg][cl] = a;
-  __syncthreads();
-  if (rg == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) t += red[r][cl];
-    float* o = (which == 0 ? dgamma : dbeta) + c;
-    *o = accumulate ? (*o + t) : t;
-  }
+// partial blocks [nblk][2][E] (gamma | beta) -> two jobs of the batched reduction (reduce.hip)
+int submit_ln_reduce(const float* part, float* dgamma, float* dbeta, int nblk, int E, int accumulate, hipStream_t st) {
+  RgbnmReduceJob j;
+  j.part = part; j.stride = 2LL * E; j.out = dgamma; j.n = E; j.S = nblk; j.cols = 1; j.perm_heads = 0;
+  j.accumulate = accumulate; j.epw = 8;
+  const int rc = rgbnm_reduce_submit(j, st);
+  if (rc != RGBNM_OK) return rc;
+  j.part = part + E; j.out = dbeta;
+  return rgbnm_reduce_submit(j, st);
 }
 
 // ---- head pooling: pooled[b] = mean_t LN(x[b,t,:])  (one workgroup per image) ------------------------
@@ -284,9 +276,7 @@ int ln_bwd_t(const void* dy, const void* x, const float* g, const float* mean, c
   else if (E == 384) hipLaunchKernelGGL((ln_bwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 8), dim3(256), 0, st, ws, dgamma, dbeta, grid, E, accumulate);
-  LAUNCH_CHECK();
-  return RGBNM_OK;
+  return submit_ln_reduce(ws, dgamma, dbeta, grid, E, accumulate, st);
 }
 
 }  // namespace
@@ -347,9 +337,7 @@ int rgbnm_head_pool_bwd(int dtype, const void* dpooled, const void* x, const flo
   else return RGBNM_EINVAL;
 #undef POOLB
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(2 * E / 8), dim3(256), 0, st, ws, dgamma, dbeta, B, E, accumulate);
-  LAUNCH_CHECK();
-  return RGBNM_OK;
+  return submit_ln_reduce(ws, dgamma, dbeta, B, E, accumulate, (hipStream_t)st);
 }
 
 }  // extern "C"

@@ -93,12 +93,23 @@ const char* rgbnm_strerror(int code) {
   }
 }
 
+// workspace regions of one block backward: fc2 dW | fc1 dW | proj dW | qkv dW | LN2 | LN1 ; returns the total
+static size_t block_ws_offsets(int M, int E, int I, size_t (&off)[7]) {
+  const size_t sz[6] = {rgbnm_gemm_tn_workspace(M, E, 4 * E), rgbnm_gemm_tn_workspace(M, 4 * E, E),
+                        rgbnm_gemm_tn_workspace(M, E, I),     rgbnm_gemm_tn_workspace(M, 3 * I, E),
+                        rgbnm_layernorm_bwd_workspace(M, E),  rgbnm_layernorm_bwd_workspace(M, E)};
+  off[0] = 0;
+  for (int i = 0; i < 6; ++i) off[i + 1] = off[i] + ((sz[i] + 255) & ~(size_t)255);
+  return off[6];
+}
+
 size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* c) {
   if (!c) return 0;
   const int M = c->B * c->N, E = c->E, I = c->heads * 64;
-  size_t w = rgbnm_gemm_tn_workspace(M, 4 * E, E);
-  w = max_sz(w, rgbnm_gemm_tn_workspace(M, 3 * I, E));
-  w = max_sz(w, rgbnm_gemm_tn_workspace(M, E, 4 * E));
+  // a block's backward keeps the partials of its four weight-gradient GEMMs and two LayerNorms side by side until
+  // the one batched reduction at its end (block_ws_offsets below)
+  size_t off[7];
+  size_t w = block_ws_offsets(M, E, I, off);
   w = max_sz(w, rgbnm_gemm_tn_workspace(M, E, 384));
   w = max_sz(w, rgbnm_gemm_tn_workspace(c->B, 1024, E));
   w = max_sz(w, rgbnm_layernorm_bwd_workspace(M, E));
@@ -127,26 +138,35 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
                         const rgbnm_block_grads* g, const rgbnm_block_scratch* s, const void* dy, void* dx, void* st) {
   if (!c || !p || !a || !g || !s || !dy || !dx) return RGBNM_EINVAL;
   const int dt = c->dtype, M = c->B * c->N, E = c->E, I = c->heads * 64;
+  size_t off[7];
+  if (s->ws_bytes < block_ws_offsets(M, E, I, off)) return RGBNM_EWORKSPACE;
+  char* wsb = (char*)s->ws;
+#define WS(i) (wsb + off[i]), (off[(i) + 1] - off[i])
+  rgbnm_reduce_defer_begin();     // the 12 partial reductions of this block run as one launch at the end
+  const int rc = [&]() -> int {
   // ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ------------------------------------
-  TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, s->ws, s->ws_bytes, st));
+  TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DGELU, dy, E, p->w2_t, E, s->du, 4 * E, 0, a->u, 4 * E, 0, 0, 0, 0, M, 4 * E, E, 0,
                     st));
-  TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, s->ws, s->ws_bytes, st));
+  TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, WS(1), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->du, 4 * E, p->w1_t, 4 * E, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 4 * E, 0,
                     st));
   TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid, g->dln2_g, g->dln2_b, M,
-                          E, 0, s->ws, s->ws_bytes, st));
+                          E, 0, WS(4), st));
   // ---- attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in)))) -------------------------------
-  TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, s->ws, s->ws_bytes, st));
+  TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, WS(2), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dx_mid, E, p->wproj_t, E, s->dattn, I, 0, 0, 0, 0, 0, 0, 0, M, I, E, 0, st));
   TRY(rgbnm_attention_bwd(dt, a->qkv, a->attn, s->dattn, a->lse, s->dqkv, c->B, c->N, c->heads, c->attn_scale, st));
-  TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, s->ws, s->ws_bytes,
-                    st));
+  TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dqkv, 3 * I, p->wqkv_t, 3 * I, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 3 * I,
                     0, st));
   TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_in, p->ln1_g, a->mean1, a->rstd1, s->dx_mid, dx, g->dln1_g, g->dln1_b, M,
-                          E, 0, s->ws, s->ws_bytes, st));
+                          E, 0, WS(5), st));
   return RGBNM_OK;
+  }();
+#undef WS
+  const int rf = rgbnm_reduce_defer_flush((hipStream_t)st);
+  return rc != RGBNM_OK ? rc : rf;
 }
 
 int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* c, int in_dtype, const void* y, const void* cbcr, const float* conv16,
