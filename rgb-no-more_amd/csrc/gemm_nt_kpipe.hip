@@ -30,13 +30,25 @@ constexpr int NVEC = (BM * (BN / 8) + NTHREADS - 1) / NTHREADS;      // 12 outpu
 static_assert(BM * CP * 2 <= NSTAGE * STAGE, "staging tile lives in the ring");
 static_assert(SMEM <= 160 * 1024, "LDS");
 
-enum { EPI_NONE = 0, EPI_RES = 1 };
+enum { EPI_NONE = 0, EPI_RES = 1, EPI_LNBWD = 2 };
+constexpr int LN_E = 192, LN_GROUPS = NTHREADS / 16, LN_ITERS = BM / LN_GROUPS;   // 28 row groups of 16 lanes, 8 rounds
+constexpr int RED_OFF = 90112;                // column-reduction scratch behind the staging tile
+static_assert(BM * CP * 2 <= RED_OFF && RED_OFF + LN_GROUPS * (LN_E + 4) * 4 <= NSTAGE * STAGE, "LN scratch");
 
 struct KpArgs {
   const bf16* A; const bf16* W; bf16* C; const float* bias; const bf16* R;
   int lda, ldw, ldc, ldr;
   int M, K, rows_per_wg, npanels;
+  // EPI_LNBWD: C = [R +] LayerNorm'(A.W^T) w.r.t. its input X (saved mean / rstd), partial dgamma/dbeta per panel
+  const bf16* X; const float* gamma; const float* mean; const float* rstd; float* part;
+  int ldx;
 };
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 __device__ __forceinline__ int fswz(int row) {
   return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
@@ -61,6 +73,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
       const int idx = tid + NTHREADS * i, row = idx / (BN / 8), vec = idx % (BN / 8);
       const int rr = row < rows ? row : rows - 1;
       rv[i] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)(m0 + rr) * p.ldr + vec * 8);
+    }
+  }
+  // EPI_LNBWD: the LayerNorm input rows, their statistics and the residual gradient, also ahead of the loop
+  const int l16 = tid & 15, grp = tid >> 4;
+  bf16x4 lx[LN_ITERS][3], lr[LN_ITERS][3];
+  float lmu[LN_ITERS], lrs[LN_ITERS];
+  f32x4 gm[3];
+  if (EPI == EPI_LNBWD) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) gm[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
+#pragma unroll
+    for (int it = 0; it < LN_ITERS; ++it) {
+      const int row = it * LN_GROUPS + grp, rr = m0 + (row < rows ? row : rows - 1);
+      lmu[it] = p.mean[rr];
+      lrs[it] = p.rstd[rr];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        lx[it][v] = *reinterpret_cast<const bf16x4*>(p.X + (size_t)rr * p.ldx + (v * 16 + l16) * 4);
+      }
     }
   }
   if (w < BN / 64) {
@@ -151,8 +182,78 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
       v += *reinterpret_cast<const f32x4*>(Bs + nl);
       store4<bf16>(Cs + ml * CP + nl, v);
     }
+  if (EPI == EPI_LNBWD && p.R) {   // residual gradient rows: requested now (the accumulators are dead), used below
+#pragma unroll
+    for (int it = 0; it < LN_ITERS; ++it) {
+      const int row = it * LN_GROUPS + grp, rr = m0 + (row < rows ? row : rows - 1);
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+        lr[it][v] = *reinterpret_cast<const bf16x4*>(p.R + (size_t)rr * p.ldr + (v * 16 + l16) * 4);
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (EPI == EPI_LNBWD) {
+    // ---- LayerNorm backward on the staged rows (same arithmetic as ln_bwd_kernel, layernorm.hip): 16 lanes per row
+    f32x4 dg[3], db[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < LN_ITERS; ++it) {
+      const int row = it * LN_GROUPS + grp;
+      if (row < rows) {
+        const float mu = lmu[it], rs = lrs[it];
+        f32x4 xh[3], gv[3];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          const bf16x4 dvb = *reinterpret_cast<const bf16x4*>(Cs + row * CP + (v * 16 + l16) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float dv = (float)dvb[i];
+            xh[v][i] = ((float)lx[it][v][i] - mu) * rs;
+            gv[v][i] = dv * gm[v][i];
+            s1 += gv[v][i];
+            s2 += gv[v][i] * xh[v][i];
+            dg[v][i] += dv * xh[v][i];
+            db[v][i] += dv;
+          }
+        }
+        const float c1 = group16_sum(s1) * (1.f / LN_E), c2 = group16_sum(s2) * (1.f / LN_E);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          f32x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2);
+          if (p.R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += (float)lr[it][v][i];
+          }
+          store4<bf16>(p.C + (size_t)(m0 + row) * p.ldc + (v * 16 + l16) * 4, o);
+        }
+      }
+    }
+    // panel-level column sums of dgamma / dbeta (fixed order => deterministic); reduced across panels by reduce.hip
+    float* red = reinterpret_cast<float*>(smem + RED_OFF);
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[grp * (LN_E + 4) + (v * 16 + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
+      __syncthreads();
+      for (int e = tid; e < LN_E; e += NTHREADS) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < LN_GROUPS; ++r) a += red[r * (LN_E + 4) + e];
+        p.part[((size_t)panel * 2 + pass) * LN_E + e] = a;
+      }
+    }
+    return;
+  }
   // ---- pass 2: valid rows x 24 vectors of 8 features, coalesced 384-byte rows
 #pragma unroll
   for (int i = 0; i < NVEC; ++i) {
@@ -185,6 +286,29 @@ int launch(const KpArgs& p, hipStream_t st) {
 
 }  // namespace
 
+// dx = [dres +] LayerNorm'(A . W^T): the dX GEMM of fc1 / qkv with the LayerNorm backward fused into its epilogue
+// (saves writing and re-reading the [M,192] gradient and one launch).  part: [npanels][2][192] partial dgamma/dbeta;
+// *npanels_out tells the caller how many slices to reduce.  Returns 1 when the shape is not eligible.
+int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, const void* X, int ldx,
+                                const float* gamma, const float* mean, const float* rstd, const void* dres, int ldr,
+                                void* dx, int ldc, float* part, int* npanels_out, int M, int N, int K, hipStream_t st) {
+  if (N != BN || K % 64 || K < 256 || lda % 8 || ldw % 8 || ldc % 4 || ldx % 4 || (dres && ldr % 4) || M < 8192) return 1;
+  KpArgs p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)dx; p.bias = nullptr; p.R = (const bf16*)dres;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
+  p.X = (const bf16*)X; p.gamma = gamma; p.mean = mean; p.rstd = rstd; p.part = part; p.ldx = ldx;
+  int rows = cdiv(M, 256);
+  if (rows > BM) rows = BM;
+  p.rows_per_wg = rows;
+  p.npanels = cdiv(M, rows);
+  *npanels_out = p.npanels;
+  const double mn = (double)M * N;
+  const int slot = rgbnm_trace_begin(TR_NT, 2.0 * mn * K, ((double)M * K + (double)N * K) * 2.0 + mn * 2.0 * (dres ? 3.0 : 2.0), st);
+  const int rc = launch<EPI_LNBWD>(p, st);
+  rgbnm_trace_end(slot, st);
+  return rc;
+}
+
 // returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, int M, int N, int K, hipStream_t st) {
@@ -194,6 +318,7 @@ int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ld
   KpArgs p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)C; p.bias = bias; p.R = (const bf16*)R;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
+  p.X = nullptr; p.gamma = p.mean = p.rstd = nullptr; p.part = nullptr; p.ldx = 0;
   // one panel per CU when it fits (M / 256 rows, at most 224); otherwise whole rounds of 224-row panels
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;

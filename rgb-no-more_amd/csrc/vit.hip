@@ -27,7 +27,7 @@ hipEvent_t take_event() {
   return e;
 }
 struct Opt { const char* name; int value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"trace", 0}, {"tn_wgs", 512}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"trace", 0}, {"tn_wgs", 512}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -93,6 +93,25 @@ const char* rgbnm_strerror(int code) {
   }
 }
 
+// dx = dres + LayerNorm'(A . W^T) in one launch (gemm_nt_kpipe.hip) + two jobs for the batched reduction.
+// false: not eligible (fp32, E != 192, small M, option ln_fuse = 0) -> the caller runs GEMM and LayerNorm separately.
+static bool fused_dx_lnbwd(int dt, const void* A, int lda, const void* Wt, int ldw, const void* x, const float* gamma,
+                           const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+                           float* dbeta, int M, int E, int K, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (dt != RGBNM_DT_BF16 || E != 192 || !rgbnm_get_option("ln_fuse") || !rgbnm_get_option("nt_kpipe")) return false;
+  if (ws_bytes < (size_t)cdiv(M, cdiv(M, 256)) * 2 * E * sizeof(float)) return false;
+  int npanels = 0;
+  const int rc = rgbnm_launch_nt_kpipe_lnbwd(A, lda, Wt, ldw, x, E, gamma, mean, rstd, dres, E, dx, E, (float*)ws,
+                                             &npanels, M, E, K, st);
+  if (rc != RGBNM_OK) return false;
+  RgbnmReduceJob j;
+  j.part = (const float*)ws; j.stride = 2LL * E; j.out = dgamma; j.n = E; j.S = npanels; j.cols = 1; j.perm_heads = 0;
+  j.accumulate = 0; j.epw = 8;
+  if (rgbnm_reduce_submit(j, st) != RGBNM_OK) return false;
+  j.part = (const float*)ws + E; j.out = dbeta;
+  return rgbnm_reduce_submit(j, st) == RGBNM_OK;
+}
+
 // workspace regions of one block backward: fc2 dW | fc1 dW | proj dW | qkv dW | LN2 | LN1 ; returns the total
 static size_t block_ws_offsets(int M, int E, int I, size_t (&off)[7]) {
   const size_t sz[6] = {rgbnm_gemm_tn_workspace(M, E, 4 * E), rgbnm_gemm_tn_workspace(M, 4 * E, E),
@@ -149,19 +168,26 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DGELU, dy, E, p->w2_t, E, s->du, 4 * E, 0, a->u, 4 * E, 0, 0, 0, 0, M, 4 * E, E, 0,
                     st));
   TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, WS(1), st));
-  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->du, 4 * E, p->w1_t, 4 * E, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 4 * E, 0,
-                    st));
-  TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid, g->dln2_g, g->dln2_b, M,
-                          E, 0, WS(4), st));
+  // dx_mid = dy + LN2'(du . W1): LayerNorm backward fused into the GEMM epilogue when eligible
+  if (!fused_dx_lnbwd(dt, s->du, 4 * E, p->w1_t, 4 * E, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid,
+                      g->dln2_g, g->dln2_b, M, E, 4 * E, WS(4), (hipStream_t)st)) {
+    TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->du, 4 * E, p->w1_t, 4 * E, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 4 * E,
+                      0, st));
+    TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid, g->dln2_g, g->dln2_b,
+                            M, E, 0, WS(4), st));
+  }
   // ---- attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in)))) -------------------------------
   TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, WS(2), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dx_mid, E, p->wproj_t, E, s->dattn, I, 0, 0, 0, 0, 0, 0, 0, M, I, E, 0, st));
   TRY(rgbnm_attention_bwd(dt, a->qkv, a->attn, s->dattn, a->lse, s->dqkv, c->B, c->N, c->heads, c->attn_scale, st));
   TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
-  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dqkv, 3 * I, p->wqkv_t, 3 * I, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 3 * I,
-                    0, st));
-  TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_in, p->ln1_g, a->mean1, a->rstd1, s->dx_mid, dx, g->dln1_g, g->dln1_b, M,
-                          E, 0, WS(5), st));
+  if (!fused_dx_lnbwd(dt, s->dqkv, 3 * I, p->wqkv_t, 3 * I, a->x_in, p->ln1_g, a->mean1, a->rstd1, s->dx_mid, dx,
+                      g->dln1_g, g->dln1_b, M, E, 3 * I, WS(5), (hipStream_t)st)) {
+    TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dqkv, 3 * I, p->wqkv_t, 3 * I, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E,
+                      3 * I, 0, st));
+    TRY(rgbnm_layernorm_bwd(dt, s->dxn, a->x_in, p->ln1_g, a->mean1, a->rstd1, s->dx_mid, dx, g->dln1_g, g->dln1_b, M,
+                            E, 0, WS(5), st));
+  }
   return RGBNM_OK;
   }();
 #undef WS

@@ -172,3 +172,32 @@ def test_state_dict_roundtrip_and_torch_optimizers():
     m2.compute_dtype = torch.float32
     with torch.no_grad():
         assert torch.equal(m2(y, c), m(y, c))
+
+
+def test_bf16_backward_with_and_without_fused_layernorm_backward():
+    """ln_fuse=1 folds the LayerNorm backward into the epilogue of the preceding dX GEMM (block backward).  Both
+    settings on the same weights and inputs (48 images = 9408 tokens, enough for the row-panel kernels): input-side
+    gradients are bit-identical, gamma / beta gradients are summed in a different grouping (fp32 rounding only)."""
+    from rgb_no_more_amd import lib as L
+    lib = L.lib()
+    m, sd, _, _, _ = build("ti_d2", torch.bfloat16)
+    B = 48
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 81)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 82)).to(DEV)
+    old = lib.rgbnm_get_option(b"ln_fuse")
+    grads = {}
+    try:
+        for fuse in (0, 1):
+            L.check(lib.rgbnm_set_option(b"ln_fuse", fuse))
+            m.zero_grad(set_to_none=True)
+            m.train()
+            out = m(y, c)
+            out.float().square().mean().backward()
+            grads[fuse] = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()}
+    finally:
+        lib.rgbnm_set_option(b"ln_fuse", old)
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert torch.isfinite(b).all()
+        rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
+        assert rel < 1e-4, (n, rel)
