@@ -224,6 +224,15 @@ typedef struct rgbnm_block_scratch {     /* backward temporaries, caller-owned, 
 size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* cfg);
 int rgbnm_vit_block_fwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, const rgbnm_block_acts* a,
                         void* stream);
+/* Chained forward over consecutive blocks: when rgbnm_vit_ln_chain(cfg) is 1 the epilogue of this block's fc2 can
+ * also produce the NEXT block's LN1 (next_a->xn1 / mean1 / rstd1 from next_p->ln1_g / ln1_b; requires
+ * next_a->x_in == a->x_out), and flags bit 0 tells a block that its own LN1 was produced that way and must be
+ * skipped.  next_p / next_a may be NULL.  rgbnm_vit_block_fwd(cfg, p, a, s) == rgbnm_vit_block_fwd_chain(cfg, p, a, 0,
+ * NULL, NULL, s).  (LayerNorm stays reference arithmetic; only the launch and one read of x are saved.) */
+int rgbnm_vit_ln_chain(const rgbnm_vit_cfg* cfg);
+int rgbnm_vit_block_fwd_chain(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, const rgbnm_block_acts* a,
+                              int flags, const rgbnm_block_params* next_p, const rgbnm_block_acts* next_a,
+                              void* stream);
 /* dy = grad wrt x_out, dx = grad wrt x_in (dx may alias dy). */
 int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, const rgbnm_block_acts* a,
                         const rgbnm_block_grads* g, const rgbnm_block_scratch* s, const void* dy, void* dx,

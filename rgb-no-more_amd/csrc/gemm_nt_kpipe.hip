@@ -30,7 +30,7 @@ constexpr int NVEC = (BM * (BN / 8) + NTHREADS - 1) / NTHREADS;      // 12 outpu
 static_assert(BM * CP * 2 <= NSTAGE * STAGE, "staging tile lives in the ring");
 static_assert(SMEM <= 160 * 1024, "LDS");
 
-enum { EPI_NONE = 0, EPI_RES = 1, EPI_LNBWD = 2 };
+enum { EPI_NONE = 0, EPI_RES = 1, EPI_LNBWD = 2, EPI_RES_LN = 3 };
 constexpr int LN_E = 192, LN_GROUPS = NTHREADS / 16, LN_ITERS = BM / LN_GROUPS;   // 28 row groups of 16 lanes, 8 rounds
 constexpr int RED_OFF = 90112;                // column-reduction scratch behind the staging tile
 static_assert(BM * CP * 2 <= RED_OFF && RED_OFF + LN_GROUPS * (LN_E + 4) * 4 <= NSTAGE * STAGE, "LN scratch");
@@ -42,6 +42,8 @@ struct KpArgs {
   // EPI_LNBWD: C = [R +] LayerNorm'(A.W^T) w.r.t. its input X (saved mean / rstd), partial dgamma/dbeta per panel
   const bf16* X; const float* gamma; const float* mean; const float* rstd; float* part;
   int ldx;
+  // EPI_RES_LN: C = A.W^T + bias + R, then Y2 = LayerNorm(C) (gamma, beta) with its row statistics saved
+  const float* beta; bf16* Y2; float* mean_o; float* rstd_o; float eps; int ldy2;
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -80,6 +82,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
   bf16x4 lx[LN_ITERS][3], lr[LN_ITERS][3];
   float lmu[LN_ITERS], lrs[LN_ITERS];
   f32x4 gm[3];
+  f32x4 bt[3];
+  if (EPI == EPI_RES_LN) {     // residual rows in the 16-lanes-per-row layout of the LayerNorm pass
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      gm[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
+      bt[v] = *reinterpret_cast<const f32x4*>(p.beta + (v * 16 + l16) * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < LN_ITERS; ++it) {
+      const int row = it * LN_GROUPS + grp, rr = m0 + (row < rows ? row : rows - 1);
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+        lr[it][v] = *reinterpret_cast<const bf16x4*>(p.R + (size_t)rr * p.ldr + (v * 16 + l16) * 4);
+    }
+  }
   if (EPI == EPI_LNBWD) {
 #pragma unroll
     for (int v = 0; v < 3; ++v) gm[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
@@ -193,6 +210,51 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (EPI == EPI_RES_LN) {
+    // ---- residual add, then LayerNorm forward of the finished rows (same arithmetic as ln_fwd_kernel)
+#pragma unroll
+    for (int it = 0; it < LN_ITERS; ++it) {
+      const int row = it * LN_GROUPS + grp;
+      if (row < rows) {
+        f32x4 xv[3];
+        float sm = 0.f;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          const bf16x4 cb = *reinterpret_cast<const bf16x4*>(Cs + row * CP + (v * 16 + l16) * 4);
+          bf16x4 xb;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            xb[i] = (bf16)((float)cb[i] + (float)lr[it][v][i]);     // the residual stream is stored in bf16 ...
+            xv[v][i] = (float)xb[i];                                // ... and LayerNorm sees exactly those values
+          }
+          *reinterpret_cast<bf16x4*>(p.C + (size_t)(m0 + row) * p.ldc + (v * 16 + l16) * 4) = xb;
+          sm += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+        }
+        const float mu = group16_sum(sm) * (1.f / LN_E);
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float d = xv[v][i] - mu;
+            q += d * d;
+          }
+        const float rs = rsqrtf(group16_sum(q) * (1.f / LN_E) + p.eps);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          f32x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (xv[v][i] - mu) * rs * gm[v][i] + bt[v][i];
+          store4<bf16>(p.Y2 + (size_t)(m0 + row) * p.ldy2 + (v * 16 + l16) * 4, o);
+        }
+        if (l16 == 0) {
+          p.mean_o[m0 + row] = mu;
+          p.rstd_o[m0 + row] = rs;
+        }
+      }
+    }
+    return;
+  }
   if (EPI == EPI_LNBWD) {
     // ---- LayerNorm backward on the staged rows (same arithmetic as ln_bwd_kernel, layernorm.hip): 16 lanes per row
     f32x4 dg[3], db[3];
@@ -286,6 +348,27 @@ int launch(const KpArgs& p, hipStream_t st) {
 
 }  // namespace
 
+// x = A . W^T + bias + R ; y = LayerNorm(x): fc2 (+ the next block's LN1) and proj (+ LN2) in one launch each.
+int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* R,
+                                 int ldr, void* x, int ldc, const float* gamma, const float* beta, void* y, int ldy,
+                                 float* mean, float* rstd, float eps, int M, int N, int K, hipStream_t st) {
+  if (N != BN || K % 64 || K < 128 || lda % 8 || ldw % 8 || ldc % 4 || ldr % 4 || ldy % 4 || M < 8192) return 1;
+  KpArgs p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)x; p.bias = bias; p.R = (const bf16*)R;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
+  p.X = nullptr; p.mean = p.rstd = nullptr; p.part = nullptr; p.ldx = 0;
+  p.gamma = gamma; p.beta = beta; p.Y2 = (bf16*)y; p.mean_o = mean; p.rstd_o = rstd; p.eps = eps; p.ldy2 = ldy;
+  int rows = cdiv(M, 256);
+  if (rows > BM) rows = BM;
+  p.rows_per_wg = rows;
+  p.npanels = cdiv(M, rows);
+  const double mn = (double)M * N;
+  const int slot = rgbnm_trace_begin(TR_NT, 2.0 * mn * K, ((double)M * K + (double)N * K) * 2.0 + mn * 2.0 * 3.0, st);
+  const int rc = launch<EPI_RES_LN>(p, st);
+  rgbnm_trace_end(slot, st);
+  return rc;
+}
+
 // dx = [dres +] LayerNorm'(A . W^T): the dX GEMM of fc1 / qkv with the LayerNorm backward fused into its epilogue
 // (saves writing and re-reading the [M,192] gradient and one launch).  part: [npanels][2][192] partial dgamma/dbeta;
 // *npanels_out tells the caller how many slices to reduce.  Returns 1 when the shape is not eligible.
@@ -297,6 +380,7 @@ int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, 
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)dx; p.bias = nullptr; p.R = (const bf16*)dres;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
   p.X = (const bf16*)X; p.gamma = gamma; p.mean = mean; p.rstd = rstd; p.part = part; p.ldx = ldx;
+  p.beta = nullptr; p.Y2 = nullptr; p.mean_o = p.rstd_o = nullptr; p.eps = 0.f; p.ldy2 = 0;
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;
   p.rows_per_wg = rows;
@@ -319,6 +403,7 @@ int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ld
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)C; p.bias = bias; p.R = (const bf16*)R;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
   p.X = nullptr; p.gamma = p.mean = p.rstd = nullptr; p.part = nullptr; p.ldx = 0;
+  p.beta = nullptr; p.Y2 = nullptr; p.mean_o = p.rstd_o = nullptr; p.eps = 0.f; p.ldy2 = 0;
   // one panel per CU when it fits (M / 256 rows, at most 224); otherwise whole rounds of 224-row panels
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;

@@ -21,6 +21,10 @@ int rgbnm_launch_nt_wres(int epi, const void* A, int lda, const void* W, int ldw
 // Row-panel N = 192 bf16 NT GEMM with a pipelined reduction (gemm_nt_kpipe.hip).  Same return convention.
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, int M, int N, int K, hipStream_t st);
+// Linear + bias + residual + LayerNorm of the result in one launch (gemm_nt_kpipe.hip); 1 = not eligible.
+int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* R,
+                                 int ldr, void* x, int ldc, const float* gamma, const float* beta, void* y, int ldy,
+                                 float* mean, float* rstd, float eps, int M, int N, int K, hipStream_t st);
 // fc1 / qkv dX GEMM with the LayerNorm backward fused into the epilogue (gemm_nt_kpipe.hip); 1 = not eligible.
 int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, const void* X, int ldx,
                                 const float* gamma, const float* mean, const float* rstd, const void* dres, int ldr,

@@ -136,21 +136,49 @@ size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* c) {
   return w;
 }
 
-int rgbnm_vit_block_fwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, const rgbnm_block_acts* a, void* st) {
+int rgbnm_vit_ln_chain(const rgbnm_vit_cfg* c) {
+  if (!c) return 0;
+  return c->dtype == RGBNM_DT_BF16 && c->E == 192 && c->B * c->N >= 8192 && rgbnm_get_option("ln_fuse") &&
+         rgbnm_get_option("nt_kpipe");
+}
+
+int rgbnm_vit_block_fwd_chain(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, const rgbnm_block_acts* a, int flags,
+                              const rgbnm_block_params* next_p, const rgbnm_block_acts* next_a, void* st) {
   if (!c || !p || !a) return RGBNM_EINVAL;
   const int dt = c->dtype, M = c->B * c->N, E = c->E, I = c->heads * 64;
-  TRY(rgbnm_layernorm_fwd(dt, a->x_in, p->ln1_g, p->ln1_b, a->xn1, a->mean1, a->rstd1, M, E, c->ln_eps, st));
+  const bool chain = rgbnm_vit_ln_chain(c) != 0;
+  if ((flags & 1) && !chain) return RGBNM_EINVAL;
+  if (!(flags & 1))
+    TRY(rgbnm_layernorm_fwd(dt, a->x_in, p->ln1_g, p->ln1_b, a->xn1, a->mean1, a->rstd1, M, E, c->ln_eps, st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, a->xn1, E, p->wqkv, E, a->qkv, 3 * I, p->bqkv_perm, 0, 0, 0, 0, 0, 0, M,
                     3 * I, E, 0, st));
   TRY(rgbnm_attention_fwd(dt, a->qkv, a->attn, a->lse, c->B, c->N, c->heads, c->attn_scale, st));
-  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_RES, a->attn, I, p->wproj, I, a->x_mid, E, p->bproj, a->x_in, E, 0, 0, 0, 0, M, E,
-                    I, 0, st));
-  TRY(rgbnm_layernorm_fwd(dt, a->x_mid, p->ln2_g, p->ln2_b, a->xn2, a->mean2, a->rstd2, M, E, c->ln_eps, st));
+  // x_mid = x_in + proj(attn) ; xn2 = LN2(x_mid): one launch when chaining is on
+  if (!chain || rgbnm_launch_nt_kpipe_res_ln(a->attn, I, p->wproj, I, p->bproj, a->x_in, E, a->x_mid, E, p->ln2_g,
+                                             p->ln2_b, a->xn2, E, a->mean2, a->rstd2, c->ln_eps, M, E, I,
+                                             (hipStream_t)st) != RGBNM_OK) {
+    TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_RES, a->attn, I, p->wproj, I, a->x_mid, E, p->bproj, a->x_in, E, 0, 0, 0, 0, M, E,
+                      I, 0, st));
+    TRY(rgbnm_layernorm_fwd(dt, a->x_mid, p->ln2_g, p->ln2_b, a->xn2, a->mean2, a->rstd2, M, E, c->ln_eps, st));
+  }
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_GELU, a->xn2, E, p->w1, E, a->gl, 4 * E, p->b1, 0, 0, a->u, 4 * E, 0, 0, M, 4 * E,
                     E, 0, st));
+  // x_out = x_mid + fc2(gl) [; next block's xn1 = LN1(x_out)]
+  if (chain && next_p && next_a) {
+    if (next_a->x_in != a->x_out) return RGBNM_EINVAL;
+    const int rc = rgbnm_launch_nt_kpipe_res_ln(a->gl, 4 * E, p->w2, 4 * E, p->b2, a->x_mid, E, a->x_out, E,
+                                                next_p->ln1_g, next_p->ln1_b, next_a->xn1, E, next_a->mean1,
+                                                next_a->rstd1, c->ln_eps, M, E, 4 * E, (hipStream_t)st);
+    if (rc != RGBNM_OK) return rc < 0 ? rc : RGBNM_EINVAL;    // rgbnm_vit_ln_chain() promised eligibility
+    return RGBNM_OK;
+  }
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_RES, a->gl, 4 * E, p->w2, 4 * E, a->x_out, E, p->b2, a->x_mid, E, 0, 0, 0, 0, M, E,
                     4 * E, 0, st));
   return RGBNM_OK;
+}
+
+int rgbnm_vit_block_fwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, const rgbnm_block_acts* a, void* st) {
+  return rgbnm_vit_block_fwd_chain(c, p, a, 0, nullptr, nullptr, st);
 }
 
 int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, const rgbnm_block_acts* a,

@@ -86,6 +86,8 @@ PROTOTYPES = {
     "rgbnm_clip_adamw_wd_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _sz, _vp]),
     "rgbnm_vit_workspace": (_sz, [_P(VitCfg)]),
     "rgbnm_vit_block_fwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _vp]),
+    "rgbnm_vit_ln_chain": (_i, [_P(VitCfg)]),
+    "rgbnm_vit_block_fwd_chain": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _i, _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
                                  _vp, _vp]),
     "rgbnm_patch_embed_fwd": (_i, [_P(VitCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -155,8 +155,14 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, st, idx, *params):
         m, a = st.model, st.arena
         assert x.data_ptr() == a.xbuf(idx).data_ptr()
-        L.check(L.lib().rgbnm_vit_block_fwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
-                                            L.stream()), "vit_block_fwd")
+        # consecutive blocks are chained: fc2 of block i also emits LN1 of block i+1 (rgbnm.h, rgbnm_vit_block_fwd_chain)
+        chain = st.ln_chain
+        last = idx + 1 >= m.depth
+        nxt_p = C.byref(m._bparams[idx + 1]) if chain and not last else None
+        nxt_a = C.byref(a.acts[idx + 1]) if chain and not last else None
+        L.check(L.lib().rgbnm_vit_block_fwd_chain(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
+                                                  1 if (chain and idx > 0) else 0, nxt_p, nxt_a, L.stream()),
+                "vit_block_fwd")
         ctx.st, ctx.idx = st, idx
         return a.xbuf(idx + 1).detach()
 
@@ -371,6 +377,7 @@ class ViT(FlatParamModule):
         self._prep(cdtype)
         arena = self._acquire_arena(B, cdtype, need_grad)
         st = _FwdState(self, arena, self._grad_buffer() if need_grad else None)
+        st.ln_chain = bool(L.lib().rgbnm_vit_ln_chain(C.byref(arena.cfg)))
         named = self._named
         h = _PatchEmbedFn.apply(x, cbcr, st, named["patchembed.projection.0.weight"],
                                 named["patchembed.projection.0.bias"])

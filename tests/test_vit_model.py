@@ -175,7 +175,8 @@ def test_state_dict_roundtrip_and_torch_optimizers():
 
 
 def test_bf16_backward_with_and_without_fused_layernorm_backward():
-    """ln_fuse=1 folds the LayerNorm backward into the epilogue of the preceding dX GEMM (block backward).  Both
+    """ln_fuse=1 folds LayerNorm forward into the proj / fc2 epilogues (chained blocks) and LayerNorm backward into the
+    epilogue of the preceding dX GEMM.  Both
     settings on the same weights and inputs (48 images = 9408 tokens, enough for the row-panel kernels): input-side
     gradients are bit-identical, gamma / beta gradients are summed in a different grouping (fp32 rounding only)."""
     from rgb_no_more_amd import lib as L
@@ -194,8 +195,11 @@ def test_bf16_backward_with_and_without_fused_layernorm_backward():
             out = m(y, c)
             out.float().square().mean().backward()
             grads[fuse] = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()}
+            grads[fuse]["__logits__"] = out.detach().float().cpu().clone()
     finally:
         lib.rgbnm_set_option(b"ln_fuse", old)
+    # forward: the chained LayerNorm (fc2 / proj epilogue) uses the arithmetic of the stand-alone kernel -> same bits
+    assert torch.equal(grads[0]["__logits__"], grads[1]["__logits__"])
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert torch.isfinite(b).all()
