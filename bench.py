@@ -266,7 +266,7 @@ def main():
                     traffic = json.load(open(tpath)).get("gemm_nt_bytes_per_launch")
                 roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "kernel": "gemm_nt (all nn.Linear forward + dX GEMMs; largest share of step time)",
+                        "kernel": "gemm_nt family (gemm_nt_wres / gemm_nt_kpipe / gemm_nt: all nn.Linear forward + dX GEMMs with their fused epilogues; largest share of step time)",
                         "launches_per_step": cnt.value // max(1, traced_steps), "traced_steps": traced_steps,
                         "avg_launch_us": round(1e3 * tms.value / cnt.value, 2),
                         "algorithmic_bytes_per_launch": round(by.value / cnt.value),

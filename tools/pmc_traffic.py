@@ -18,8 +18,8 @@ def load(d):
 def main(fetch_dir, write_dir, out):
     f, w = load(fetch_dir), load(write_dir)
     res = {}
-    for key, pat in (("gemm_nt", "gemm_nt_kernel"), ("gemm_tn", "gemm_tn_pipe_kernel"), ("attn_fwd", "attn2_fwd_kernel"),
-                     ("attn_bwd", "attn2_bwd_kernel"), ("dct_resize", "dct_resize_kernel"), ("dct_randaug", "dct_randaug_kernel")):
+    for key, pat in (("gemm_nt", "gemm_nt_"), ("gemm_tn", "gemm_tn_pipe_kernel"), ("attn_fwd", "attn2_fwd_kernel"),
+                     ("attn_bwd", "attn[23]_bwd_kernel"), ("dct_resize", "dct_resize_kernel"), ("dct_randaug", "dct_randaug_kernel")):
         ff = f[f.Kernel_Name.str.contains(pat) & (f.Counter_Name == "FETCH_SIZE")]
         ww = w[w.Kernel_Name.str.contains(pat) & (w.Counter_Name == "WRITE_SIZE")]
         if len(ff) == 0 or len(ww) == 0:
