@@ -608,8 +608,8 @@ int rgbnm_gemm_nt(int dtype, int epi, const void* A, int lda, const void* W, int
 }
 
 size_t rgbnm_gemm_tn_workspace(int M, int No, int Ki) {
-  // worst case split count is capped at 64
-  return (size_t)64 * ((size_t)No * Ki + No) * sizeof(float);
+  // worst case split count
+  return (size_t)RGBNM_TN_MAX_SPLIT * ((size_t)No * Ki + No) * sizeof(float);
 }
 
 int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int No,
@@ -617,9 +617,9 @@ int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, fl
   if (!dY || !X || !dW || !workspace) return RGBNM_EINVAL;
   if (workspace_bytes < rgbnm_gemm_tn_workspace(M, No, Ki)) return RGBNM_EWORKSPACE;
   GemmTN p;
-  p.dY = dY; p.X = X; p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki; p.S = 64;
+  p.dY = dY; p.X = X; p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki; p.S = RGBNM_TN_MAX_SPLIT;
   p.part = reinterpret_cast<float*>(workspace);
-  p.bpart = db ? p.part + (size_t)64 * No * Ki : nullptr;
+  p.bpart = db ? p.part + (size_t)RGBNM_TN_MAX_SPLIT * No * Ki : nullptr;
   p.tok_per_split = 0; p.rtiles = p.ctiles = 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) return launch_tn<bf16>(p, dW, db, perm_heads, accumulate, st);

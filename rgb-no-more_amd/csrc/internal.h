@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+constexpr int RGBNM_TN_MAX_SPLIT = 128;   // token-axis splits of a weight-gradient GEMM (workspace is sized for it)
 // Pipelined bf16 weight-gradient GEMM (gemm_tn_pipe.hip).  Returns RGBNM_OK, or 1 if the shape is not eligible
 // (caller falls back to the generic kernel), or a negative error.
 int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,

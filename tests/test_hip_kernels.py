@@ -404,3 +404,12 @@ def test_attention_bf16_backward_schedules(option, persist):
     option("attn_persist", persist)
     for shp in [(3, 196, 3), (100, 196, 3), (2, 64, 3), (1, 100, 2), (2, 33, 3), (50, 196, 6)]:
         test_attention_fwd_bwd(torch.bfloat16, *shp)
+
+
+@pytest.mark.parametrize("sq", [0, 1])
+def test_gemm_tn_bf16_square_tile_path(option, sq):
+    """tn_square=1: 192 x 192 output tiles (6 waves) for weight gradients with >= 3 such tiles; 0: 128 x 192 tiles."""
+    option("tn_square", sq)
+    for shp in [(50176, 768, 192, 0), (50176, 192, 768, 0), (50176, 576, 192, 3), (64 * 49, 576, 192, 3),
+                (256, 1000, 192, 0), (64 * 100, 1152, 384, 6), (64 * 30, 384, 384, 0)]:
+        test_gemm_tn(torch.bfloat16, *shp)
