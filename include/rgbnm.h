@@ -72,7 +72,7 @@ typedef struct rgbnm_linear_desc {
   long long bperm_off; /* bias_perm: [N] fp32 de-interleaved bias (only if perm_heads) */
   int N, K;
   int perm_heads;      /* >0 for the qkv Linear: number of heads                      */
-  int _pad;
+  int add_identity;    /* shadows hold W + I (residual Linear y = x W^T + x, plainvit.py:345-347) */
 } rgbnm_linear_desc;
 
 /* master fp32 -> per-step operand shadows for every Linear (descs_dev: device array of ndesc descriptors). */

@@ -55,6 +55,18 @@ def sincos_table(h, w, e, dtype=torch.float32):
 def patch_embed(p, y, cbcr, patch_size=16):
     feat = subblock_features(y, cbcr, patch_size)                       # (B, h, w, 384)
     B, h, w, _ = feat.shape
+    if "patchembed.linearMix.weight" in p:
+        # ver=2, use_subblock: PatchEmbedding_DCT_Separate_subblock (plainvit.py:280-352).  Y tile (256) and CbCr
+        # blocks (2 x 64; chroma patch 8 => identity sub-block matrix) are projected separately, concatenated,
+        # GELU'd ("mistakenly not added" before the concat in the reference: it acts on the concatenation),
+        # mixed by a residual Linear, then the sin-cos table is added.
+        fy = F.linear(feat[..., :256], p["patchembed.projection_Y.1.weight"], p["patchembed.projection_Y.1.bias"])
+        fc = F.linear(feat[..., 256:], p["patchembed.projection_C.1.weight"], p["patchembed.projection_C.1.bias"])
+        g = F.gelu(torch.cat([fy, fc], dim=3))
+        x = F.linear(g, p["patchembed.linearMix.weight"], p["patchembed.linearMix.bias"]) + g
+        e = x.shape[-1]
+        x = x + sincos_table(h, w, e, x.dtype).view(1, h, w, e)
+        return x.reshape(B, h * w, e)
     x = F.linear(feat, p["patchembed.projection.0.weight"], p["patchembed.projection.0.bias"])
     e = x.shape[-1]
     x = x + sincos_table(h, w, e, x.dtype).view(1, h, w, e)
@@ -106,11 +118,18 @@ def vit_forward(p, y, cbcr, depth, num_heads, emb_size, patch_size=16, return_in
     return (logits, inter) if return_inter else logits
 
 
-def param_shapes(depth=12, emb=192, heads=3, n_classes=1000, patch_size=16):
-    """The reference state_dict keys/shapes (152 tensors for depth 12)."""
+def param_shapes(depth=12, emb=192, heads=3, n_classes=1000, patch_size=16, ver=1):
+    """The reference state_dict keys/shapes (152 tensors for depth 12, ver=1; 156 for ver=2)."""
     inner = heads * 64
     fin = patch_size ** 2 + 2 * (patch_size // 2) ** 2
-    s = {"patchembed.projection.0.weight": (emb, fin), "patchembed.projection.0.bias": (emb,)}
+    if ver == 1:
+        s = {"patchembed.projection.0.weight": (emb, fin), "patchembed.projection.0.bias": (emb,)}
+    else:
+        ey, ec = emb // 6 * 4, emb // 6 * 2
+        s = {"patchembed.projection_Y.1.weight": (ey, patch_size ** 2), "patchembed.projection_Y.1.bias": (ey,),
+             "patchembed.projection_C.1.weight": (ec, 2 * (patch_size // 2) ** 2),
+             "patchembed.projection_C.1.bias": (ec,),
+             "patchembed.linearMix.weight": (emb, emb), "patchembed.linearMix.bias": (emb,)}
     for i in range(depth):
         a, b = f"encoder.{i}.0.fn.", f"encoder.{i}.1.fn."
         s[a + "eb_lrnorm1.weight"] = (emb,)

@@ -569,7 +569,7 @@ __global__ void prep_weights_kernel(const rgbnm_linear_desc* __restrict__ descs,
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(i / d.K), c = (int)(i % d.K);   // r = shadow (GEMM) row
     const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
-    const T v = from_f32<T>(master[d.w_off + (size_t)src * d.K + c]);
+    const T v = from_f32<T>(master[d.w_off + (size_t)src * d.K + c] + ((d.add_identity && r == c) ? 1.0f : 0.0f));
     shadow[d.ws_off + i] = v;
     shadow[d.wst_off + (size_t)c * d.N + r] = v;
   }

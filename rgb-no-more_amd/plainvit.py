@@ -55,6 +55,26 @@ class PatchEmbedding_DCT_Group(nn.Module):
         self.conv_Y = dops.generate_conversion_matrix(8, patch_size // 8, scale=True, dtype=torch.float32)
 
 
+class PatchEmbedding_DCT_Separate_subblock(nn.Module):
+    """plainvit.py:280-352 (ver=2 / embed_type 2 with use_subblock; train.py's default): Y tile -> Linear(256, E/6*4),
+    Cb|Cr blocks -> Linear(128, E/6*2), GELU on the concatenation, residual Linear(E, E), sin-cos.  Parameter holder
+    only; compute is _PatchEmbed2Fn (the same C-ABI GEMM / sub-block kernels as ver=1)."""
+
+    def __init__(self, patch_size=16, emb_size=768, chroma_scale=2, device="cpu", dtype=torch.float32):
+        super().__init__()
+        assert not (patch_size & (patch_size - 1)) and patch_size >= 2, \
+            f"Patch size should be 2^n (n>0, n=int). Current value: {patch_size}"
+        if patch_size != 16 or chroma_scale != 2:
+            raise NotImplementedError("HIP path covers patch_size=16, 4:2:0 (JPEG-Ti/S configs)")
+        self.patch_size = patch_size
+        kw = dict(device=device, dtype=dtype)
+        # index 0 of each Sequential is the reference's parameter-free Rearrange
+        self.projection_Y = nn.Sequential(nn.Identity(), nn.Linear(256, emb_size // 6 * 4, **kw))
+        self.projection_C = nn.Sequential(nn.Identity(), nn.Linear(128, emb_size // 6 * 2, **kw))
+        self.linearMix = nn.Linear(emb_size, emb_size, **kw)
+        self.conv_Y = dops.generate_conversion_matrix(8, patch_size // 8, scale=True, dtype=torch.float32)
+
+
 def sincos_table(h, w, e, device="cpu"):
     """SinCosEmbedding (plainvit.py:90-121) as a constant (h*w, e) fp32 table."""
     hg, wg = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
@@ -79,6 +99,10 @@ class _Arena:
         f32 = torch.float32
         self.cfg = L.VitCfg(L.dt_of(T), B, N, E, model.num_heads, 1e-5, 1.0 / math.sqrt(E))
         self.feat = e(M, 384)
+        if model.ver == 2:
+            self.pe_g, self.pe_gp = e(M, E), e(M, E)
+            if need_grad:
+                self.pe_dh = e(M, E)
         nx = D + 1 if need_grad else 2
         self.x = [e(M, E) for _ in range(nx)]
         nb = D if need_grad else 1
@@ -148,6 +172,63 @@ class _PatchEmbedFn(torch.autograd.Function):
         L.check(L.lib().rgbnm_patch_embed_bwd(C.byref(a.cfg), dx0.data_ptr(), a.feat.data_ptr(), gw.data_ptr(),
                                               gb.data_ptr(), a.ws.data_ptr(), a.ws_bytes, L.stream()), "patch_embed_bwd")
         return None, None, None, gw, gb
+
+
+_PE2_NAMES = ["patchembed.projection_Y.1.weight", "patchembed.projection_Y.1.bias", "patchembed.projection_C.1.weight",
+              "patchembed.projection_C.1.bias", "patchembed.linearMix.weight", "patchembed.linearMix.bias"]
+
+
+class _PatchEmbed2Fn(torch.autograd.Function):
+    """ver=2 patch embedding (reference: PatchEmbedding_DCT_Separate_subblock.forward, plainvit.py:326-352) on the
+    C-ABI kernels:  feat = subblock(y, cbcr);  g = gelu([feat_Y Wy^T + by | feat_C Wc^T + bc])  (two GEMMs with the GELU
+    epilogue writing column slices of g and gelu');  x0 = g (Wm + I)^T + bm + sincos  (one GEMM, sin-cos epilogue; the
+    residual is folded into the operand shadow, rgbnm_linear_desc.add_identity)."""
+
+    @staticmethod
+    def forward(ctx, y, cbcr, st, wy, by, wc, bc, wm, bm):
+        m, a = st.model, st.arena
+        lib, dt, M, E = L.lib(), a.cfg.dtype, a.cfg.B * a.cfg.N, a.cfg.E
+        Ey = E // 6 * 4
+        Hb, Wb = y.shape[2], y.shape[3]
+        if (Hb // 2) * (Wb // 2) != a.cfg.N:
+            raise ValueError("expected a 28 x 28 block grid")
+        es = a.feat.element_size()
+        L.check(lib.rgbnm_subblock_embed(L.dt_of(y.dtype), dt, y.data_ptr(), cbcr.data_ptr(), m._conv16.data_ptr(),
+                                         a.feat.data_ptr(), a.cfg.B, Hb, Wb, 0, L.stream()), "subblock_embed")
+        g, gp = a.pe_g, a.pe_gp
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_GELU, a.feat.data_ptr(), 384, m._sh_ptr("peY", "ws"), 256, g.data_ptr(), E,
+                                  by.data_ptr(), None, 0, gp.data_ptr(), E, None, 0, M, Ey, 256, 0, L.stream()), "pe2 Y")
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_GELU, a.feat.data_ptr() + 256 * es, 384, m._sh_ptr("peC", "ws"), 128,
+                                  g.data_ptr() + Ey * es, E, bc.data_ptr(), None, 0, gp.data_ptr() + Ey * es, E, None,
+                                  0, M, E - Ey, 128, 0, L.stream()), "pe2 C")
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_POS, g.data_ptr(), E, m._sh_ptr("peM", "ws"), E, a.xbuf(0).data_ptr(), E,
+                                  bm.data_ptr(), None, 0, None, 0, m._pos.data_ptr(), a.cfg.N, M, E, E, 0, L.stream()),
+                "pe2 mix")
+        ctx.st = st
+        return a.xbuf(0).detach()
+
+    @staticmethod
+    def backward(ctx, dx0):
+        st = ctx.st
+        m, a = st.model, st.arena
+        lib, dt, M, E = L.lib(), a.cfg.dtype, a.cfg.B * a.cfg.N, a.cfg.E
+        Ey = E // 6 * 4
+        dx0 = dx0.contiguous()
+        es = a.feat.element_size()
+        gr = [m._gview(st.gbuf, n) for n in _PE2_NAMES]
+        ws, wsb = a.ws.data_ptr(), a.ws_bytes
+        # d linearMix (the identity part of the shadow has no gradient)
+        L.check(lib.rgbnm_gemm_tn(dt, dx0.data_ptr(), E, a.pe_g.data_ptr(), E, gr[4].data_ptr(), gr[5].data_ptr(), M, E,
+                                  E, 0, 0, ws, wsb, L.stream()), "pe2 dWm")
+        # dh = (dx0 (Wm + I)) * gelu'(h)
+        dh = a.pe_dh
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_DGELU, dx0.data_ptr(), E, m._sh_ptr("peM", "wst"), E, dh.data_ptr(), E,
+                                  None, a.pe_gp.data_ptr(), E, None, 0, None, 0, M, E, E, 0, L.stream()), "pe2 dh")
+        L.check(lib.rgbnm_gemm_tn(dt, dh.data_ptr(), E, a.feat.data_ptr(), 384, gr[0].data_ptr(), gr[1].data_ptr(), M, Ey,
+                                  256, 0, 0, ws, wsb, L.stream()), "pe2 dWy")
+        L.check(lib.rgbnm_gemm_tn(dt, dh.data_ptr() + Ey * es, E, a.feat.data_ptr() + 256 * es, 384, gr[2].data_ptr(),
+                                  gr[3].data_ptr(), M, E - Ey, 128, 0, 0, ws, wsb, L.stream()), "pe2 dWc")
+        return (None, None, None) + tuple(gr)
 
 
 class _BlockFn(torch.autograd.Function):
@@ -221,8 +302,9 @@ class ViT(FlatParamModule):
         super().__init__()
         if pixel_space.lower() not in ("dct", "rgb2dct"):
             raise NotImplementedError("rgb-no-more_amd implements the --domain DCT path only")
-        if ver != 1:
-            raise NotImplementedError("embed_type 1 (PatchEmbedding_DCT_Group) only; see SURVEY.md 8f f3")
+        if ver not in (1, 2) or (ver == 2 and not use_subblock):
+            raise NotImplementedError("embed_type 1 (PatchEmbedding_DCT_Group) and 2 with use_subblock "
+                                      "(PatchEmbedding_DCT_Separate_subblock); ver=3 has 294 tokens (SURVEY.md 8f f3)")
         if drop_p not in (0, 0.0):
             raise NotImplementedError("dropout p must be 0 (cfg.TRAIN.DROP default, configs.py:27)")
         if head_size != 64 or emb_size not in (192, 384) or input_embed >= 0:
@@ -235,7 +317,9 @@ class ViT(FlatParamModule):
         self.n_tokens = 196
         E = emb_size
         kw = dict(device=device, dtype=dtype)
-        self.patchembed = PatchEmbedding_DCT_Group(patch_size, E, use_subblock, **kw)
+        self.ver = ver
+        self.patchembed = (PatchEmbedding_DCT_Group(patch_size, E, use_subblock, **kw) if ver == 1 else
+                           PatchEmbedding_DCT_Separate_subblock(patch_size, E, **kw))
         blocks = []
         for _ in range(depth):
             att = ResidualAdd(nn.Sequential(OrderedDict([
@@ -270,7 +354,11 @@ class ViT(FlatParamModule):
         params = self._pack_parameters()
         offs = self._offs
         # ---- Linear descriptors + shadow layout
-        lin = [("pe", "patchembed.projection.0", 0)]
+        if self.ver == 1:
+            lin = [("pe", "patchembed.projection.0", 0)]
+        else:
+            lin = [("peY", "patchembed.projection_Y.1", 0), ("peC", "patchembed.projection_C.1", 0),
+                   ("peM", "patchembed.linearMix", 0)]
         for i in range(self.depth):
             lin += [(f"qkv{i}", f"encoder.{i}.0.fn.eb_mha.qkv", self.num_heads),
                     (f"proj{i}", f"encoder.{i}.0.fn.eb_mha.projection", 0),
@@ -285,7 +373,8 @@ class ViT(FlatParamModule):
             bp = bo
             if ph:
                 bo += _align(Nn)
-            descs[k] = L.LinearDesc(offs[name + ".weight"], offs[name + ".bias"], ws, wst, bp, Nn, Kk, ph, 0)
+            descs[k] = L.LinearDesc(offs[name + ".weight"], offs[name + ".bias"], ws, wst, bp, Nn, Kk, ph,
+                                    1 if key == "peM" else 0)
             self._sh_off[key] = (ws, wst, bp)
         self._ndesc, self._sh_total = len(lin), so
         self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
@@ -368,7 +457,7 @@ class ViT(FlatParamModule):
             raise TypeError("Y and CbCr must share a dtype")
         cdtype = self.compute_dtype
         if cdtype is None:
-            cdtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+            cdtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
         if cdtype not in (torch.float32, torch.bfloat16):
             raise NotImplementedError(f"compute dtype {cdtype}: the MI355X path implements fp32 and bf16")
         self._ensure_flat()
@@ -379,8 +468,11 @@ class ViT(FlatParamModule):
         st = _FwdState(self, arena, self._grad_buffer() if need_grad else None)
         st.ln_chain = bool(L.lib().rgbnm_vit_ln_chain(C.byref(arena.cfg)))
         named = self._named
-        h = _PatchEmbedFn.apply(x, cbcr, st, named["patchembed.projection.0.weight"],
-                                named["patchembed.projection.0.bias"])
+        if self.ver == 1:
+            h = _PatchEmbedFn.apply(x, cbcr, st, named["patchembed.projection.0.weight"],
+                                    named["patchembed.projection.0.bias"])
+        else:
+            h = _PatchEmbed2Fn.apply(x, cbcr, st, *[named[n] for n in _PE2_NAMES])
         for i in range(self.depth):
             h = _BlockFn.apply(h, st, i, *[named[n] for n in self._block_param_order[i]])
         return _HeadFn.apply(h, st, *[named[n] for n in self._head_param_order])

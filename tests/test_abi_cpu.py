@@ -42,6 +42,13 @@ def test_state_dict_surface_matches_reference(golden):
     # the weight-decay name filter of pipeline_utils.py:537 selects the Linear weights only
     sel = [n for n, _ in m.named_parameters() if (".weight" in n) and ("lrnorm" not in n)]
     assert len(sel) == 1 + 12 * 4 + 2
+    # ver=2 (embed_type 2): the reference's PatchEmbedding_DCT_Separate_subblock keys and shapes (golden g14)
+    g2 = golden("g14_model_v2.npz")
+    m2 = rg.ViT(3, 16, 192, depth=2, n_classes=1000, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=2)
+    assert list(m2.state_dict().keys()) == [str(s) for s in g2["ti_d2_v2_names"]]
+    assert [str(tuple(v.shape)) for v in m2.state_dict().values()] == [str(s) for s in g2["ti_d2_v2_shapes"]]
+    with pytest.raises(NotImplementedError):
+        rg.ViT(3, 16, 192, depth=1, drop_p=0.0, num_heads=3, pixel_space="DCT", ver=3)
 
 
 def test_no_cpu_fallback():

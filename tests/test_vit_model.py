@@ -205,3 +205,48 @@ def test_bf16_backward_with_and_without_fused_layernorm_backward():
         assert torch.isfinite(b).all()
         rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
         assert rel < 1e-4, (n, rel)
+
+
+@pytest.mark.parametrize("tag,emb,heads", [("ti_d2_v2", 192, 3), ("s_d2_v2", 384, 6)])
+def test_embed_type2_fp32_and_bf16_vs_reference_golden(golden, tag, emb, heads):
+    """ver=2 (embed_type 2, PatchEmbedding_DCT_Separate_subblock: train.py's default patch embedding).  fp32 logits
+    within the north-star 1e-3 of the reference (golden g14, generated from /root/reference), gradients of the three
+    patch-embedding Linears included; bf16 within the bf16 tolerance of test_bf16_logits_vs_reference_golden."""
+    g = golden("g14_model_v2.npz")
+    m = rg.ViT(3, 16, emb, depth=2, n_classes=1000, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
+               pixel_space="DCT", ver=2, use_subblock=True)
+    assert [str(s) for s in g[tag + "_names"]] == list(m.state_dict().keys())
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert [str(v) for v in shapes.values()] == [str(s) for s in g[tag + "_shapes"]]
+    sd = detfill.fill_state_dict(shapes, base_seed=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    B = 2
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 73, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    m.train()
+    m.compute_dtype = torch.float32
+    logits = m(y, c)
+    err = np.abs(logits.detach().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] fp32 max |dlogit| = {err:.3e}")
+    assert err <= 1e-3 and err <= 5e-5
+    loss = rg.cls_transforms.cross_entropy(logits, tgt)
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-5
+    loss.backward()
+    gn = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=1e-3, atol=1e-7)
+    named = dict(m.named_parameters())
+    for nm in ("patchembed.projection_Y.1.weight", "patchembed.projection_C.1.bias", "patchembed.linearMix.weight"):
+        got = named[nm].grad.reshape(-1)[::37].cpu().numpy()
+        np.testing.assert_allclose(got, g[tag + "_grad_" + nm], rtol=2e-3, atol=3e-7, err_msg=nm)
+    m.zero_grad(set_to_none=True)
+    m.compute_dtype = torch.bfloat16
+    lb = m(y, c)
+    errb = np.abs(lb.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] bf16 max |dlogit| = {errb:.3e}")
+    assert errb <= 2.5e-2
+    rg.cls_transforms.cross_entropy(lb, tgt, grad_dtype=torch.bfloat16).backward()
+    gnb = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    rel = np.abs(gnb - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    assert np.median(rel) < 2e-2 and rel.max() < 0.15
