@@ -90,7 +90,14 @@ def cpu_baseline(arch, n_images, batch=8):
     from rgb_no_more_amd import custom_transforms as CT
     emb, heads = ARCH[arch]
     depth = 12
-    torch.set_num_threads(min(32, os.cpu_count() or 1))   # batch-8 fp32 GEMMs stop scaling well before 128 threads
+    ncpu = os.cpu_count() or 1
+    try:                                   # honour a cgroup CPU quota (the GPU box: 16 of 256 hardware threads)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            ncpu = max(1, min(ncpu, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(min(32, ncpu))   # batch-8 fp32 GEMMs stop scaling well before 128 threads
     shapes = V.param_shapes(depth, emb, heads)
     p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in detfill.fill_state_dict(shapes, 1).items()}
     params = list(p.values())

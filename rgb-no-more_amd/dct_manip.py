@@ -92,17 +92,30 @@ def read_coefficients_bytes(data: bytes):
     return _read(data=bytes(data))
 
 
-def read_coefficients_batch(paths, threads=8, grid=(64, 64), pin_memory=False):
+def alloc_batch(n, grid=(64, 64), pin_memory=True):
+    """Reusable (pinned) staging buffers for read_coefficients_batch(out=...): allocating pinned memory per batch costs
+    more than decoding it."""
+    hb, wb = grid
+    hbc, wbc = (hb + 1) // 2, (wb + 1) // 2
+    kw = dict(dtype=torch.int16, pin_memory=pin_memory)
+    return (torch.empty((n, 1, hb, wb, 8, 8), **kw), torch.empty((n, 2, hbc, wbc, 8, 8), **kw),
+            torch.empty((n, 3, 8, 8), **kw))
+
+
+def read_coefficients_batch(paths, threads=8, grid=(64, 64), pin_memory=False, out=None):
     """Decode len(paths) JPEGs of one coefficient grid (default 512x512 4:2:0 -> 64x64 luma blocks) in parallel.
-    Returns Y (B,1,Hb,Wb,8,8), CbCr (B,2,Hb/2,Wb/2,8,8), quant (B,3,8,8) int16 CPU tensors (optionally pinned)."""
+    Returns Y (B,1,Hb,Wb,8,8), CbCr (B,2,Hb/2,Wb/2,8,8), quant (B,3,8,8) int16 CPU tensors (optionally pinned);
+    out = buffers from alloc_batch() to decode into (ring of staging buffers)."""
     L = lib()
     n = len(paths)
     hb, wb = grid
     hbc, wbc = (hb + 1) // 2, (wb + 1) // 2
-    kw = dict(dtype=torch.int16, pin_memory=pin_memory)
-    Y = torch.empty((n, 1, hb, wb, 8, 8), **kw)
-    CbCr = torch.empty((n, 2, hbc, wbc, 8, 8), **kw)
-    quant = torch.empty((n, 3, 8, 8), **kw)
+    if out is None:
+        out = alloc_batch(n, grid, pin_memory)
+    Y, CbCr, quant = out
+    if tuple(Y.shape) != (n, 1, hb, wb, 8, 8) or tuple(CbCr.shape) != (n, 2, hbc, wbc, 8, 8) or \
+            tuple(quant.shape) != (n, 3, 8, 8) or any(t.dtype != torch.int16 or not t.is_contiguous() for t in out):
+        raise ValueError("out buffers do not match the batch (use alloc_batch)")
     status = torch.zeros(n, dtype=torch.int32)
     arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
     bad = L.rgbnm_read_coefficients_batch(arr, n, int(threads), hb, wb, hbc, wbc, Y.data_ptr(), CbCr.data_ptr(),

@@ -1,0 +1,129 @@
+#!/usr/bin/env python
+"""JPEG-fed end-to-end figure (SURVEY 8d "report the JPEG-fed pipeline figure separately", 8f f2): real baseline
+JPEG files -> librgbnm_reader.so (pthread pool, libjpeg coefficient read, no IDCT) into pinned int16 batches -> one H2D
+copy -> HIP dequant/crop/resize/RandAugment/ToRange -> mixup -> HIP ViT train step.  The decoder thread runs ahead of
+the GPU by a two-deep queue.  Prints one JSON line; never part of bench.py's `value` (that one starts from HBM-resident
+coefficients).  S-jpeg set: 64 files, 512x512, 4:2:0, q90 (32x32 uniform RGB upsampled bicubic + N(0,8) noise)."""
+import argparse
+import json
+import os
+import queue
+import sys
+import tempfile
+import threading
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rgb_no_more_amd as rg  # noqa: E402
+from rgb_no_more_amd import custom_transforms as CT  # noqa: E402
+from rgb_no_more_amd import dct_manip as dm  # noqa: E402
+
+
+def write_sjpeg(d, n=64):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(n):
+        small = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+        img = np.asarray(Image.fromarray(small).resize((512, 512), Image.BICUBIC), dtype=np.float32)
+        img = np.clip(img + rng.normal(0, 8, img.shape), 0, 255).astype(np.uint8)
+        p = os.path.join(d, f"s{i:03d}.jpg")
+        Image.fromarray(img).save(p, quality=90, subsampling="4:2:0")
+        paths.append(p)
+    return paths
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--threads", type=int, default=os.cpu_count())
+    a = ap.parse_args()
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    tmp = tempfile.mkdtemp(prefix="sjpeg_")
+    paths = write_sjpeg(tmp)
+    fsize = sum(os.path.getsize(p) for p in paths) / len(paths)
+    B = a.batch
+    batch_paths = [paths[i % len(paths)] for i in range(B)]
+
+    # ---- host decode alone
+    ring = [dm.alloc_batch(B) for _ in range(4)]          # pinned staging buffers, re-used
+    for _ in range(2):
+        dm.read_coefficients_batch(batch_paths, threads=a.threads, out=ring[0])
+    t0 = time.perf_counter()
+    nrep = 8
+    for i in range(nrep):
+        dm.read_coefficients_batch(batch_paths, threads=a.threads, out=ring[i % 4])
+    dec = nrep * B / (time.perf_counter() - t0)
+
+    model = rg.ViT(3, 16, 192, depth=12, n_classes=1000, drop_p=0.0, device=dev, num_heads=3, head_size=64,
+                   pixel_space="DCT", ver=1, use_subblock=True)
+    model.compute_dtype = torch.bfloat16
+    opt = rg.custom_optims.FusedClipAdamWWD(model, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
+    mix = rg.cls_transforms.RandomMixup_DCT(1000, alpha=0.2)
+    mix.out_dtype = torch.bfloat16
+    aug = CT.TrainTransform_DCT(out_dtype=torch.bfloat16)
+    sampler = CT.FastParamSampler(aug, seed=1234)
+    lab = torch.randint(0, 999, (B,), device=dev)
+
+    q = queue.Queue(maxsize=2)
+    stop = threading.Event()
+
+    def producer():
+        k = 0
+        while not stop.is_set():
+            # 4 buffers: 2 queued + 1 being copied by the consumer + 1 being filled
+            item = dm.read_coefficients_batch(batch_paths, threads=a.threads, out=ring[k % 4])
+            k += 1
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    pass
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    copy_stream = torch.cuda.Stream()
+
+    def step():
+        Y, Cc, Q = q.get()
+        with torch.cuda.stream(copy_stream):
+            Yd, Cd, Qd = Y.to(dev, non_blocking=True), Cc.to(dev, non_blocking=True), Q.to(dev, non_blocking=True)
+        copy_stream.synchronize()                 # the pinned buffer goes back to the decoder ring
+        opt.zero_grad(set_to_none=True)
+        packed, nops = sampler.sample(B, 64, 64)
+        y, c = CT.apply_packed(aug, Yd, Cd, Qd, packed, nops)
+        (my, mc), mt = mix((y, c), lab)
+        loss = rg.cls_transforms.cross_entropy(model(my, mc), mt, grad_dtype=torch.bfloat16)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stop.set()
+    out = {"metric": "images/sec JPEG-Ti DCT train step fed from JPEG files (host entropy decode + H2D inside)",
+           "value": round(B * a.steps / dt, 1), "unit": "images/sec", "n_gpus": 1, "steps": a.steps,
+           "ms_per_step": round(1e3 * dt / a.steps, 3), "per_gpu_batch": B, "host_threads": a.threads,
+           "host_decode_only_images_per_sec": round(dec, 1), "avg_jpeg_bytes": round(fsize),
+           "h2d_bytes_per_image": 64 * 64 * 64 * 2 + 2 * 32 * 32 * 64 * 2 + 3 * 64 * 2,
+           "loss": round(float(loss.item()), 4),
+           "note": "one process; decoder thread (pthread pool inside librgbnm_reader.so, GIL released) runs two batches "
+                   "ahead; bounded by the host Huffman decode when value ~ host_decode_only"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
