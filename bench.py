@@ -49,7 +49,41 @@ def parse():
     ap.add_argument("--cpu-baseline-images", type=int, default=64)
     ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel HIP-event trace of the timed region")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B experiments)")
+    ap.add_argument("--grad-sync", default="flat", choices=["flat", "ddp"],
+                    help="N > 1: zero-copy slice-wise all-reduce of the flat gradient buffer (self-checked, falls back "
+                         "to ddp) or torch DistributedDataParallel")
     return ap.parse_args()
+
+
+def _flat_sync_selfcheck(model, fsync, cdt, dev, B, dist):
+    """One backward with the overlapped slice-wise exchange vs the same backward followed by ONE blocking all-reduce of
+    the whole flat gradient buffer: must agree on every rank (summation order inside RCCL may differ: tolerance)."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + dist.get_rank())
+    y = torch.randn(B, 1, 28, 28, 8, 8, device=dev, generator=g)
+    c = torch.randn(B, 2, 14, 14, 8, 8, device=dev, generator=g)
+
+    def backward():
+        model.zero_grad(set_to_none=True)
+        model(y, c).float().square().mean().backward()
+
+    backward()
+    fsync.wait()
+    base = model.flat_grad_base()
+    if base is None:
+        return False
+    g1 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model._grad_sync = None
+    backward()
+    g2 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    dist.all_reduce(g2, op=dist.ReduceOp.SUM)
+    g2 /= dist.get_world_size()
+    model._grad_sync = fsync
+    model.zero_grad(set_to_none=True)
+    err = (g1 - g2).abs().max().item()
+    ref = g2.abs().max().item()
+    return bool(torch.isfinite(g1).all()) and err <= 1e-4 * ref + 1e-8 and fsync.collectives >= 2
 
 
 def synth_coefficients(B, dev, seed):
@@ -168,11 +202,14 @@ def main():
     if world == 1 and a.gpus > 1:
         raise SystemExit("for --gpus N>1 launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 bench.py --gpus N ...")
+    if os.environ.get("RGBNM_BENCH_SAME_DEVICE") == "1":   # smoke test of the N > 1 code path on a 1-GPU box (gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+        # "nccl" IS RCCL on ROCm; RGBNM_BENCH_BACKEND=gloo only for the 1-GPU smoke test above
+        dist.init_process_group(os.environ.get("RGBNM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     lib = L.lib()
     for o in a.opt:
@@ -185,10 +222,28 @@ def main():
                    pixel_space="DCT", ver=1, use_subblock=True)
     model.compute_dtype = cdt
     net = model
+    grad_sync = "none"
     if world > 1:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        # several ~4 MB buckets so the all-reduce of late layers overlaps the backward of early ones
-        net = DDP(model, device_ids=[local], output_device=local, bucket_cap_mb=4, gradient_as_bucket_view=False)
+        grad_sync = a.grad_sync
+        if grad_sync == "flat":
+            # zero-copy exchange: ~4 MB slices of the flat gradient buffer are all-reduced (RCCL, AVG) from inside the
+            # backward as soon as a block's gradients are final (rgb_no_more_amd/parallel.py); verified below against
+            # one blocking all-reduce, with torch DDP as the fallback
+            try:
+                fsync = rg.parallel.FlatGradSync(model, bucket_bytes=4 << 20)
+                ok = _flat_sync_selfcheck(model, fsync, cdt, dev, a.batch, dist)
+            except Exception as e:          # noqa: BLE001
+                print(f"[rank {rank}] FlatGradSync unavailable ({type(e).__name__}: {e}); using torch DDP", file=sys.stderr)
+                ok = False
+            flag = torch.tensor([1 if ok else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() == 0:
+                model._grad_sync = None
+                grad_sync = "ddp"
+        if grad_sync == "ddp":
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            # several ~4 MB buckets so the all-reduce of late layers overlaps the backward of early ones
+            net = DDP(model, device_ids=[local], output_device=local, bucket_cap_mb=4, gradient_as_bucket_view=False)
     opt = rg.custom_optims.FusedClipAdamWWD(model, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
     mix = rg.cls_transforms.RandomMixup_DCT(1000, alpha=0.2)
     mix.out_dtype = cdt
@@ -289,7 +344,7 @@ def main():
                                    ("Ti" if a.arch == "vitti" else "S", a.dtype, B,
                                     "model-only on S-randn inputs" if a.no_augment else
                                     "HIP DCT-augment of S-coef 512x512 coefficient batches resident in HBM"),
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "grad_sync": grad_sync,
                        "loss": round(float(loss.item()), 5)},
             "mfma_pct_whole_step": round(100 * step_tflops / peak, 2),
             "step_tflops_per_gpu": round(step_tflops, 1),

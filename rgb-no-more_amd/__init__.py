@@ -10,3 +10,4 @@ from . import lib, dct_ops, plainvit, cls_transforms, custom_optims  # noqa: F40
 from .plainvit import ViT  # noqa: F401,E402
 from . import custom_transforms  # noqa: F401,E402
 from . import dct_manip  # noqa: F401,E402
+from . import parallel  # noqa: F401,E402

@@ -74,6 +74,8 @@ class FusedClipAdamWWD(Optimizer):
         g = self.param_groups[0]
         m = self._m
         self._step += 1
+        if m._grad_sync is not None:       # overlapped flat all-reduce (parallel.FlatGradSync): gradients are final after this
+            m._grad_sync.wait()
         gptr = self._flat_grads()
         L.check(L.lib().rgbnm_clip_adamw_wd_step(
             m._flat.data_ptr(), gptr, self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr(),

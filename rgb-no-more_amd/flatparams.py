@@ -21,6 +21,7 @@ class FlatParamModule(nn.Module):
     """Mixin: call `_pack_parameters()` once parameters sit on their final device."""
 
     _flat = None
+    _grad_sync = None      # parallel.FlatGradSync: overlapped all-reduce of the flat gradient buffer
 
     def _pack_parameters(self):
         params = list(self.named_parameters())

@@ -171,6 +171,8 @@ class _PatchEmbedFn(torch.autograd.Function):
         gw, gb = m._gview(st.gbuf, "patchembed.projection.0.weight"), m._gview(st.gbuf, "patchembed.projection.0.bias")
         L.check(L.lib().rgbnm_patch_embed_bwd(C.byref(a.cfg), dx0.data_ptr(), a.feat.data_ptr(), gw.data_ptr(),
                                               gb.data_ptr(), a.ws.data_ptr(), a.ws_bytes, L.stream()), "patch_embed_bwd")
+        if m._grad_sync is not None:            # last gradients of the step: flush the exchange (parallel.py)
+            m._grad_sync.ready(st.gbuf, ["patchembed.projection.0.weight", "patchembed.projection.0.bias"], last=True)
         return None, None, None, gw, gb
 
 
@@ -228,6 +230,8 @@ class _PatchEmbed2Fn(torch.autograd.Function):
                                   256, 0, 0, ws, wsb, L.stream()), "pe2 dWy")
         L.check(lib.rgbnm_gemm_tn(dt, dh.data_ptr() + Ey * es, E, a.feat.data_ptr() + 256 * es, 384, gr[2].data_ptr(),
                                   gr[3].data_ptr(), M, E - Ey, 128, 0, 0, ws, wsb, L.stream()), "pe2 dWc")
+        if m._grad_sync is not None:
+            m._grad_sync.ready(st.gbuf, _PE2_NAMES, last=True)
         return (None, None, None) + tuple(gr)
 
 
@@ -260,6 +264,8 @@ class _BlockFn(torch.autograd.Function):
         L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
                                             C.byref(g), C.byref(a.scratch), dy.data_ptr(), dx.data_ptr(),
                                             L.stream()), "vit_block_bwd")
+        if m._grad_sync is not None:            # this block's gradients are final: start their all-reduce now
+            m._grad_sync.ready(st.gbuf, m._block_names[idx])
         # grads come back in BlockGrads field order; reorder to the order the params were passed in
         by_name = dict(zip(m._block_names[idx], grads))
         return (dx, None, None) + tuple(by_name[n] for n in m._block_param_order[idx])
@@ -288,6 +294,8 @@ class _HeadFn(torch.autograd.Function):
         L.check(L.lib().rgbnm_head_bwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(ctx.acts), C.byref(g),
                                        dl.data_ptr(), a.da.data_ptr(), a.dpooled.data_ptr(), dx.data_ptr(),
                                        a.ws.data_ptr(), a.ws_bytes, L.stream()), "head_bwd")
+        if m._grad_sync is not None:
+            m._grad_sync.ready(st.gbuf, names)
         by_name = dict(zip(names, grads))
         return (dx, None) + tuple(by_name[n] for n in m._head_param_order)
 

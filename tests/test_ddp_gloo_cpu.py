@@ -38,6 +38,9 @@ class _Fn(torch.autograd.Function):
         gb.copy_(dz.sum(0))
         gg.copy_((dy * z).sum(0))
         gs.copy_(dy.sum(0))
+        if m._grad_sync is not None:     # same hook as the HIP autograd nodes (plainvit.py)
+            m._grad_sync.ready(gbuf, ["x_lrnorm.weight", "x_lrnorm.bias"])
+            m._grad_sync.ready(gbuf, ["lin.weight", "lin.bias"], last=True)
         return dz @ w, None, None, gw, gb, gg, gs
 
 
@@ -96,6 +99,25 @@ def _worker(rank, world, port, out):
     ddp(x).square().mean().backward()
     g2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
     assert torch.allclose(g2, 2 * g, atol=1e-5)
+    # ---- the zero-copy exchange used by bench.py at N > 1: parallel.FlatGradSync all-reduces slices of the flat
+    # gradient buffer in place, launched from the autograd node (here: the toy node, like plainvit's nodes)
+    from rgb_no_more_amd.parallel import FlatGradSync
+    m3 = Toy()
+    m3.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        if rank == 1:                                    # diverge rank 1 on purpose: the ctor must broadcast rank 0
+            for p in m3.parameters():
+                p.add_(1.0)
+    sync = FlatGradSync(m3, bucket_bytes=16)             # tiny buckets: several collectives per backward
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in m3.parameters()]),
+                       torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
+    m3(x).square().mean().backward()
+    sync.wait()
+    assert sync.collectives >= 2
+    g3 = torch.cat([p.grad.reshape(-1) for p in m3.parameters()])
+    assert torch.allclose(g3, g, atol=1e-6)              # same averaged gradient as torch DDP
+    assert m3.flat_grad_base() == m3._gflat.data_ptr()   # still one flat buffer: optimizer zero-copy path
+    sync.detach()
     # bench.py's timing reduction: MAX over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
