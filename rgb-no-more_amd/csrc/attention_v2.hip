@@ -450,10 +450,24 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
 // vmcnt retires in order, so every wait is "everything except the youngest DMA group".  The exponent is one FMA +
 // exp2 (log2 e folded into scale and lse), `scale` multiplies dQ/dK once at the end, lse/D rows are read as float4,
 // and the key/query mask is applied on the ragged last tile only.
+template <int NTOK, int T> __device__ __forceinline__ bool tile_on(int N) {
+  if constexpr (NTOK > 0) return T * 32 < NTOK;
+  else return T * 32 < N;
+}
+template <int NTOK, int T> __device__ __forceinline__ bool tile_ragged(int N) {
+  if constexpr (NTOK > 0) return T * 32 + 32 > NTOK;
+  else return T * 32 + 32 > N;
+}
+
+// NTOK > 0: the token count is a compile-time constant (196 for JPEG-Ti/S): every tile test folds away and only the
+// ragged last tile carries a mask.  (With a runtime N the compiler kept 14 tile predicates and 100+ lane masks alive in
+// SGPRs and spilled them through v_writelane / v_readlane: 650 of the kernel's 2900 VALU instructions.)
+template <int NTOK>
 __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                              const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, bf16* __restrict__ dqkv,
-                                                             int N, int heads, int nbh, float scale) {
+                                                             int N_rt, int heads, int nbh, float scale) {
+  const int N = NTOK > 0 ? NTOK : N_rt;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qs = smem;
   unsigned char* Ks = smem + ARR;
@@ -469,7 +483,6 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
   const bool active = w * 32 < N;
   const float LOG2E = 1.4426950408889634f;
   const float c2 = scale * LOG2E;
-  const bool ragged = (N & 31) != 0;
 
   auto issue_kv = [&](int bh) {
     const bf16* Q = qkv + (size_t)(bh / heads) * N * ld + (bh % heads) * HD;
@@ -499,6 +512,12 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
 
   int bh = blockIdx.x;
   if (bh >= nbh) return;
+#ifdef ATTN_PROF
+  int pit = 0;
+#define APROF3(i) do { if (L.lane == 0 && pit == 1) g_attn_prof[(blockIdx.x * 8 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define APROF3(i) do {} while (0)
+#endif
   issue_kv(bh);
   issue_qg(bh);
   load_own(bh);
@@ -510,7 +529,9 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     first = false;
+    APROF3(0);
     __builtin_amdgcn_s_barrier();
+    APROF3(1);
 
     // ================= phase A: wave = 32 queries -> dQ, D =================
     Frag<bf16> kf[4], vf[4];
@@ -534,7 +555,7 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
       const unsigned kt = (unsigned)(size_t)Ks + L.tr0;
       TileLoop<NTILE>::run([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        if (t * 32 < N) {
+        if (tile_on<NTOK, t>(N)) {
           f32x16 sa, da;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
@@ -549,7 +570,7 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
             const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lq2));
             ds[r] = pr * (da[r] - Dq);
           }
-          if (ragged && t * 32 + 32 > N) {
+          if (tile_ragged<NTOK, t>(N)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               if (t * 32 + acc_row(r, L.lane) >= N) ds[r] = 0.f;
@@ -580,10 +601,12 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
         vf[c] = rowfrag(Vs, w, L.l31, c, L.g, L.fl);
       }
     }
+    APROF3(2);
     // Q,dO of this pair have landed once only this wave's 8 dQ stores (younger) are outstanding
     if (active) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // D_s / L2_s complete; every wave is done with K,V
+    APROF3(3);
     if (nxt < nbh) issue_kv(nxt);
 
     // ================= phase B: wave = 32 keys -> dK, dV =================
@@ -596,7 +619,7 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
       const unsigned qt_ = (unsigned)(size_t)Qs + L.tr0, gt_ = (unsigned)(size_t)Gs + L.tr0;
       TileLoop<NTILE>::run([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        if (t * 32 < N) {
+        if (tile_on<NTOK, t>(N)) {
           f32x16 sa, da;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
@@ -618,7 +641,7 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
               ds[r] = pr * (da[r] - d4[e]);
             }
           }
-          if (ragged && t * 32 + 32 > N) {
+          if (tile_ragged<NTOK, t>(N)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               if (t * 32 + acc_row(r, L.lane) >= N) { pp[r] = 0.f; ds[r] = 0.f; }
@@ -654,12 +677,17 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
           }
       }
     }
+    APROF3(4);
     if (nxt < nbh) {
       load_own(nxt);                         // (issuing these during phase B would spill: 256-register budget)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // every wave is done with Q,dO, D_s, L2_s
       issue_qg(nxt);
     }
+    APROF3(5);
+#ifdef ATTN_PROF
+    ++pit;
+#endif
   }
 }
 
@@ -699,13 +727,18 @@ int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, c
   if (rgbnm_get_option("attn_persist")) {
     static bool attr3 = false;
     if (!attr3) {
-      if (hipFuncSetAttribute((const void*)attn3_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)attn3_bwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess ||
+          hipFuncSetAttribute((const void*)attn3_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess)
         return RGBNM_ELAUNCH;
       attr3 = true;
     }
     const int nbh = B * heads;
-    hipLaunchKernelGGL(attn3_bwd_kernel, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv,
-                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, heads, nbh, scale);
+    if (N == 196)
+      hipLaunchKernelGGL(attn3_bwd_kernel<196>, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv,
+                         (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, heads, nbh, scale);
+    else
+      hipLaunchKernelGGL(attn3_bwd_kernel<0>, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv,
+                         (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, heads, nbh, scale);
   } else {
     hipLaunchKernelGGL(attn2_bwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out,
                        (const bf16*)dout, lse, (bf16*)dqkv, N, heads, scale);

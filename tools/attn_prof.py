@@ -23,7 +23,8 @@ buf = np.zeros(768 * 8 * 8, dtype=np.uint64)
 f = L.lib().rgbnm_debug_attn_prof; f.restype = C.c_int; f.argtypes = [C.c_void_p]
 assert f(buf.ctypes.data) == 0
 p = buf.reshape(768, 8, 8).astype(np.int64)[:, :7, :7]
-names = ["start", "loaded+barrier", "phaseA_math", "phaseA_stores_issued", "barrier2", "phaseB_math", "end(drained)"]
-for i in range(1, 7):
+names = ["top_wait_done", "barrier1", "phaseA(+own kf/vf)", "mid wait+barrier", "phaseB(+stores)", "own loads+end barrier+issue"]
+print("persistent kernel: second (image, head) pair of every workgroup")
+for i in range(1, 6):
     d = p[:, :, i] - p[:, :, i - 1]
     print(f"{names[i]:22s} delta mean={d.mean():8.0f} min={d.min():8.0f} max={d.max():8.0f}   since start mean={(p[:, :, i] - p[:, :, 0]).mean():9.0f}")
