@@ -267,6 +267,39 @@ int rgbnm_head_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_head_params* p, const r
                    const rgbnm_head_grads* g, const void* dlogits, void* da, void* dpooled, void* dx, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SwinV2 DCT (models/swinv2.py; BASELINE config 5) - the parts that are not plain Linears (those use rgbnm_gemm_nt/tn).
+ * ------------------------------------------------------------------------------------------- */
+/* PatchEmbedding_DCT_Group with patch 4 (swinv2.py:505-576, plainvit.py:50-88): every 8x8 block is decomposed,
+ * X' = A^T X A with convY = conversion_matrix(4,2) / convC = conversion_matrix(2,4) (8x8 fp32 each), tokens on the
+ * 2Hb x 2Wb grid, feat [B, 2Hb*2Wb, 24] = Y 4x4 | Cb 2x2 | Cr 2x2 (einops split '(p1 pdh)(p2 pdw)', coefficient-major). */
+int rgbnm_swin_embed(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* convY, const float* convC,
+                     void* feat, int B, int Hb, int Wb, void* stream);
+/* LayerNorm of any width E % 4 == 0, E <= 768:  y = [res +] [sample_scale[row / rows_per_sample] *] LN(x)
+ * (res-post-norm + DropPath scale, swinv2.py:302-307).  Backward: dx = LN'(scale * dy), dgamma / dbeta fp32. */
+int rgbnm_ln_generic_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* res,
+                         const float* sample_scale, int rows_per_sample, void* y, float* mean, float* rstd, int M, int E,
+                         float eps, void* stream);
+size_t rgbnm_ln_generic_bwd_workspace(int M, int E);
+int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                         const float* rstd, const float* sample_scale, int rows_per_sample, void* dx, float* dgamma,
+                         float* dbeta, int M, int E, int accumulate, void* workspace, size_t workspace_bytes,
+                         void* stream);
+/* WindowAttention + cyclic shift + window partition / reverse (swinv2.py:143-182, 273-300) on token-major tensors:
+ * qkv [B, res*res, 3C] (q | k | v, heads of 32), bias [heads, 64, 64] fp32 (= 16 sigmoid(cpb_mlp(table))[index]),
+ * scale [heads] fp32 (= exp(min(logit_scale, ln 100))), shift in {0, 4}: window 8x8, cosine attention, shift mask -100.
+ * out [B, res*res, C]; lse [B * nW * heads * 64] saved for backward.  Backward ACCUMULATES into dbias (zero it first)
+ * and writes one partial d(scale) per (window, head) into dscale_part [B * nW * heads]. */
+int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, float* lse,
+                               int B, int res, int C, int heads, int shift, void* stream);
+int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
+                               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, int B,
+                               int res, int C, int heads, int shift, void* stream);
+/* PatchMerging's concat (swinv2.py:357-362): [B, res*res, C] -> [B, (res/2)^2, 4C] (inverse != 0: the reverse copy). */
+int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int C, int inverse, void* stream);
+/* mean over tokens [B,N,C] -> [B,C] (backward != 0: [B,C] -> [B,N,C], dy / N). */
+int rgbnm_token_mean(int dtype, const void* in, void* out, int B, int N, int C, int backward, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,3 +11,5 @@ from .plainvit import ViT  # noqa: F401,E402
 from . import custom_transforms  # noqa: F401,E402
 from . import dct_manip  # noqa: F401,E402
 from . import parallel  # noqa: F401,E402
+from . import swinv2  # noqa: F401,E402
+from .swinv2 import SwinTransformerV2  # noqa: F401,E402

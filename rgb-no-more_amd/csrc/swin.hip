@@ -1,0 +1,611 @@
+// SwinV2 DCT specifics (BASELINE config 5; reference models/swinv2.py): everything of the model
+// that is not a plain Linear - the Linears run on the GEMM family of gemm.hip.
+//   swin_embed      8x8 DCT blocks DEcomposed into 4x4 (Y) / 2x2 (CbCr) sub-block tokens: X' = A^T X A per block,
+//                   einops split '(p1 pdh) (p2 pdw)' (coefficient-major!), 16 + 2*4 = 24 features per token
+//                   (swinv2.py:556-576, plainvit.py:50-88)
+//   ln_generic      LayerNorm for any width (96 / 192 / 384 / 768 here), optional residual and per-sample scale:
+//                   y = res + s_b * LN(x)  (res-post-norm + DropPath, swinv2.py:302-307), backward with partial
+//                   gamma / beta sums for the batched reduction (reduce.hip)
+//   window_attention  8x8-window cosine attention with continuous position bias, per-head logit scale and the shift
+//                   mask (swinv2.py:143-182, 247-268).  Cyclic shift, window partition and their inverses are pure
+//                   index arithmetic and happen in the kernel's gather / scatter: no rolled or partitioned copy of the
+//                   activations exists.  One wave per (window, head), lane = query row (forward, dQ pass) or key row
+//                   (dK / dV pass); head_dim 32.  First, correctness-oriented generation: fp32 VALU math, no MFMA.
+//   merge_gather    PatchMerging's 2x2 neighbourhood concat as one gather (scatter in backward) (swinv2.py:357-362)
+//   token_mean      AdaptiveAvgPool1d(1) over tokens (swinv2.py:703-705)
+#include "common.h"
+#include "../../include/rgbnm.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int WS = 8, WT = 64, HD = 32;       // window side, tokens per window, head dim
+constexpr int WIN_TILE = WT * (HD + 1) * 4;                       // one padded fp32 [64][33] tile
+constexpr int WIN_SMEM_FWD = 4 * 2 * WIN_TILE + 4 * WT * 4;        // K, V per wave + mask ids
+constexpr int WIN_SMEM_BWD = 4 * 4 * WIN_TILE + 3 * 4 * WT * 4;    // Q, K, V, dO per wave + lse, D, mask ids
+
+// ------------------------------------------------------------------------------------------------ embed
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void swin_embed_kernel(const TI* __restrict__ y, const TI* __restrict__ cbcr,
+                                                         const float* __restrict__ Ay, const float* __restrict__ Ac,
+                                                         TO* __restrict__ feat, int B, int H, int W) {
+  __shared__ float Xs[4][64], Ts[4][64], As[2][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < 64) As[0][threadIdx.x] = Ay[threadIdx.x];
+  else if (threadIdx.x < 128) As[1][threadIdx.x - 64] = Ac[threadIdx.x - 64];
+  const int Hc = H / 2, Wc = W / 2;
+  const long long nY = (long long)B * H * W, nC = (long long)B * 2 * Hc * Wc;
+  const long long blk = (long long)blockIdx.x * 4 + w;
+  const bool valid = blk < nY + nC;
+  const bool luma = blk < nY;
+  const int r = lane >> 3, c = lane & 7;
+  if (valid) Xs[w][lane] = to_f32(luma ? y[blk * 64 + lane] : cbcr[(blk - nY) * 64 + lane]);
+  __syncthreads();
+  if (!valid) return;
+  const float* A = As[luma ? 0 : 1];
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t += A[k * 8 + r] * Xs[w][k * 8 + c];       // (A^T X)[r][c]
+  Ts[w][lane] = t;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v += Ts[w][r * 8 + k] * A[k * 8 + c];       // (A^T X A)[r][c]
+  const int TW = 2 * W;                                                    // token grid is 2H x 2W
+  if (luma) {
+    const int b = (int)(blk / (H * W)), hw = (int)(blk % (H * W)), h = hw / W, ww = hw % W;
+    const int p1 = r >> 1, pdh = r & 1, p2 = c >> 1, pdw = c & 1;
+    const long long tok = ((long long)b * 2 * H + 2 * h + pdh) * TW + 2 * ww + pdw;
+    feat[tok * 24 + p1 * 4 + p2] = from_f32<TO>(v);
+  } else {
+    const long long cb = blk - nY;
+    const int b = (int)(cb / (2 * Hc * Wc)), rem = (int)(cb % (2 * Hc * Wc));
+    const int ch = rem / (Hc * Wc), hw = rem % (Hc * Wc), h = hw / Wc, ww = hw % Wc;
+    const int p1 = r >> 2, pdh = r & 3, p2 = c >> 2, pdw = c & 3;
+    const long long tok = ((long long)b * 2 * H + 4 * h + pdh) * TW + 4 * ww + pdw;
+    feat[tok * 24 + 16 + ch * 4 + p1 * 2 + p2] = from_f32<TO>(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm, any E
+constexpr int LN_MAXV = 3;      // E <= 768: up to 3 float4 per lane
+template <typename T>
+__global__ __launch_bounds__(256) void ln_generic_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const T* __restrict__ res,
+                                                             const float* __restrict__ sscale, int rows_per_sample,
+                                                             T* __restrict__ y, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int M, int E, float eps) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nv = E / 4;
+  for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
+    f32x4 xv[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nv) {
+        xv[i] = load4<T>(x + (size_t)row * E + v * 4);
+        s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
+      }
+    }
+    const float mu = wave_sum(s) / E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + 64 * i < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xv[i][e] - mu;
+          q += d * d;
+        }
+      }
+    const float rs = rsqrtf(wave_sum(q) / E + eps);
+    const float sc = sscale ? sscale[row / rows_per_sample] : 1.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nv) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + v * 4), bt = *reinterpret_cast<const f32x4*>(beta + v * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ((xv[i][e] - mu) * rs * g[e] + bt[e]) * sc;
+        if (res) {
+          const f32x4 rv = load4<T>(res + (size_t)row * E + v * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rv[e];
+        }
+        store4<T>(y + (size_t)row * E + v * 4, o);
+      }
+    }
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+// dx = LN'(s_b * dy);  partial dgamma / dbeta per workgroup: part[blk][2][E]
+template <typename T>
+__global__ __launch_bounds__(256) void ln_generic_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ sscale, int rows_per_sample,
+                                                             T* __restrict__ dx, float* __restrict__ part, int M, int E) {
+  __shared__ float red[4][2 * 768];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nv = E / 4;
+  f32x4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (lane + 64 * i < nv) gm[i] = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+  }
+  for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float sc = sscale ? sscale[row / rows_per_sample] : 1.f;
+    f32x4 xh[LN_MAXV], gv[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nv) {
+        const f32x4 xv = load4<T>(x + (size_t)row * E + v * 4);
+        const f32x4 dv = load4<T>(dy + (size_t)row * E + v * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = dv[e] * sc;
+          xh[i][e] = (xv[e] - mu) * rs;
+          gv[i][e] = d * gm[i][e];
+          s1 += gv[i][e];
+          s2 += gv[i][e] * xh[i][e];
+          dg[i][e] += d * xh[i][e];
+          db[i][e] += d;
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / E, c2 = wave_sum(s2) / E;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nv) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gv[i][e] - c1 - xh[i][e] * c2);
+        store4<T>(dx + (size_t)row * E + v * 4, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[w][v * 4 + e] = dg[i][e];
+        red[w][E + v * 4 + e] = db[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * E; e += 256)
+    part[(size_t)blockIdx.x * 2 * E + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// ------------------------------------------------------------------------------------------------ window attention
+struct WinGeo {
+  int b, wy, wx, h;
+};
+__device__ __forceinline__ int region(int s, int res, int shift) { return s < res - WS ? 0 : (s < res - shift ? 1 : 2); }
+// token index (in the un-shifted image) and mask id of local position i of window (wy, wx)
+__device__ __forceinline__ int win_token(int i, int wy, int wx, int res, int shift, int& mid) {
+  const int sy = wy * WS + (i >> 3), sx = wx * WS + (i & 7);            // coordinates in the shifted frame
+  mid = shift ? 3 * region(sy, res, shift) + region(sx, res, shift) : 0;
+  int yy = sy + shift, xx = sx + shift;                                  // shifted[y] = x[(y + shift) % res]
+  yy = yy >= res ? yy - res : yy;
+  xx = xx >= res ? xx - res : xx;
+  return yy * res + xx;
+}
+
+// logits row of query i against all 64 keys: cos * scale + bias + mask, softmax statistics on the fly
+template <typename T>
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
+                                                           const float* __restrict__ scale, T* __restrict__ out,
+                                                           float* __restrict__ lse, int B, int res, int C, int heads,
+                                                           int shift) {
+  extern __shared__ float win_smem[];
+  typedef float Tile[WT][HD + 1];
+  Tile* Ks = reinterpret_cast<Tile*>(win_smem);
+  Tile* Vs = Ks + 4;
+  int (*Mid)[WT] = reinterpret_cast<int (*)[WT]>(Vs + 4);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = res / WS;
+  const long long unit = (long long)blockIdx.x * 4 + w, total = (long long)B * nw * nw * heads;
+  if (unit >= total) return;
+  const int h = (int)(unit % heads);
+  const long long win = unit / heads;
+  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+  int mid;
+  const int tok = win_token(lane, wy, wx, res, shift, mid);
+  const T* row = qkv + ((size_t)b * res * res + tok) * 3 * C + h * HD;
+  float q[HD];
+  float nq = 0.f, nk = 0.f;
+  float kk[HD];
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      q[d + e] = a[e];
+      kk[d + e] = k4[e];
+      nq += a[e] * a[e];
+      nk += k4[e] * k4[e];
+      Vs[w][lane][d + e] = v4[e];
+    }
+  }
+  const float iq = 1.f / fmaxf(sqrtf(nq), 1e-12f), ik = 1.f / fmaxf(sqrtf(nk), 1e-12f);   // F.normalize eps
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] *= iq;
+    Ks[w][lane][d] = kk[d] * ik;
+  }
+  Mid[w][lane] = mid;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float sc = scale[h];
+  const float* brow = bias + ((size_t)h * WT + lane) * WT;
+  float s[WT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < WT; ++j) {
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dot += q[d] * Ks[w][j][d];
+    float v = dot * sc + brow[j];
+    if (shift && Mid[w][j] != mid) v += -100.f;
+    s[j] = v;
+    m = fmaxf(m, v);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < WT; ++j) {
+    s[j] = __expf(s[j] - m);
+    sum += s[j];
+  }
+  const float inv = 1.f / sum;
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < WT; ++j) {
+    const float pj = s[j] * inv;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] += pj * Vs[w][j][d];
+  }
+  T* orow = out + ((size_t)b * res * res + tok) * C + h * HD;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) store4<T>(orow + d, (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]});
+  lse[unit * WT + lane] = m + __logf(sum);
+}
+
+// backward: pass Q (lane = query) -> dq, dscale partial, dbias (atomics);  pass K (lane = key) -> dk, dv
+template <typename T>
+__global__ __launch_bounds__(256) void win_attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                           const T* __restrict__ dout, const float* __restrict__ bias,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ lse, T* __restrict__ dqkv,
+                                                           float* __restrict__ dbias, float* __restrict__ dscale_part,
+                                                           int B, int res, int C, int heads, int shift) {
+  extern __shared__ float win_smem[];
+  typedef float Tile[WT][HD + 1];
+  Tile* Qs = reinterpret_cast<Tile*>(win_smem);
+  Tile* Ks = Qs + 4;
+  Tile* Vs = Ks + 4;
+  Tile* Gs = Vs + 4;
+  float (*Ls)[WT] = reinterpret_cast<float (*)[WT]>(Gs + 4);
+  float (*Ds)[WT] = Ls + 4;
+  int (*Mid)[WT] = reinterpret_cast<int (*)[WT]>(Ds + 4);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = res / WS;
+  const long long unit = (long long)blockIdx.x * 4 + w, total = (long long)B * nw * nw * heads;
+  if (unit >= total) return;
+  const int h = (int)(unit % heads);
+  const long long win = unit / heads;
+  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+  int mid;
+  const int tok = win_token(lane, wy, wx, res, shift, mid);
+  const size_t trow = (size_t)b * res * res + tok;
+  const T* row = qkv + trow * 3 * C + h * HD;
+  float q[HD], k[HD], v[HD], g[HD];
+  float nq = 0.f, nk = 0.f, Dq = 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
+    const f32x4 g4 = load4<T>(dout + trow * C + h * HD + d), o4 = load4<T>(out + trow * C + h * HD + d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      q[d + e] = a[e]; k[d + e] = k4[e]; v[d + e] = v4[e]; g[d + e] = g4[e];
+      nq += a[e] * a[e];
+      nk += k4[e] * k4[e];
+      Dq += g4[e] * o4[e];                      // D_i = sum_j p_ij dP_ij = dO_i . O_i
+    }
+  }
+  const float rq = fmaxf(sqrtf(nq), 1e-12f), rk = fmaxf(sqrtf(nk), 1e-12f);
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] /= rq;
+    k[d] /= rk;
+    Qs[w][lane][d] = q[d];
+    Ks[w][lane][d] = k[d];
+    Vs[w][lane][d] = v[d];
+    Gs[w][lane][d] = g[d];
+  }
+  const float li = lse[unit * WT + lane];
+  Ls[w][lane] = li;
+  Ds[w][lane] = Dq;
+  Mid[w][lane] = mid;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float sc = scale[h];
+  // ---- pass Q: lane = query i
+  {
+    const float* brow = bias + ((size_t)h * WT + lane) * WT;
+    float* dbrow = dbias + ((size_t)h * WT + lane) * WT;
+    float dqn[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dqn[d] = 0.f;
+    float dsc = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < WT; ++j) {
+      float cosv = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        cosv += q[d] * Ks[w][j][d];
+        dp += g[d] * Vs[w][j][d];
+      }
+      float lg = cosv * sc + brow[j];
+      if (shift && Mid[w][j] != mid) lg += -100.f;
+      const float p = __expf(lg - li);
+      const float ds = p * (dp - Dq);
+      dsc += ds * cosv;
+      atomicAdd(dbrow + j, ds);
+      const float t = ds * sc;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dqn[d] += t * Ks[w][j][d];
+    }
+    float proj = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) proj += q[d] * dqn[d];
+    T* drow = dqkv + trow * 3 * C + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (dqn[d + e] - q[d + e] * proj) / rq;      // d(x/|x|) = (I - n n^T) dy / |x|
+      store4<T>(drow + d, o);
+    }
+    dsc = wave_sum(dsc);
+    if (lane == 0) dscale_part[unit] = dsc;
+  }
+  // ---- pass K: lane = key j
+  {
+    float dkn[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dkn[d] = 0.f; dv[d] = 0.f; }
+#pragma unroll 2
+    for (int i = 0; i < WT; ++i) {
+      float cosv = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        cosv += Qs[w][i][d] * k[d];
+        dp += Gs[w][i][d] * v[d];
+      }
+      float lg = cosv * sc + bias[((size_t)h * WT + i) * WT + lane];
+      if (shift && Mid[w][i] != mid) lg += -100.f;
+      const float p = __expf(lg - Ls[w][i]);
+      const float t = p * (dp - Ds[w][i]) * sc;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        dkn[d] += t * Qs[w][i][d];
+        dv[d] += p * Gs[w][i][d];
+      }
+    }
+    float proj = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) proj += k[d] * dkn[d];
+    T* drow = dqkv + trow * 3 * C + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      f32x4 o, o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (dkn[d + e] - k[d + e] * proj) / rk;
+        o2[e] = dv[d + e];
+      }
+      store4<T>(drow + C + d, o);
+      store4<T>(drow + 2 * C + d, o2);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ merge / mean
+// fwd: out[b, (y/2)(res/2) + x/2, (dy + 2 dx) C + c] = in[b, y res + x, c];  bwd: the inverse copy
+template <typename T>
+__global__ void merge_gather_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int res, int C, int inverse) {
+  const long long n4 = (long long)B * res * res * C / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int c = (int)(e % C);
+    const long long t = e / C;
+    const int x = (int)(t % res), yy = (int)((t / res) % res), b = (int)(t / ((long long)res * res));
+    const long long o = (((long long)b * (res / 2) + yy / 2) * (res / 2) + x / 2) * 4 * C + ((yy & 1) + 2 * (x & 1)) * C + c;
+    typedef typename Vec4<T>::type V;
+    if (inverse) *reinterpret_cast<V*>(out + e) = *reinterpret_cast<const V*>(in + o);
+    else *reinterpret_cast<V*>(out + o) = *reinterpret_cast<const V*>(in + e);
+  }
+}
+
+template <typename T>
+__global__ void token_mean_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += to_f32(x[((size_t)b * N + n) * C + c]);
+    y[(size_t)b * C + c] = from_f32<T>(a / N);
+  }
+}
+template <typename T>
+__global__ void token_mean_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int C) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x)
+    dx[(size_t)b * N * C + i] = from_f32<T>(to_f32(dy[(size_t)b * C + i % C]) / N);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgbnm_swin_embed(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* convY, const float* convC,
+                     void* feat, int B, int Hb, int Wb, void* stream) {
+  if (!y || !cbcr || !convY || !convC || !feat || B <= 0 || (Hb & 1) || (Wb & 1)) return RGBNM_EINVAL;
+  const long long nblk = (long long)B * Hb * Wb + (long long)B * 2 * (Hb / 2) * (Wb / 2);
+  const int grid = (int)((nblk + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+#define EMB(TI, TO) hipLaunchKernelGGL((swin_embed_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)y, (const TI*)cbcr, convY, convC, (TO*)feat, B, Hb, Wb)
+  if (in_dtype == DT_F32 && out_dtype == DT_F32) EMB(float, float);
+  else if (in_dtype == DT_F32 && out_dtype == DT_BF16) EMB(float, bf16);
+  else if (in_dtype == DT_BF16 && out_dtype == DT_BF16) EMB(bf16, bf16);
+  else if (in_dtype == DT_BF16 && out_dtype == DT_F32) EMB(bf16, float);
+  else return RGBNM_EINVAL;
+#undef EMB
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+size_t rgbnm_ln_generic_bwd_workspace(int M, int E) {
+  int blocks = (M + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  return (size_t)blocks * 2 * E * sizeof(float);
+}
+
+int rgbnm_ln_generic_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* res,
+                         const float* sample_scale, int rows_per_sample, void* y, float* mean, float* rstd, int M, int E,
+                         float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || E % 4 || E > 768 || (sample_scale && rows_per_sample <= 0))
+    return RGBNM_EINVAL;
+  int grid = (M + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(ln_generic_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, (const bf16*)res, sample_scale, rows_per_sample, (bf16*)y, mean, rstd, M, E, eps);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL(ln_generic_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (const float*)res, sample_scale, rows_per_sample, (float*)y, mean, rstd, M, E, eps);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                         const float* rstd, const float* sample_scale, int rows_per_sample, void* dx, float* dgamma,
+                         float* dbeta, int M, int E, int accumulate, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || M <= 0 || E % 4 || E > 768)
+    return RGBNM_EINVAL;
+  if (workspace_bytes < rgbnm_ln_generic_bwd_workspace(M, E)) return RGBNM_EWORKSPACE;
+  int grid = (M + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(ln_generic_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, sample_scale, rows_per_sample, (bf16*)dx, part, M, E);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL(ln_generic_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, sample_scale, rows_per_sample, (float*)dx, part, M, E);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  RgbnmReduceJob j;
+  j.part = part; j.stride = 2LL * E; j.out = dgamma; j.n = E; j.S = grid; j.cols = 1; j.perm_heads = 0;
+  j.accumulate = accumulate; j.epw = 8;
+  int rc = rgbnm_reduce_submit(j, st);
+  if (rc != RGBNM_OK) return rc;
+  j.part = part + E; j.out = dbeta;
+  return rgbnm_reduce_submit(j, st);
+}
+
+int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, float* lse,
+                               int B, int res, int C, int heads, int shift, void* stream) {
+  if (!qkv || !bias || !scale || !out || !lse || B <= 0 || res % WS || C != heads * HD || shift < 0 || shift >= WS)
+    return RGBNM_EINVAL;
+  const long long units = (long long)B * (res / WS) * (res / WS) * heads;
+  const int grid = (int)((units + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)win_attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_FWD) != hipSuccess ||
+        hipFuncSetAttribute((const void*)win_attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_FWD) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr = true;
+  }
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(win_attn_fwd_kernel<bf16>, dim3(grid), dim3(256), WIN_SMEM_FWD, st, (const bf16*)qkv, bias, scale, (bf16*)out, lse, B, res, C, heads, shift);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL(win_attn_fwd_kernel<float>, dim3(grid), dim3(256), WIN_SMEM_FWD, st, (const float*)qkv, bias, scale, (float*)out, lse, B, res, C, heads, shift);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+/* dbias [heads,64,64] fp32 is ACCUMULATED into (zero it first); dscale_part [B*nW*heads] fp32 per (window, head). */
+int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
+                               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, int B,
+                               int res, int C, int heads, int shift, void* stream) {
+  if (!qkv || !out || !dout || !bias || !scale || !lse || !dqkv || !dbias || !dscale_part || B <= 0 || res % WS ||
+      C != heads * HD || shift < 0 || shift >= WS)
+    return RGBNM_EINVAL;
+  const long long units = (long long)B * (res / WS) * (res / WS) * heads;
+  const int grid = (int)((units + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)win_attn_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_BWD) != hipSuccess ||
+        hipFuncSetAttribute((const void*)win_attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_BWD) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr = true;
+  }
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(win_attn_bwd_kernel<bf16>, dim3(grid), dim3(256), WIN_SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, bias, scale, lse, (bf16*)dqkv, dbias, dscale_part, B, res, C, heads, shift);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL(win_attn_bwd_kernel<float>, dim3(grid), dim3(256), WIN_SMEM_BWD, st, (const float*)qkv, (const float*)out, (const float*)dout, bias, scale, lse, (float*)dqkv, dbias, dscale_part, B, res, C, heads, shift);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int C, int inverse, void* stream) {
+  if (!in || !out || B <= 0 || (res & 1) || C % 4) return RGBNM_EINVAL;
+  const long long n4 = (long long)B * res * res * C / 4;
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(merge_gather_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)in, (bf16*)out, B, res, C, inverse);
+  else if (dtype == DT_F32) hipLaunchKernelGGL(merge_gather_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, B, res, C, inverse);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_token_mean(int dtype, const void* in, void* out, int B, int N, int C, int backward, void* stream) {
+  if (!in || !out || B <= 0 || N <= 0 || C <= 0) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+#define TM(T) do { if (backward) hipLaunchKernelGGL(token_mean_bwd_kernel<T>, dim3(B), dim3(256), 0, st, (const T*)in, (T*)out, N, C); \
+                   else hipLaunchKernelGGL(token_mean_fwd_kernel<T>, dim3(B), dim3(256), 0, st, (const T*)in, (T*)out, N, C); } while (0)
+  if (dtype == DT_BF16) TM(bf16);
+  else if (dtype == DT_F32) TM(float);
+  else return RGBNM_EINVAL;
+#undef TM
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // extern "C"

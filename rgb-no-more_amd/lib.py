@@ -87,6 +87,14 @@ PROTOTYPES = {
     "rgbnm_vit_workspace": (_sz, [_P(VitCfg)]),
     "rgbnm_vit_block_fwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_ln_chain": (_i, [_P(VitCfg)]),
+    "rgbnm_swin_embed": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rgbnm_ln_generic_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "rgbnm_ln_generic_bwd_workspace": (_sz, [_i, _i]),
+    "rgbnm_ln_generic_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "rgbnm_window_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbnm_window_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbnm_merge_gather": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rgbnm_token_mean": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbnm_vit_block_fwd_chain": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _i, _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
                                  _vp, _vp]),

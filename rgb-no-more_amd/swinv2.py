@@ -1,0 +1,413 @@
+"""Host mirror of the reference `models/swinv2.py` for `--domain DCT` (BASELINE config 5):
+`SwinTransformerV2(img_size=256, patch_size=4, embed_dim=96, depths, num_heads, window_size=8, ..., pixel_space='dct')`
+with the reference's constructor signature, parameter / buffer names (state_dict-compatible) and `forward(y, cbcr)`.
+
+Compute runs on the C-ABI kernels of librgbnm.so: `rgbnm_swin_embed` (8x8 -> 4x4 / 2x2 sub-block decomposition),
+`rgbnm_gemm_nt/tn` (every Linear, GELU fused), `rgbnm_ln_generic_*` (res-post-norm LayerNorm + DropPath scale),
+`rgbnm_window_attention_*` (cosine attention, position bias, shift mask; roll / window partition are index arithmetic
+inside the kernel), `rgbnm_merge_gather`, `rgbnm_token_mean`.  torch is used for autograd bookkeeping, for the
+parameter-only continuous-position-bias MLP (15x15 table -> [heads,64,64]; 0.1 MFLOP) and for per-step weight casts.
+First generation (round 1): correct and complete for training, not yet tuned (generic GEMM tiles, VALU attention).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import dct_ops as dops
+from . import lib as L
+
+WS = 8
+
+
+# ------------------------------------------------------------------ autograd nodes over the C ABI
+def _ws(dev, nbytes):
+    t = _ws.cache.get(dev)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        _ws.cache[dev] = t
+    return t
+
+
+_ws.cache = {}
+
+
+def _gemm_nt(epi, A, W, bias=None, R=None, want_c2=False):
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=A.dtype)
+    c2 = torch.empty_like(out) if want_c2 else None
+    L.check(L.lib().rgbnm_gemm_nt(L.dt_of(A.dtype), epi, A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, L.ptr(bias),
+                                  L.ptr(R), N, L.ptr(c2), N, None, 0, M, N, K, 0, L.stream()), "gemm_nt")
+    return out, c2
+
+
+def _gemm_tn(dY, X, want_bias):
+    M, No = dY.shape
+    Ki = X.shape[1]
+    dW = torch.empty(No, Ki, device=dY.device, dtype=torch.float32)
+    db = torch.empty(No, device=dY.device, dtype=torch.float32) if want_bias else None
+    wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
+    ws = _ws(dY.device, wsb)
+    L.check(L.lib().rgbnm_gemm_tn(L.dt_of(dY.dtype), dY.data_ptr(), No, X.data_ptr(), Ki, dW.data_ptr(), L.ptr(db), M, No,
+                                  Ki, 0, 0, ws.data_ptr(), ws.numel(), L.stream()), "gemm_tn")
+    return dW, db
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b  (x [M,K] in the compute dtype, W fp32 master [N,K], b fp32 or None)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        Wc = W.detach().to(x.dtype).contiguous()
+        y, _ = _gemm_nt(L.EPI_NONE, x, Wc, None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(x, Wc)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wc = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW, db = _gemm_tn(dy, x, ctx.has_b)
+        dx, _ = _gemm_nt(L.EPI_NONE, dy, Wc.t().contiguous())
+        return dx, dW, db
+
+
+class _MlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) with the GELU (and its derivative) fused into the fc1 epilogue and the derivative product
+    fused into fc2's dX GEMM (swinv2.py:19-35)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        W1c, W2c = W1.detach().to(x.dtype).contiguous(), W2.detach().to(x.dtype).contiguous()
+        g, gp = _gemm_nt(L.EPI_GELU, x, W1c, b1.detach().float().contiguous(), want_c2=True)
+        y, _ = _gemm_nt(L.EPI_NONE, g, W2c, b2.detach().float().contiguous())
+        ctx.save_for_backward(x, W1c, W2c, g, gp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W1c, W2c, g, gp = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW2, db2 = _gemm_tn(dy, g, True)
+        du, _ = _gemm_nt(L.EPI_DGELU, dy, W2c.t().contiguous(), None, R=gp)
+        dW1, db1 = _gemm_tn(du, x, True)
+        dx, _ = _gemm_nt(L.EPI_NONE, du, W1c.t().contiguous())
+        return dx, dW1, db1, dW2, db2
+
+
+class _LNFn(torch.autograd.Function):
+    """y = [res +] [s_b *] LayerNorm(x) over the last dim (any width up to 768)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, sscale, rows_per_sample):
+        M, E = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        L.check(L.lib().rgbnm_ln_generic_fwd(L.dt_of(x.dtype), x.data_ptr(), g.data_ptr(), b.data_ptr(), L.ptr(res),
+                                             L.ptr(sscale), rows_per_sample, y.data_ptr(), mean.data_ptr(),
+                                             rstd.data_ptr(), M, E, 1e-5, L.stream()), "ln_generic_fwd")
+        ctx.save_for_backward(x, g, mean, rstd, sscale)
+        ctx.rps, ctx.has_res = rows_per_sample, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd, sscale = ctx.saved_tensors
+        M, E = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(E, device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        wsb = L.lib().rgbnm_ln_generic_bwd_workspace(M, E)
+        ws = _ws(x.device, wsb)
+        L.check(L.lib().rgbnm_ln_generic_bwd(L.dt_of(x.dtype), dy.data_ptr(), x.data_ptr(), g.data_ptr(), mean.data_ptr(),
+                                             rstd.data_ptr(), L.ptr(sscale), ctx.rps, dx.data_ptr(), dg.data_ptr(),
+                                             db.data_ptr(), M, E, 0, ws.data_ptr(), ws.numel(), L.stream()),
+                "ln_generic_bwd")
+        return dx, dg, db, (dy if ctx.has_res else None), None, None
+
+
+class _WinAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bias, scale, B, res, C_, heads, shift):
+        out = torch.empty(qkv.shape[0], C_, device=qkv.device, dtype=qkv.dtype)
+        nw = (res // WS) ** 2
+        lse = torch.empty(B * nw * heads * 64, device=qkv.device, dtype=torch.float32)
+        bias_c, scale_c = bias.detach().float().contiguous(), scale.detach().float().contiguous()
+        L.check(L.lib().rgbnm_window_attention_fwd(L.dt_of(qkv.dtype), qkv.data_ptr(), bias_c.data_ptr(),
+                                                   scale_c.data_ptr(), out.data_ptr(), lse.data_ptr(), B, res, C_, heads,
+                                                   shift, L.stream()), "window_attention_fwd")
+        ctx.save_for_backward(qkv, out, bias_c, scale_c, lse)
+        ctx.geo = (B, res, C_, heads, shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, bias_c, scale_c, lse = ctx.saved_tensors
+        B, res, C_, heads, shift = ctx.geo
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.zeros_like(bias_c)
+        nw = (res // WS) ** 2
+        dsp = torch.empty(B * nw * heads, device=qkv.device, dtype=torch.float32)
+        L.check(L.lib().rgbnm_window_attention_bwd(L.dt_of(qkv.dtype), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                                   bias_c.data_ptr(), scale_c.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                                   dbias.data_ptr(), dsp.data_ptr(), B, res, C_, heads, shift,
+                                                   L.stream()), "window_attention_bwd")
+        return dqkv, dbias, dsp.view(-1, heads).sum(0), None, None, None, None, None
+
+
+class _MergeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, B, res, C_):
+        out = torch.empty(B * (res // 2) ** 2, 4 * C_, device=x.device, dtype=x.dtype)
+        L.check(L.lib().rgbnm_merge_gather(L.dt_of(x.dtype), x.data_ptr(), out.data_ptr(), B, res, C_, 0, L.stream()),
+                "merge_gather")
+        ctx.geo = (B, res, C_)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, res, C_ = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty(B * res * res, C_, device=dy.device, dtype=dy.dtype)
+        L.check(L.lib().rgbnm_merge_gather(L.dt_of(dy.dtype), dy.data_ptr(), dx.data_ptr(), B, res, C_, 1, L.stream()),
+                "merge_scatter")
+        return dx, None, None, None
+
+
+class _MeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, B, N, C_):
+        out = torch.empty(B, C_, device=x.device, dtype=x.dtype)
+        L.check(L.lib().rgbnm_token_mean(L.dt_of(x.dtype), x.data_ptr(), out.data_ptr(), B, N, C_, 0, L.stream()),
+                "token_mean")
+        ctx.geo = (B, N, C_)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, C_ = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty(B * N, C_, device=dy.device, dtype=dy.dtype)
+        L.check(L.lib().rgbnm_token_mean(L.dt_of(dy.dtype), dy.data_ptr(), dx.data_ptr(), B, N, C_, 1, L.stream()),
+                "token_mean_bwd")
+        return dx, None, None, None
+
+
+# ------------------------------------------------------------------ parameter holders (reference names)
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features, **kw):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features, **kw)
+        self.fc2 = nn.Linear(hidden_features, in_features, **kw)
+
+
+class WindowAttention(nn.Module):
+    """swinv2.py:70-182: parameters + the derived constant buffers; compute in SwinTransformerBlock.run."""
+
+    def __init__(self, dim, window_size, num_heads, **kw):
+        super().__init__()
+        ws = window_size
+        self.dim, self.window_size, self.num_heads = dim, (ws, ws), num_heads
+        self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((num_heads, 1, 1), **kw)))
+        self.cpb_mlp = nn.Sequential(nn.Linear(2, 512, bias=True, **kw), nn.ReLU(inplace=True),
+                                     nn.Linear(512, num_heads, bias=False, **kw))
+        r = torch.arange(-(ws - 1), ws, dtype=torch.float32)
+        tab = torch.stack(torch.meshgrid(r, r, indexing="ij"), dim=-1).unsqueeze(0) / (ws - 1) * 8
+        tab = torch.sign(tab) * torch.log2(torch.abs(tab) + 1.0) / np.log2(8)
+        self.register_buffer("relative_coords_table", tab.to(kw.get("device", "cpu")))
+        c = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+        rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous() + (ws - 1)
+        self.register_buffer("relative_position_index", (rel[:, :, 0] * (2 * ws - 1) + rel[:, :, 1]).to(kw.get("device", "cpu")))
+        self.qkv = nn.Linear(dim, dim * 3, bias=False, **kw)
+        self.q_bias = nn.Parameter(torch.zeros(dim, **kw))
+        self.v_bias = nn.Parameter(torch.zeros(dim, **kw))
+        self.proj = nn.Linear(dim, dim, **kw)
+
+    def bias_and_scale(self):
+        """[heads,64,64] position bias and [heads] logit scale (swinv2.py:158-168): parameter-only, fp32 torch ops."""
+        n = self.window_size[0] * self.window_size[1]
+        tab = self.cpb_mlp(self.relative_coords_table).view(-1, self.num_heads)
+        bias = tab[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1).contiguous()
+        scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().view(-1)
+        return 16 * torch.sigmoid(bias), scale
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size, shift_size, drop_path, **kw):
+        super().__init__()
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size = window_size, shift_size
+        if min(input_resolution) <= window_size:
+            self.shift_size, self.window_size = 0, min(input_resolution)
+        if self.window_size != WS or input_resolution[0] != input_resolution[1]:
+            raise NotImplementedError("HIP window attention covers 8x8 windows on square grids (config 5: window 8)")
+        self.norm1 = nn.LayerNorm(dim, **kw)
+        self.attn = WindowAttention(dim, self.window_size, num_heads, **kw)
+        self.drop_path_p = float(drop_path)
+        self.norm2 = nn.LayerNorm(dim, **kw)
+        self.mlp = Mlp(dim, dim * 4, **kw)
+        if self.shift_size > 0:
+            H = W = input_resolution[0]
+            img = torch.zeros((1, H, W, 1))
+            cnt = 0
+            for hs in (slice(0, -WS), slice(-WS, -self.shift_size), slice(-self.shift_size, None)):
+                for wsl in (slice(0, -WS), slice(-WS, -self.shift_size), slice(-self.shift_size, None)):
+                    img[:, hs, wsl, :] = cnt
+                    cnt += 1
+            mw = img.view(1, H // WS, WS, W // WS, WS, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, WS * WS)
+            am = mw.unsqueeze(1) - mw.unsqueeze(2)
+            am = am.masked_fill(am != 0, float(-100.0)).masked_fill(am == 0, float(0.0))
+            self.register_buffer("attn_mask", am.to(kw.get("device", "cpu")))     # kept for state_dict parity; the
+        else:                                                                       # kernel derives it from coordinates
+            self.register_buffer("attn_mask", None)
+
+    def _drop_scale(self, B, dev):
+        if not self.training or self.drop_path_p == 0.0:
+            return None
+        keep = 1.0 - self.drop_path_p                   # timm DropPath: per-sample Bernoulli(keep) / keep
+        return (torch.rand(B, device=dev) < keep).float() / keep
+
+    def run(self, x, B):
+        res, C_ = self.input_resolution[0], self.dim
+        a = self.attn
+        bias, scale = a.bias_and_scale()
+        qb = torch.cat((a.q_bias, torch.zeros_like(a.v_bias, requires_grad=False), a.v_bias))
+        qkv = _LinearFn.apply(x, a.qkv.weight, qb)
+        o = _WinAttnFn.apply(qkv, bias, scale, B, res, C_, self.num_heads, self.shift_size)
+        o = _LinearFn.apply(o, a.proj.weight, a.proj.bias)
+        x = _LNFn.apply(o, self.norm1.weight, self.norm1.bias, x, self._drop_scale(B, x.device), res * res)
+        h = _MlpFn.apply(x, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias)
+        return _LNFn.apply(h, self.norm2.weight, self.norm2.bias, x, self._drop_scale(B, x.device), res * res)
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, input_resolution, dim, **kw):
+        super().__init__()
+        self.input_resolution, self.dim = input_resolution, dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False, **kw)
+        self.norm = nn.LayerNorm(2 * dim, **kw)
+
+    def run(self, x, B):
+        m = _MergeFn.apply(x, B, self.input_resolution[0], self.dim)
+        m = _LinearFn.apply(m, self.reduction.weight, None)
+        return _LNFn.apply(m, self.norm.weight, self.norm.bias, None, None, 1)
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, drop_path, downsample, **kw):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, input_resolution, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2,
+                                 drop_path[i], **kw) for i in range(depth)])
+        self.downsample = PatchMerging(input_resolution, dim, **kw) if downsample else None
+
+
+class PatchEmbedding_DCT_Group(nn.Module):
+    def __init__(self, img_size, emb_size, **kw):
+        super().__init__()
+        self.patches_resolution = [img_size // 4, img_size // 4]
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.projection = nn.Sequential(nn.Linear(16 + 2 * 4, emb_size, **kw))
+        self.norm = nn.LayerNorm(emb_size, **kw)
+        self.conv_Y = dops.generate_conversion_matrix(4, 2, scale=True, dtype=torch.float32)
+        self.conv_C = dops.generate_conversion_matrix(2, 4, scale=True, dtype=torch.float32)
+
+
+class SwinTransformerV2(nn.Module):
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=(2, 2, 6, 2),
+                 num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True, use_checkpoint=False,
+                 pretrained_window_sizes=(0, 0, 0, 0), device="cpu", pixel_space="rgb", **kwargs):
+        super().__init__()
+        if str(pixel_space).lower() != "dct":
+            raise NotImplementedError("rgb-no-more_amd implements the --domain DCT path only")
+        if patch_size != 4 or window_size != WS or mlp_ratio != 4.0 or not qkv_bias or ape or not patch_norm or \
+                drop_rate or attn_drop_rate or any(pretrained_window_sizes) or norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("HIP SwinV2 covers the config-5 shape: patch 4, window 8, mlp_ratio 4, qkv_bias, "
+                                      "no ape, patch_norm, no dropout, no pretrained window size")
+        if any(embed_dim * 2 ** i != 32 * h for i, h in enumerate(num_heads)):
+            raise NotImplementedError("head_dim must be 32 in every stage (SwinV2-T/S/B: embed_dim = 32 * heads[0])")
+        if img_size % 8 or (img_size // 4) % (WS * 2 ** (len(depths) - 1)):
+            raise NotImplementedError("every stage must keep a grid that is a multiple of the 8x8 window")
+        kw = dict(device=device, dtype=torch.float32)
+        self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.pixel_space = "dct"
+        self.patch_embed = PatchEmbedding_DCT_Group(img_size, embed_dim, **kw)
+        self.patches_resolution = self.patch_embed.patches_resolution
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            r = self.patches_resolution[0] // (2 ** i)
+            self.layers.append(BasicLayer(int(embed_dim * 2 ** i), (r, r), depths[i], num_heads[i], window_size,
+                                          dpr[sum(depths[:i]):sum(depths[:i + 1])], i < self.num_layers - 1, **kw))
+        self.norm = nn.LayerNorm(self.num_features, **kw)
+        self.head = nn.Linear(self.num_features, num_classes, **kw)
+        self.apply(self._init_weights)
+        for ly in self.layers:                      # res-post-norm init (swinv2.py:450-455)
+            for blk in ly.blocks:
+                for n in (blk.norm1, blk.norm2):
+                    nn.init.constant_(n.bias, 0)
+                    nn.init.constant_(n.weight, 0)
+        self.compute_dtype = None                   # None: follow autocast; or torch.float32 / torch.bfloat16
+        self._conv = None
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def no_weight_decay(self):
+        return {"absolute_pos_embed"}
+
+    def no_weight_decay_keywords(self):
+        return {"cpb_mlp", "logit_scale", "relative_position_bias_table"}
+
+    def forward(self, y, cbcr=None):
+        if cbcr is None:
+            raise ValueError("DCT path needs both Y and CbCr tensors")
+        L.require_cuda(y, cbcr)
+        B, _, Hb, Wb, _, _ = y.shape
+        res = self.patches_resolution[0]
+        if y.dim() != 6 or (2 * Hb, 2 * Wb) != (res, res) or tuple(cbcr.shape) != (B, 2, Hb // 2, Wb // 2, 8, 8):
+            raise ValueError(f"expected Y (B,1,{res // 2},{res // 2},8,8) and CbCr (B,2,{res // 4},{res // 4},8,8)")
+        cdt = self.compute_dtype
+        if cdt is None:
+            cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        if cdt not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"compute dtype {cdt}")
+        dev = y.device
+        if self._conv is None or self._conv[0].device != dev:
+            self._conv = (self.patch_embed.conv_Y.to(dev).contiguous(), self.patch_embed.conv_C.to(dev).contiguous())
+        y, cbcr = y.contiguous(), cbcr.contiguous()
+        if y.dtype not in (torch.float32, torch.bfloat16) or cbcr.dtype != y.dtype:
+            raise TypeError("Y and CbCr must be fp32 or bf16 and share a dtype")
+        feat = torch.empty(B * res * res, 24, device=dev, dtype=cdt)
+        L.check(L.lib().rgbnm_swin_embed(L.dt_of(y.dtype), L.dt_of(cdt), y.data_ptr(), cbcr.data_ptr(),
+                                         self._conv[0].data_ptr(), self._conv[1].data_ptr(), feat.data_ptr(), B, Hb, Wb,
+                                         L.stream()), "swin_embed")
+        pe = self.patch_embed
+        x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias)
+        x = _LNFn.apply(x, pe.norm.weight, pe.norm.bias, None, None, 1)
+        for ly in self.layers:
+            for blk in ly.blocks:
+                x = blk.run(x, B)
+            if ly.downsample is not None:
+                x = ly.downsample.run(x, B)
+                res //= 2
+        x = _LNFn.apply(x, self.norm.weight, self.norm.bias, None, None, 1)
+        x = _MeanFn.apply(x, B, res * res, self.num_features)
+        return _LinearFn.apply(x, self.head.weight, self.head.bias)

@@ -1,0 +1,214 @@
+"""SwinV2 DCT (BASELINE config 5) on the HIP kernels against the oracle (oracle/swin_torch.py) and
+the reference goldens (tests/golden/g15_swin.npz, generated from /root/reference/models/swinv2.py).
+fp32: logits within the north-star 1e-3 (measured ~1e-5); bf16: tolerance of the ViT bf16 test; index ops bit exact."""
+import numpy as np
+import pytest
+import torch
+
+import rgb_no_more_amd as rg
+from rgb_no_more_amd import detfill, lib as L, swinv2 as SW
+from oracle import swin_torch as S
+
+DEV = "cuda"
+CASES = {"sw3": (128, [2, 2, 2], [3, 6, 12], 2), "swt": (256, [2, 2, 6, 2], [3, 6, 12, 24], 1)}
+
+
+def _model(tag, device):
+    img, depths, heads, B = CASES[tag]
+    m = rg.SwinTransformerV2(img_size=img, patch_size=4, embed_dim=96, depths=depths, num_heads=heads, window_size=8,
+                             mlp_ratio=4.0, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, qkv_bias=True,
+                             ape=False, patch_norm=True, pretrained_window_sizes=[0] * len(depths), device=device,
+                             pixel_space="dct")
+    return m, img, depths, heads, B
+
+
+def test_state_dict_surface_matches_reference(golden):
+    g = golden("g15_swin.npz")
+    for tag in CASES:
+        m, *_ = _model(tag, "cpu")
+        assert [n for n, _ in m.named_parameters()] == [str(s) for s in g[tag + "_names"]]
+        assert [str(tuple(p.shape)) for _, p in m.named_parameters()] == [str(s) for s in g[tag + "_shapes"]]
+        assert [n for n, _ in m.named_buffers()] == [str(s) for s in g[tag + "_buffers"]]
+    with pytest.raises(NotImplementedError):
+        rg.SwinTransformerV2(img_size=256, patch_size=4, window_size=7, pixel_space="dct")
+    with pytest.raises(NotImplementedError):
+        rg.SwinTransformerV2(img_size=256, patch_size=4, window_size=8, pixel_space="rgb")
+
+
+def _load(m, tag, g):
+    names = [str(n) for n in g[tag + "_names"]]
+    img, depths, heads, B = CASES[tag]
+    shapes = S.param_shapes(depths, heads)
+    sd = S.fill_params({n: shapes[n] for n in names})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    nb = img // 8
+    y = torch.from_numpy(detfill.normalish((B, 1, nb, nb, 8, 8), 171)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, nb // 2, nb // 2, 8, 8), 172)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 173, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    return names, y, c, tgt
+
+
+@pytest.mark.gpu
+def test_embed_decomposition_is_exact_index_work_plus_fp32_products():
+    B, H = 3, 6
+    y = torch.from_numpy(detfill.normalish((B, 1, H, H, 8, 8), 5))
+    c = torch.from_numpy(detfill.normalish((B, 2, H // 2, H // 2, 8, 8), 6))
+    ref = S.decompose_features(y, c).reshape(B * 4 * H * H, 24)
+    Ay = torch.from_numpy(S.dct_np.conversion_matrix(4, 2)).float().to(DEV)
+    Ac = torch.from_numpy(S.dct_np.conversion_matrix(2, 4)).float().to(DEV)
+    out = torch.full((B * 4 * H * H, 24), float("nan"), device=DEV)
+    yd, cd = y.to(DEV), c.to(DEV)
+    L.check(L.lib().rgbnm_swin_embed(0, 0, yd.data_ptr(), cd.data_ptr(), Ay.data_ptr(), Ac.data_ptr(), out.data_ptr(), B, H,
+                                     H, L.stream()))
+    assert torch.isfinite(out).all()                      # every (token, feature) slot written exactly once
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-6)
+    # a block holding a single non-zero coefficient lands in the tokens / features the einops string dictates
+    y0 = torch.zeros(1, 1, 2, 2, 8, 8)
+    y0[0, 0, 1, 0, 0, 0] = 1.0                            # DC of block (1, 0): spreads to the DC of its 2x2 sub-blocks
+    r0 = S.decompose_features(y0, torch.zeros(1, 2, 1, 1, 8, 8)).reshape(16, 24)
+    o0 = torch.empty(16, 24, device=DEV)
+    z = torch.zeros(1, 2, 1, 1, 8, 8, device=DEV)
+    y0d = y0.to(DEV)
+    L.check(L.lib().rgbnm_swin_embed(0, 0, y0d.data_ptr(), z.data_ptr(), Ay.data_ptr(), Ac.data_ptr(), o0.data_ptr(), 1, 2, 2,
+                                     L.stream()))
+    np.testing.assert_allclose(o0.cpu().numpy(), r0.numpy(), atol=1e-6)
+    assert (o0.abs() > 1e-3).sum().item() == (r0.abs() > 1e-3).sum().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("E", [96, 192, 768])
+def test_layernorm_any_width_with_residual_and_sample_scale(dt, E):
+    B, N = 3, 70
+    M = B * N
+    x = torch.from_numpy(detfill.normalish((M, E), 11)).to(DEV).to(dt)
+    res = torch.from_numpy(detfill.normalish((M, E), 12)).to(DEV).to(dt)
+    g = torch.from_numpy(1.0 + detfill.uniform((E,), 13, -0.3, 0.3)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(detfill.uniform((E,), 14, -0.3, 0.3)).to(DEV).requires_grad_(True)
+    ss = torch.tensor([0.0, 1.25, 1.25], device=DEV)
+    xg, rg_ = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    out = SW._LNFn.apply(xg, g, b, rg_, ss, N)
+    xr, rr = x.float().clone().requires_grad_(True), res.float().clone().requires_grad_(True)
+    gr, br = g.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ref = rr + ss.repeat_interleave(N)[:, None] * torch.nn.functional.layer_norm(xr, (E,), gr, br, 1e-5)
+    tol = 2e-5 if dt == torch.float32 else 3e-2
+    assert (out.float() - ref).abs().max().item() < tol
+    w = torch.from_numpy(detfill.normalish((M, E), 15)).to(DEV)
+    (out.float() * w).sum().backward()
+    (ref * w).sum().backward()
+    rel = lambda a, bb: ((a.float() - bb).norm() / (bb.norm() + 1e-12)).item()   # noqa: E731
+    assert rel(xg.grad, xr.grad) < (1e-5 if dt == torch.float32 else 2e-2)
+    assert rel(rg_.grad, rr.grad) < (1e-6 if dt == torch.float32 else 1e-2)
+    assert rel(g.grad, gr.grad) < (1e-5 if dt == torch.float32 else 2e-2)
+    assert rel(b.grad, br.grad) < (1e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("res,heads,shift", [(16, 3, 0), (16, 3, 4), (8, 6, 0), (32, 3, 4)])
+def test_window_attention_forward_backward_vs_oracle(dt, res, heads, shift):
+    """Cyclic shift + window partition + cosine attention + bias + mask + reverse, against the oracle's explicit
+    roll / partition / softmax pipeline (oracle/swin_torch.py:window_attention) with identity qkv / proj Linears."""
+    B, C_ = 2, heads * 32
+    qkv = torch.from_numpy(detfill.normalish((B * res * res, 3 * C_), 21)).to(DEV).to(dt)
+    bias = torch.from_numpy(detfill.uniform((heads, 64, 64), 22, 0.0, 16.0)).to(DEV).requires_grad_(True)
+    scale = torch.from_numpy(detfill.uniform((heads,), 23, 5.0, 30.0)).to(DEV).requires_grad_(True)
+    qg = qkv.clone().requires_grad_(True)
+    out = SW._WinAttnFn.apply(qg, bias, scale, B, res, C_, heads, shift)
+    # oracle: same math with torch ops on the CPU in fp32
+    q32 = qkv.float().cpu().clone().requires_grad_(True)
+    bias_r, scale_r = bias.detach().cpu().clone().requires_grad_(True), scale.detach().cpu().clone().requires_grad_(True)
+    x = q32.reshape(B, res, res, 3 * C_)
+    xs = torch.roll(x, (-shift, -shift), (1, 2)) if shift else x
+    nw = res // 8
+    xw = xs.reshape(B, nw, 8, nw, 8, 3 * C_).permute(0, 1, 3, 2, 4, 5).reshape(B * nw * nw, 64, 3, heads, 32)
+    q, k, v = xw.permute(2, 0, 3, 1, 4)
+    att = torch.nn.functional.normalize(q, dim=-1) @ torch.nn.functional.normalize(k, dim=-1).transpose(-2, -1)
+    att = att * scale_r.view(1, heads, 1, 1) + bias_r.unsqueeze(0)
+    if shift:
+        m = S.shift_mask(res, 8, shift)
+        att = (att.reshape(B, nw * nw, heads, 64, 64) + m[None, :, None]).reshape(-1, heads, 64, 64)
+    o = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B, nw, nw, 8, 8, C_).permute(0, 1, 3, 2, 4, 5)
+    o = o.reshape(B, res, res, C_)
+    ref = (torch.roll(o, (shift, shift), (1, 2)) if shift else o).reshape(B * res * res, C_)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert (out.float().cpu() - ref).abs().max().item() < tol
+    w = torch.from_numpy(detfill.normalish((B * res * res, C_), 24))
+    (out.float() * w.to(DEV)).sum().backward()
+    (ref * w).sum().backward()
+    rel = lambda a, bb: ((a.float().cpu() - bb).norm() / (bb.norm() + 1e-12)).item()   # noqa: E731
+    t = 2e-5 if dt == torch.float32 else 3e-2
+    assert rel(qg.grad, q32.grad) < t
+    assert rel(bias.grad, bias_r.grad) < t
+    # d(scale) is a heavily cancelling sum over all logits; in bf16 it also sees the rounding of O inside D = dO.O
+    assert rel(scale.grad, scale_r.grad) < (t if dt == torch.float32 else 8e-2)
+
+
+@pytest.mark.gpu
+def test_merge_gather_and_token_mean_are_exact():
+    B, res, C_ = 2, 6, 8
+    x = torch.arange(B * res * res * C_, dtype=torch.float32, device=DEV).reshape(B * res * res, C_).requires_grad_(True)
+    out = SW._MergeFn.apply(x, B, res, C_)
+    xr = x.detach().reshape(B, res, res, C_)
+    ref = torch.cat([xr[:, 0::2, 0::2], xr[:, 1::2, 0::2], xr[:, 0::2, 1::2], xr[:, 1::2, 1::2]], -1).reshape(-1, 4 * C_)
+    assert torch.equal(out, ref)
+    out.backward(out.detach())
+    assert torch.equal(x.grad, x.detach())                # scatter is the exact inverse of the gather
+    t = torch.from_numpy(detfill.normalish((3 * 10, 16), 31)).to(DEV).requires_grad_(True)
+    mo = SW._MeanFn.apply(t, 3, 10, 16)
+    np.testing.assert_allclose(mo.detach().cpu().numpy(), t.detach().reshape(3, 10, 16).mean(1).cpu().numpy(), atol=1e-6)
+    mo.sum().backward()
+    np.testing.assert_allclose(t.grad.cpu().numpy(), np.full((30, 16), 0.1, np.float32), atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["sw3", "swt"])
+def test_swin_fp32_logits_and_grads_vs_reference_golden(golden, tag):
+    g = golden("g15_swin.npz")
+    m, img, depths, heads, B = _model(tag, DEV)
+    names, y, c, tgt = _load(m, tag, g)
+    m.train()
+    m.compute_dtype = torch.float32
+    logits = m(y, c)
+    err = np.abs(logits.detach().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] fp32 max |dlogit| = {err:.3e}")
+    assert err <= 1e-3 and err <= 1e-4
+    loss = rg.cls_transforms.cross_entropy(logits, tgt)
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 2e-5
+    loss.backward()
+    named = dict(m.named_parameters())
+    gn = np.array([named[n].grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=2e-3, atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_swin_bf16_and_drop_path_training_step(golden):
+    g = golden("g15_swin.npz")
+    m, img, depths, heads, B = _model("sw3", DEV)
+    names, y, c, tgt = _load(m, "sw3", g)
+    m.train()
+    m.compute_dtype = torch.bfloat16
+    logits = m(y, c)
+    err = np.abs(logits.detach().float().cpu().numpy() - g["sw3_logits"]).max()
+    print(f"[sw3] bf16 max |dlogit| = {err:.3e}")
+    assert err <= 6e-2
+    rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
+    named = dict(m.named_parameters())
+    gn = np.array([named[n].grad.double().norm().item() for n in names])
+    rel = np.abs(gn - g["sw3_gradnorms"]) / (g["sw3_gradnorms"] + 1e-9)
+    assert np.median(rel) < 3e-2
+    # stochastic depth: with p > 0 in training mode some samples skip a branch entirely; eval mode is deterministic
+    for ly in m.layers:
+        for blk in ly.blocks:
+            blk.drop_path_p = 0.5
+    m.compute_dtype = torch.float32
+    torch.manual_seed(0)
+    a = m(y, c)
+    b2 = m(y, c)
+    assert not torch.equal(a, b2)
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(y, c), m(y, c)
+    assert torch.equal(e1, e2)
+    np.testing.assert_allclose(e1.cpu().numpy(), g["sw3_logits"], atol=1e-4)
