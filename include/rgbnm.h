@@ -293,8 +293,9 @@ int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* 
 int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, float* lse,
                                int B, int res, int C, int heads, int shift, void* stream);
 int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
-                               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, int B,
-                               int res, int C, int heads, int shift, void* stream);
+                               const float* bias_t /* [heads,64(key),64(query)]: bias transposed */, const float* scale,
+                               const float* lse, void* dqkv, float* dbias, float* dscale_part, int B, int res, int C,
+                               int heads, int shift, void* stream);
 /* PatchMerging's concat (swinv2.py:357-362): [B, res*res, C] -> [B, (res/2)^2, 4C] (inverse != 0: the reverse copy). */
 int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int C, int inverse, void* stream);
 /* mean over tokens [B,N,C] -> [B,C] (backward != 0: [B,C] -> [B,N,C], dy / N). */

