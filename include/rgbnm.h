@@ -288,14 +288,15 @@ int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* 
 /* WindowAttention + cyclic shift + window partition / reverse (swinv2.py:143-182, 273-300) on token-major tensors:
  * qkv [B, res*res, 3C] (q | k | v, heads of 32), bias [heads, 64, 64] fp32 (= 16 sigmoid(cpb_mlp(table))[index]),
  * scale [heads] fp32 (= exp(min(logit_scale, ln 100))), shift in {0, 4}: window 8x8, cosine attention, shift mask -100.
- * out [B, res*res, C]; lse [B * nW * heads * 64] saved for backward.  Backward ACCUMULATES into dbias (zero it first)
- * and writes one partial d(scale) per (window, head) into dscale_part [B * nW * heads]. */
+ * out [B, res*res, C]; lse [B * nW * heads * 64] saved for backward.  Backward writes dbias (per-wave partials in the
+ * workspace, deterministic reduction) and one partial d(scale) per (window, head) into dscale_part [B * nW * heads]. */
 int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, float* lse,
                                int B, int res, int C, int heads, int shift, void* stream);
+size_t rgbnm_window_attention_bwd_workspace(int B, int res, int heads);
 int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
                                const float* bias_t /* [heads,64(key),64(query)]: bias transposed */, const float* scale,
                                const float* lse, void* dqkv, float* dbias, float* dscale_part, int B, int res, int C,
-                               int heads, int shift, void* stream);
+                               int heads, int shift, void* workspace, size_t workspace_bytes, void* stream);
 /* PatchMerging's concat (swinv2.py:357-362): [B, res*res, C] -> [B, (res/2)^2, 4C] (inverse != 0: the reverse copy). */
 int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int C, int inverse, void* stream);
 /* mean over tokens [B,N,C] -> [B,C] (backward != 0: [B,C] -> [B,N,C], dy / N). */

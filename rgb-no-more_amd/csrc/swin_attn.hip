@@ -12,9 +12,9 @@
 // one query and 16 keys per 32-key tile in registers - softmax is register-local plus one lane^32 exchange, and the
 // probabilities are the next MFMA's B operand straight from registers.  16 MFMAs forward, 56 backward per (window,
 // head) in bf16 (32x32x16) - the first generation of this kernel needed 8192 VALU FMAs per lane for the same work.
-// Backward: a wave walks `wpw` windows of ONE head and keeps that head's d(bias) in 64 registers (accumulator layout),
-// so the global atomics into the shared [heads,64,64] gradient shrink by wpw; d(logit_scale) leaves as one partial per
-// (window, head).  Templated on T in {float, bf16} (fp32 = exact 32x32x2 MFMA, the parity mode).
+// Backward: a wave walks `wpw` windows of ONE head and keeps that head's d(bias) in 64 registers (accumulator layout);
+// it leaves as one partial slice per wave, summed by the batched deterministic reduction (no atomics);
+// d(logit_scale) leaves as one partial per (window, head).  Templated on T in {float, bf16} (fp32 = exact 32x32x2 MFMA, the parity mode).
 #include "common.h"
 #include "../../include/rgbnm.h"
 #include "internal.h"
@@ -191,7 +191,7 @@ template <typename T>
 __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout, const float* __restrict__ bias,
     const float* __restrict__ bias_t, const float* __restrict__ scale, const float* __restrict__ lse,
-    T* __restrict__ dqkv, float* __restrict__ dbias, float* __restrict__ dscale_part, int B, int res, int C, int heads,
+    T* __restrict__ dqkv, float* __restrict__ dpart, float* __restrict__ dscale_part, int B, int res, int C, int heads,
     int shift, int wpw) {
   using A = WA<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
@@ -416,14 +416,16 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
       }
     }
   }
-  // d(bias)[h][query][key]: one atomic per element per wave (wpw windows already summed in registers)
+  // d(bias)[h][query][key] of this wave's windows -> its own partial slice [group][head][64][64]; summed over groups
+  // by the batched deterministic reduction (reduce.hip).  (Global atomics here cost 5 ms of a 20 ms step: every
+  // window of the batch adds into the same 64 x 64 x heads addresses.)
+  float* dp = dpart + (((gid % groups) * heads + h) * (size_t)(WT * WT));
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        atomicAdd(dbias + ((size_t)h * WT + 32 * i + l31) * WT + 32 * t + acc_row(r, lane), dbacc[i][t][r]);
+      for (int r = 0; r < 16; ++r) dp[(32 * i + l31) * WT + 32 * t + acc_row(r, lane)] = dbacc[i][t][r];
 }
 
 template <typename T> int set_attrs() {
@@ -450,22 +452,29 @@ int launch_fwd(const void* qkv, const float* bias, const float* scale, void* out
   return RGBNM_OK;
 }
 
+// windows per wave: keep ~4096 waves in flight (bounds the partial d(bias) buffer to 4096 x 16 KB = 64 MB)
+int bwd_wpw(long long nwin, int heads) {
+  int wpw = (int)(nwin * heads / 4096);
+  return wpw < 1 ? 1 : (wpw > 64 ? 64 : wpw);
+}
+
 template <typename T>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* bias, const float* bias_t,
-               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, int B, int res, int C,
-               int heads, int shift, hipStream_t st) {
+               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, float* dpart, int B,
+               int res, int C, int heads, int shift, hipStream_t st) {
   if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
   const long long nwin = (long long)B * (res / WS) * (res / WS);
-  // windows per wave: keep >= ~4096 waves in flight, cut the d(bias) atomics by up to 16x
-  int wpw = (int)(nwin * heads / 4096);
-  wpw = wpw < 1 ? 1 : (wpw > 16 ? 16 : wpw);
-  const long long waves = ((nwin + wpw - 1) / wpw) * heads;
+  const int wpw = bwd_wpw(nwin, heads);
+  const long long groups = (nwin + wpw - 1) / wpw, waves = groups * heads;
   const int grid = (int)((waves + WA<T>::BWD_WAVES - 1) / WA<T>::BWD_WAVES);
   hipLaunchKernelGGL(win_attn_bwd_kernel<T>, dim3(grid), dim3(64 * WA<T>::BWD_WAVES), WA<T>::BWD_WAVE * WA<T>::BWD_WAVES, st,
-                     (const T*)qkv, (const T*)out, (const T*)dout, bias, bias_t, scale, lse, (T*)dqkv, dbias, dscale_part,
+                     (const T*)qkv, (const T*)out, (const T*)dout, bias, bias_t, scale, lse, (T*)dqkv, dpart, dscale_part,
                      B, res, C, heads, shift, wpw);
   LAUNCH_CHECK();
-  return RGBNM_OK;
+  RgbnmReduceJob j;
+  j.part = dpart; j.stride = (long long)heads * WT * WT; j.out = dbias; j.n = heads * WT * WT; j.S = (int)groups;
+  j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
+  return rgbnm_reduce_submit(j, st);
 }
 
 }  // namespace
@@ -482,17 +491,28 @@ int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, co
   return RGBNM_EINVAL;
 }
 
+size_t rgbnm_window_attention_bwd_workspace(int B, int res, int heads) {
+  const long long nwin = (long long)B * (res / WS) * (res / WS);
+  const int wpw = bwd_wpw(nwin, heads);
+  return (size_t)((nwin + wpw - 1) / wpw) * heads * WT * WT * sizeof(float);
+}
+
 int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
                                const float* bias_t, const float* scale, const float* lse, void* dqkv, float* dbias,
-                               float* dscale_part, int B, int res, int C, int heads, int shift, void* stream) {
-  if (!qkv || !out || !dout || !bias || !bias_t || !scale || !lse || !dqkv || !dbias || !dscale_part || B <= 0 ||
-      res % WS || C != heads * HD || shift < 0 || shift >= WS)
+                               float* dscale_part, int B, int res, int C, int heads, int shift, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!qkv || !out || !dout || !bias || !bias_t || !scale || !lse || !dqkv || !dbias || !dscale_part || !workspace ||
+      B <= 0 || res % WS || C != heads * HD || shift < 0 || shift >= WS)
     return RGBNM_EINVAL;
+  if (workspace_bytes < rgbnm_window_attention_bwd_workspace(B, res, heads)) return RGBNM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  float* dpart = (float*)workspace;
   if (dtype == DT_BF16)
-    return launch_bwd<bf16>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, B, res, C, heads, shift, st);
+    return launch_bwd<bf16>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads,
+                            shift, st);
   if (dtype == DT_F32)
-    return launch_bwd<float>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, B, res, C, heads, shift, st);
+    return launch_bwd<float>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads,
+                             shift, st);
   return RGBNM_EINVAL;
 }
 

@@ -92,7 +92,8 @@ PROTOTYPES = {
     "rgbnm_ln_generic_bwd_workspace": (_sz, [_i, _i]),
     "rgbnm_ln_generic_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "rgbnm_window_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "rgbnm_window_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rgbnm_window_attention_bwd_workspace": (_sz, [_i, _i, _i]),
+    "rgbnm_window_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "rgbnm_merge_gather": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbnm_token_mean": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbnm_vit_block_fwd_chain": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _i, _P(BlockParams), _P(BlockActs), _vp]),

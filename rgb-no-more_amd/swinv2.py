@@ -154,14 +154,17 @@ class _WinAttnFn(torch.autograd.Function):
         B, res, C_, heads, shift = ctx.geo
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
-        dbias = torch.zeros_like(bias_c)
+        dbias = torch.empty_like(bias_c)
+        wsb = L.lib().rgbnm_window_attention_bwd_workspace(B, res, heads)
+        ws = _ws(qkv.device, wsb)
         nw = (res // WS) ** 2
         dsp = torch.empty(B * nw * heads, device=qkv.device, dtype=torch.float32)
         bias_t = bias_c.transpose(1, 2).contiguous()
         L.check(L.lib().rgbnm_window_attention_bwd(L.dt_of(qkv.dtype), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                                    bias_c.data_ptr(), bias_t.data_ptr(), scale_c.data_ptr(),
                                                    lse.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), dsp.data_ptr(), B,
-                                                   res, C_, heads, shift, L.stream()), "window_attention_bwd")
+                                                   res, C_, heads, shift, ws.data_ptr(), ws.numel(), L.stream()),
+                "window_attention_bwd")
         return dqkv, dbias, dsp.view(-1, heads).sum(0), None, None, None, None, None
 
 
