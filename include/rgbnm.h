@@ -135,6 +135,9 @@ int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void*
 #define RGBNM_OP_GRAYSCALE 13      /* CbCr *= 0                             (custom_transforms.py:1004-1005) */
 #define RGBNM_OP_CHROMADROP 14     /* iarg0 != 0 drops Cb, else Cr          (:1011-1015)          */
 #define RGBNM_OP_SHARPNESS 15      /* sharpblur_dct, iarg0 = filter index   (dct_ops.py:681-708)  */
+#define RGBNM_OP_INVERT 16         /* invert_dct: all coefficients * -1     (dct_ops.py:623-629)  */
+#define RGBNM_OP_SOLARIZE 17       /* iarg0 = floor(threshold): blocks with luma DC > threshold negated (:631-651) */
+#define RGBNM_OP_FREQENHANCE 18    /* fmag = factor: AC coefficients * factor, rounded (:1015-1035) */
 
 typedef struct rgbnm_aug_params {
   int crop_i, crop_j, crop_h, crop_w; /* luma blocks; chroma box = luma box / 2 (custom_transforms.py:647-652) */

@@ -351,6 +351,19 @@ def apply_op(Y, C, op_name, magnitude, aux=None):
     elif op_name == "ChromaDrop":
         drop_cb = bool(aux)
         C[0 if drop_cb else 1] *= 0
+    elif op_name == "Invert":                          # dct_ops.py:623-629 (zero-centred coefficients: * -1)
+        Y, C = Y * -1, C * -1
+    elif op_name == "Solarize":                        # dct_ops.py:631-651, custom_transforms.py:981-983
+        mask = Y[:, :, :, 0, 0] > magnitude            # blocks whose luma DC exceeds the threshold
+        Y[mask] *= -1
+        cm = np.tile(mask[:, ::2, ::2], (2, 1, 1))     # chroma block (r, c) follows luma block (2r, 2c)
+        C[cm] *= -1
+    elif op_name == "FreqEnhance":                     # dct_ops.py:1015-1035: AC * factor (fp32), round half to even
+        f = np.float32(1.0 + magnitude)
+        for T in (Y, C):
+            dc = T[..., 0, 0].copy()
+            T[...] = np.rint(T.astype(np.float32) * f).astype(T.dtype)
+            T[..., 0, 0] = dc
     else:
         raise ValueError(f"The provided operator {op_name} is not recognized.")
     return (np.ascontiguousarray(np.clip(Y, CMIN, CMAX)), np.ascontiguousarray(np.clip(C, CMIN, CMAX)))

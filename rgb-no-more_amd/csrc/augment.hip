@@ -186,6 +186,7 @@ __global__ __launch_bounds__(AUG_THREADS) void dct_randaug_kernel(short* inter,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   short* img = reinterpret_cast<short*>(smem_raw);                    // [NIMG]
   int* red = reinterpret_cast<int*>(smem_raw + NIMG * sizeof(short));  // [48]
+  unsigned char* smask = smem_raw + NIMG * sizeof(short) + 256;        // [S_Y * S_Y] Solarize: luma blocks to invert
   const int b = blockIdx.x, tid = threadIdx.x;
   const rgbnm_aug_params* pp = prm + b;   // indexed per slot straight from memory (a local copy would go to scratch)
   {
@@ -261,6 +262,24 @@ __global__ __launch_bounds__(AUG_THREADS) void dct_randaug_kernel(short* inter,
         float x = (float)img[e] * F[e & 63];
         x = fminf(fmaxf(x, (float)CMIN), (float)CMAX);
         img[e] = clamp_s(__float2int_rn(x));
+      }
+    } else if (op == RGBNM_OP_INVERT || op == RGBNM_OP_SOLARIZE || op == RGBNM_OP_FREQENHANCE) {
+      // whole-block ops outside the default lists: invert_dct (dct_ops.py:623-629), solarize_dct (:631-651:
+      // blocks whose ORIGINAL luma DC exceeds the threshold are negated; chroma block (r,c) follows luma block (2r,2c),
+      // custom_transforms.py:981-983), freq_enhance_dct (:1015-1035: AC * factor, round half to even, DC untouched)
+      if (op == RGBNM_OP_SOLARIZE) {
+        for (int i = tid; i < S_Y * S_Y; i += AUG_THREADS) smask[i] = img[i * 64] > i0 ? 1 : 0;
+        __syncthreads();
+      }
+      for (int e = tid; e < NIMG; e += AUG_THREADS) {
+        const Decoded d = decode(e);
+        int v = img[e];
+        if (op == RGBNM_OP_INVERT) v = -v;
+        else if (op == RGBNM_OP_SOLARIZE) {
+          const int m = d.pl == 0 ? smask[d.r * S_Y + d.c] : smask[2 * d.r * S_Y + 2 * d.c];
+          v = m ? -v : v;
+        } else if ((e & 63) != 0) v = __float2int_rn((float)v * fm);
+        img[e] = clamp_s(v);
       }
     } else if (op != RGBNM_OP_IDENTITY) {
       // ---- DC photometric ops: exact integer reduction over the DC set, fp32 update, round, clamp ----
@@ -367,7 +386,7 @@ int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* qu
     if (p.crop_i + p.crop_h > Hy || p.crop_j + p.crop_w > Wy) return RGBNM_EINVAL;
     if (CbCrq && (p.crop_i / 2 + p.crop_h / 2 > Hc || p.crop_j / 2 + p.crop_w / 2 > Wc)) return RGBNM_EINVAL;
     for (int s = 0; s < nops; ++s)
-      if (p.op[s] < 0 || p.op[s] > RGBNM_OP_SHARPNESS) return RGBNM_EINVAL;
+      if (p.op[s] < 0 || p.op[s] > RGBNM_OP_FREQENHANCE) return RGBNM_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
   ResizeArgs a;
@@ -375,7 +394,7 @@ int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* qu
   a.B = B; a.Hy = Hy; a.Wy = Wy; a.Hc = Hc; a.Wc = Wc; a.has_chroma = CbCrq != nullptr;
   hipLaunchKernelGGL(dct_resize_kernel, dim3(B, 8), dim3(256), 0, st, a);
   LAUNCH_CHECK();
-  const size_t smem = NIMG * sizeof(short) + 256;
+  const size_t smem = NIMG * sizeof(short) + 256 + 1024;    // image + reduction scratch + Solarize block mask
   if (out_dtype == DT_F32) {
     static bool attr = false;
     if (!attr) {

@@ -22,7 +22,7 @@ from . import lib as L
 
 OPS = {"Identity": 0, "AutoContrast": 1, "Posterize": 2, "SolarizeAdd": 3, "Color": 4, "Contrast": 5, "Brightness": 6,
        "MidfreqAug": 7, "Cutout": 8, "TranslateX": 9, "TranslateY": 10, "Rotate90": 11, "AutoSaturation": 12,
-       "Grayscale": 13, "ChromaDrop": 14, "Sharpness": 15}
+       "Grayscale": 13, "ChromaDrop": 14, "Sharpness": 15, "Invert": 16, "Solarize": 17, "FreqEnhance": 18}
 CHROMA_OPS = {"Grayscale", "Color", "AutoSaturation", "ChromaDrop"}
 # default vitti list (utils/configs.py:93)
 VITTI_OPS = ("AutoContrast,Posterize,SolarizeAdd,Color,Contrast,Brightness,MidfreqAug,Cutout,TranslateX,TranslateY,"
@@ -108,7 +108,8 @@ def magnitude_table(num_bins=11, image_size=(28, 28)):
             "TranslateX": (ls(0.0, 150.0 / 336.0 * image_size[1]), True),
             "TranslateY": (ls(0.0, 150.0 / 336.0 * image_size[0]), True), "Rotate90": (torch.tensor(1), True),
             "AutoSaturation": (z, False), "Grayscale": (z, False), "MidfreqAug": (ls(0.0, 0.9), True),
-            "ChromaDrop": (z, False)}
+            "ChromaDrop": (z, False), "Invert": (z, False), "Solarize": (ls(818, -818), False),
+            "FreqEnhance": (ls(0.0, 0.9), True)}
 
 
 class _FilterBank:
@@ -169,6 +170,10 @@ def encode_op(name, magnitude, aux, bank, grid=28):
             raise NotImplementedError("Rotate90 magnitude is +-1 in RandAugment_dct (custom_transforms.py:1086)")
     elif name == "ChromaDrop":
         a0 = int(bool(aux))
+    elif name == "Solarize":
+        a0 = math.floor(magnitude)                            # int DC > float threshold  <=>  DC > floor(threshold)
+    elif name == "FreqEnhance":
+        f = float(np.float32(1.0 + magnitude))
     elif name in ("MidfreqAug", "Sharpness"):
         assert -1 <= magnitude <= 1, "Intensity should be within the range of [-1, 1]"
         a0 = bank.index(name, magnitude)

@@ -201,3 +201,11 @@ def test_g13_mixup(golden):
     np.testing.assert_allclose(my.numpy(), g["my"], atol=1e-6)
     np.testing.assert_allclose(mc.numpy(), g["mc"], atol=1e-6)
     np.testing.assert_allclose(mt.numpy(), g["mt"], atol=1e-6)
+
+
+def test_g16_out_of_list_ops_invert_solarize_freqenhance(golden):
+    """Invert / Solarize / FreqEnhance through the reference's _apply_op_dct: bit exact."""
+    g = golden("g16_ops2.npz")
+    for k in range(int(g["ncases"])):
+        oy, oc = O.apply_op(g["Y"], g["C"], str(g[f"case{k}_name"]), float(g[f"case{k}_mag"]))
+        assert np.array_equal(oy, g[f"case{k}_Y"]) and np.array_equal(oc, g[f"case{k}_C"]), k
