@@ -158,6 +158,14 @@ int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* qu
                       const rgbnm_aug_params* params_host, const float* conv16, const float* filters, void* outY,
                       void* outC, int out_dtype, int B, int Hy, int Wy, int Hc, int Wc, int entry_clamp, int nops,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same pipeline for a `size` x `size` output block grid: 28 (ViT pipelines, get_transform('imagenet_dct')) or 32
+ * (SwinV2, 'imagenet_dct_swin', datasets.py:370-382; crop sides 16 / 32 / 64).  outY [B,1,size,size,8,8],
+ * outC [B,2,size/2,size/2,8,8]. */
+size_t rgbnm_dct_augment_workspace_ex(int B, int size);
+int rgbnm_dct_augment_ex(const int16_t* Yq, const int16_t* CbCrq, const int16_t* quant, const rgbnm_aug_params* params_dev,
+                         const rgbnm_aug_params* params_host, const float* conv16, const float* filters, void* outY,
+                         void* outC, int out_dtype, int size, int B, int Hy, int Wy, int Hc, int Wc, int entry_clamp,
+                         int nops, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Train-step tail

@@ -22,7 +22,7 @@ def _stale(target, deps):
 
 def build_lib(force=False, verbose=False):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "rgbnm.h"))
     objs = []
     jobs = []

@@ -186,15 +186,18 @@ class TrainTransform_DCT(torch.nn.Module):
     def __init__(self, size=28, scale=(0.05, 1.0), flip_p=0.5, num_ops=2, magnitude=3, num_magnitude_bins=11,
                  ops_list=None, out_dtype=torch.float32, eval_mode=False, size_resize=32):
         super().__init__()
-        if size != 28:
-            raise NotImplementedError("HIP augment path is built for the 28x28-block ViT pipelines (imagenet_dct)")
+        if size not in (28, 32):
+            raise NotImplementedError("HIP augment path covers 28x28-block (imagenet_dct) and 32x32-block "
+                                      "(imagenet_dct_swin) outputs")
         self.size, self.flip_p, self.num_ops, self.magnitude = size, flip_p, num_ops, magnitude
         self.num_magnitude_bins = num_magnitude_bins
         self.ops_list = list(VITTI_OPS if ops_list is None else ops_list)
         self.out_dtype = out_dtype
         self.eval_mode = eval_mode
         self.rrc = RandomResizedCrop_DCT(size, scale=scale, ratio=(1, 1))
-        self.rcc = ResizedCenterCrop_DCT(size_resize, size)
+        # eval box: ResizedCenterCrop_DCT(32, 28) for the ViT pipeline; Resize_DCT(32) of the whole grid for Swin
+        # (datasets.py:362-366, 378-382)
+        self.rcc = ResizedCenterCrop_DCT(size_resize, size) if size == 28 else None
         self.bank = _FilterBank()
         self._conv16 = None
         self._ws = None
@@ -208,7 +211,8 @@ class TrainTransform_DCT(torch.nn.Module):
         meta = magnitude_table(self.num_magnitude_bins, (self.size, self.size))
         for _ in range(B):
             if self.eval_mode:
-                out.append(dict(box=self.rcc.get_params(height, width), flip=False, ops=[]))
+                box = self.rcc.get_params(height, width) if self.rcc is not None else (0, 0, height, width)
+                out.append(dict(box=box, flip=False, ops=[]))
                 continue
             box = self.rrc.get_params(height, width)
             flip = not (torch.rand(1).item() > self.flip_p)
@@ -264,18 +268,20 @@ class TrainTransform_DCT(torch.nn.Module):
         if self._conv16 is None or self._conv16.device != dev:
             self._conv16 = dops.generate_conversion_matrix(8, 2).to(dev).contiguous()
         filt = self.bank.device_tensor(dev)
-        wsb = L.lib().rgbnm_dct_augment_workspace(B)
+        S = self.size
+        wsb = L.lib().rgbnm_dct_augment_workspace_ex(B, S)
         if self._ws is None or self._ws.numel() < wsb or self._ws.device != dev:
             self._ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-        oy = torch.empty(B, 1, 28, 28, 8, 8, device=dev, dtype=self.out_dtype)
-        oc = torch.empty(B, 2, 14, 14, 8, 8, device=dev, dtype=self.out_dtype)
-        rc = L.lib().rgbnm_dct_augment(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
-                                       C.cast(arr, C.c_void_p), self._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),
-                                       oc.data_ptr(), L.dt_of(self.out_dtype), B, Hy, Wy, Hc, Wc,
-                                       0 if self.eval_mode else 1, nops, self._ws.data_ptr(), self._ws.numel(), L.stream())
+        oy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=self.out_dtype)
+        oc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=self.out_dtype)
+        rc = L.lib().rgbnm_dct_augment_ex(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
+                                          C.cast(arr, C.c_void_p), self._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),
+                                          oc.data_ptr(), L.dt_of(self.out_dtype), S, B, Hy, Wy, Hc, Wc,
+                                          0 if self.eval_mode else 1, nops, self._ws.data_ptr(), self._ws.numel(),
+                                          L.stream())
         if rc == -1:
-            raise L.RgbnmError("dct_augment: invalid parameters (crop side must be 14/28/56 luma blocks with even "
-                               "offsets inside the coefficient grid: 512x512 inputs; see include/rgbnm.h)")
+            raise L.RgbnmError("dct_augment: invalid parameters (crop side must be size/2, size or 2*size luma blocks "
+                               "with even offsets inside the coefficient grid; see include/rgbnm.h)")
         L.check(rc, "dct_augment")
         return oy, oc
 
@@ -375,13 +381,15 @@ def apply_packed(transform, Yq, CbCrq, quant, packed, nops):
     if t._conv16 is None or t._conv16.device != dev:
         t._conv16 = dops.generate_conversion_matrix(8, 2).to(dev).contiguous()
     filt = t.bank.device_tensor(dev)
-    wsb = L.lib().rgbnm_dct_augment_workspace(B)
+    S = t.size
+    wsb = L.lib().rgbnm_dct_augment_workspace_ex(B, S)
     if t._ws is None or t._ws.numel() < wsb or t._ws.device != dev:
         t._ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-    oy = torch.empty(B, 1, 28, 28, 8, 8, device=dev, dtype=t.out_dtype)
-    oc = torch.empty(B, 2, 14, 14, 8, 8, device=dev, dtype=t.out_dtype)
-    L.check(L.lib().rgbnm_dct_augment(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(), host.ctypes.data,
-                                      t._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(), oc.data_ptr(),
-                                      L.dt_of(t.out_dtype), B, Hy, Wy, Hc, Wc, 0 if t.eval_mode else 1, nops,
-                                      t._ws.data_ptr(), t._ws.numel(), L.stream()), "dct_augment")
+    oy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=t.out_dtype)
+    oc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=t.out_dtype)
+    L.check(L.lib().rgbnm_dct_augment_ex(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
+                                         host.ctypes.data, t._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),
+                                         oc.data_ptr(), L.dt_of(t.out_dtype), S, B, Hy, Wy, Hc, Wc,
+                                         0 if t.eval_mode else 1, nops, t._ws.data_ptr(), t._ws.numel(), L.stream()),
+            "dct_augment")
     return oy, oc

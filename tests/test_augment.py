@@ -34,18 +34,18 @@ def synth(B, Hy=64, Wy=64, seed=0, gray=False):
     return Y, Cc, quant
 
 
-def run_hip(Y, Cc, quant, params, eval_mode=False, out_dtype=torch.float32):
-    t = CT.TrainTransform_DCT(eval_mode=eval_mode, out_dtype=out_dtype)
+def run_hip(Y, Cc, quant, params, eval_mode=False, out_dtype=torch.float32, size=28):
+    t = CT.TrainTransform_DCT(size=size, eval_mode=eval_mode, out_dtype=out_dtype)
     oy, oc = t(torch.from_numpy(Y).to(DEV), None if Cc is None else torch.from_numpy(Cc).to(DEV),
                torch.from_numpy(quant).to(DEV), params=params)
     torch.cuda.synchronize()
     return oy.float().cpu().numpy(), oc.float().cpu().numpy()
 
 
-def run_oracle(Y, Cc, quant, params):
+def run_oracle(Y, Cc, quant, params, size=28):
     ys, cs = [], []
     for b, p in enumerate(params):
-        oy, oc = O.train_transform(Y[b], None if Cc is None else Cc[b], quant[b], p["box"], p["flip"], p["ops"])
+        oy, oc = O.train_transform(Y[b], None if Cc is None else Cc[b], quant[b], p["box"], p["flip"], p["ops"], size)
         ys.append(oy)
         cs.append(oc)
     return np.stack(ys), np.stack(cs)
@@ -171,3 +171,43 @@ def test_invalid_crop_is_rejected():
         run_hip(Y, Cc, quant, [dict(box=(0, 0, 42, 42), flip=False, ops=[])])
     with pytest.raises(rg.lib.RgbnmError):
         run_hip(Y, Cc, quant, [dict(box=(40, 40, 56, 56), flip=False, ops=[])])
+
+
+def test_swin_pipeline_32_block_grid_every_op_and_resize_cases():
+    """get_transform('imagenet_dct_swin') (datasets.py:370-382): the same kernels instantiated for a 32 x 32 output grid
+    (image kept in L2 instead of LDS).  Identity-resize crops: every op bit exact; crop 16 (x2) / 64 (/2): <= 1 LSB;
+    eval = Resize_DCT(32) of the whole 64 x 64 grid."""
+    B = len(ALL_OPS)
+    Y, Cc, quant = synth(B, 44, 52, seed=7)
+    params = []
+    for b, op in enumerate(ALL_OPS):
+        second = ALL_OPS[(b * 5 + 1) % len(ALL_OPS)]
+        params.append(dict(box=(2 * (b % 6), 2 * (b % 10), 32, 32), flip=bool(b & 1), ops=[op, second]))
+    hy, hc = run_hip(Y, Cc, quant, params, size=32)
+    assert hy.shape[1:] == (1, 32, 32, 8, 8) and hc.shape[1:] == (2, 16, 16, 8, 8)
+    ry, rc = run_oracle(Y, Cc, quant, params, size=32)
+    for b in range(B):
+        assert np.array_equal(hy[b], ry[b]), (b, params[b]["ops"], np.abs(hy[b] - ry[b]).max())
+        assert np.array_equal(hc[b], rc[b]), (b, params[b]["ops"], np.abs(hc[b] - rc[b]).max())
+    lsb = 2.0 / 2040.0
+    Y2, C2, q2 = synth(4, 64, 64, seed=8)
+    for side in (16, 64):
+        pr = [dict(box=(2 * b, 6 - 2 * b, side, side) if side == 16 else (0, 0, 64, 64), flip=bool(b & 1),
+                   ops=[("Identity", 0.0, None)]) for b in range(4)]
+        h2, c2 = run_hip(Y2, C2, q2, pr, size=32)
+        r2, rc2 = run_oracle(Y2, C2, q2, pr, size=32)
+        for h, r in ((h2, r2), (c2, rc2)):
+            d = np.abs(h - r) / lsb
+            assert d.max() <= 1.0 + 1e-3 and (d > 0.5).mean() < 0.06, (side, d.max())
+    t = CT.TrainTransform_DCT(size=32, eval_mode=True)
+    pe = t.sample_params(4, 64, 64)
+    assert pe[0]["box"] == (0, 0, 64, 64) and pe[0]["ops"] == []
+    he, ce = run_hip(Y2, C2, q2, pe, eval_mode=True, size=32)
+    for b in range(4):
+        Yd, Cd = O.dequantize(Y2[b], C2[b], q2[b])
+        ref = O.to_range(O.resize(Yd, 32))
+        assert np.abs(he[b] - ref).max() <= lsb * 1.001
+    # the reference crop-side distribution for size 32 on 64 x 64 grids: {16, 32, 64} (SURVEY 8a a3)
+    tt = CT.TrainTransform_DCT(size=32)
+    sides = {p["box"][3] for p in tt.sample_params(400, 64, 64)}
+    assert sides <= {16, 32, 64} and len(sides) == 3
