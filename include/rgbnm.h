@@ -138,6 +138,7 @@ int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void*
 #define RGBNM_OP_INVERT 16         /* invert_dct: all coefficients * -1     (dct_ops.py:623-629)  */
 #define RGBNM_OP_SOLARIZE 17       /* iarg0 = floor(threshold): blocks with luma DC > threshold negated (:631-651) */
 #define RGBNM_OP_FREQENHANCE 18    /* fmag = factor: AC coefficients * factor, rounded (:1015-1035) */
+#define RGBNM_OP_EQUALIZE 19       /* equalize_dct: histogram equalisation of the luma DCs (:916-955) */
 
 typedef struct rgbnm_aug_params {
   int crop_i, crop_j, crop_h, crop_w; /* luma blocks; chroma box = luma box / 2 (custom_transforms.py:647-652) */

@@ -303,6 +303,25 @@ def magnitude_table(num_bins=11, image_size=(28, 28)):
     }
 
 
+def equalize(coeff):
+    """dct_ops.py:916-955 (CPU branch: bincount over the 2041 shifted DC values): per channel
+    new = round((cdf[dc] - cdf_min) / (N - cdf_min) * 2039) + CMIN, division and product in fp32, round half to even.
+    cdf_min = number of blocks holding the smallest DC.  All-equal DCs divide by zero in the reference (undefined
+    int16 cast); here they are left unchanged."""
+    out = coeff.copy()
+    for c in range(coeff.shape[0]):
+        dc = coeff[c, :, :, 0, 0].astype(np.int64) - CMIN
+        hist = np.bincount(dc.reshape(-1), minlength=CMAX - CMIN + 1)
+        nz = hist[hist != 0]
+        denom = nz[1:].sum()
+        if denom == 0:
+            continue
+        cdf = np.cumsum(hist)
+        eq = np.rint((cdf - nz[0]).astype(np.float32) / np.float32(denom) * np.float32(CMAX - CMIN - 1))
+        out[c, :, :, 0, 0] = (eq[dc] + CMIN).astype(coeff.dtype)
+    return out
+
+
 def apply_op(Y, C, op_name, magnitude, aux=None):
     """custom_transforms.py:944-1021 (_apply_op_dct) for the ops on the north-star path; random draws
     of the reference (Cutout centre, ChromaDrop coin) are passed explicitly via `aux`.
@@ -351,6 +370,8 @@ def apply_op(Y, C, op_name, magnitude, aux=None):
     elif op_name == "ChromaDrop":
         drop_cb = bool(aux)
         C[0 if drop_cb else 1] *= 0
+    elif op_name == "Equalize":                        # dct_ops.py:916-955: histogram equalisation of the luma DCs
+        Y = equalize(Y)
     elif op_name == "Invert":                          # dct_ops.py:623-629 (zero-centred coefficients: * -1)
         Y, C = Y * -1, C * -1
     elif op_name == "Solarize":                        # dct_ops.py:631-651, custom_transforms.py:981-983

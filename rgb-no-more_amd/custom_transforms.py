@@ -22,7 +22,7 @@ from . import lib as L
 
 OPS = {"Identity": 0, "AutoContrast": 1, "Posterize": 2, "SolarizeAdd": 3, "Color": 4, "Contrast": 5, "Brightness": 6,
        "MidfreqAug": 7, "Cutout": 8, "TranslateX": 9, "TranslateY": 10, "Rotate90": 11, "AutoSaturation": 12,
-       "Grayscale": 13, "ChromaDrop": 14, "Sharpness": 15, "Invert": 16, "Solarize": 17, "FreqEnhance": 18}
+       "Grayscale": 13, "ChromaDrop": 14, "Sharpness": 15, "Invert": 16, "Solarize": 17, "FreqEnhance": 18, "Equalize": 19}
 CHROMA_OPS = {"Grayscale", "Color", "AutoSaturation", "ChromaDrop"}
 # default vitti list (utils/configs.py:93)
 VITTI_OPS = ("AutoContrast,Posterize,SolarizeAdd,Color,Contrast,Brightness,MidfreqAug,Cutout,TranslateX,TranslateY,"
@@ -108,7 +108,7 @@ def magnitude_table(num_bins=11, image_size=(28, 28)):
             "TranslateX": (ls(0.0, 150.0 / 336.0 * image_size[1]), True),
             "TranslateY": (ls(0.0, 150.0 / 336.0 * image_size[0]), True), "Rotate90": (torch.tensor(1), True),
             "AutoSaturation": (z, False), "Grayscale": (z, False), "MidfreqAug": (ls(0.0, 0.9), True),
-            "ChromaDrop": (z, False), "Invert": (z, False), "Solarize": (ls(818, -818), False),
+            "ChromaDrop": (z, False), "Invert": (z, False), "Equalize": (z, False), "Solarize": (ls(818, -818), False),
             "FreqEnhance": (ls(0.0, 0.9), True)}
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""G16: the out-of-list RandAugment ops Invert / Solarize / FreqEnhance through the reference's own dispatcher
+"""G16: the out-of-list RandAugment ops Invert / Solarize / FreqEnhance / Equalize through the reference's own dispatcher
 (utils/custom_transforms.py:_apply_op_dct, with its per-op clamp) on seeded int16 coefficients.  Survey container only."""
 import os
 import sys
@@ -24,7 +24,7 @@ def main():
     Y[0, 3, 4] = -1024                                   # inverting -1024 overflows the clamp range: 1024 -> 1016
     out = {"Y": Y, "C": C}
     cases = [("Invert", 0.0), ("Solarize", 327.2), ("Solarize", -163.6), ("Solarize", 818.0), ("FreqEnhance", 0.27),
-             ("FreqEnhance", -0.27), ("FreqEnhance", 0.9)]
+             ("FreqEnhance", -0.27), ("FreqEnhance", 0.9), ("Equalize", 0.0)]
     for k, (name, mag) in enumerate(cases):
         oy, oc = ctrans._apply_op_dct([torch.from_numpy(Y.copy()), torch.from_numpy(C.copy())], name, mag, None,
                                       [None, None], [None, None])

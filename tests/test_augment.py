@@ -59,7 +59,7 @@ ALL_OPS = [("Identity", 0.0, None), ("AutoContrast", 0.0, None), ("Posterize", 2
            ("TranslateY", -3.75, None), ("Rotate90", 1.0, None), ("Rotate90", -1.0, None), ("AutoSaturation", 0.0, None),
            ("Grayscale", 0.0, None), ("ChromaDrop", 0.0, True), ("ChromaDrop", 0.0, False), ("Sharpness", 0.27, None),
            ("Sharpness", -0.27, None), ("Invert", 0.0, None), ("Solarize", 327.2, None), ("Solarize", -163.6, None),
-           ("FreqEnhance", 0.27, None), ("FreqEnhance", -0.27, None)]
+           ("FreqEnhance", 0.27, None), ("FreqEnhance", -0.27, None), ("Equalize", 0.0, None)]
 
 
 def test_every_op_bit_exact_on_identity_resize():

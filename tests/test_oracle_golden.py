@@ -204,7 +204,7 @@ def test_g13_mixup(golden):
 
 
 def test_g16_out_of_list_ops_invert_solarize_freqenhance(golden):
-    """Invert / Solarize / FreqEnhance through the reference's _apply_op_dct: bit exact."""
+    """Invert / Solarize / FreqEnhance / Equalize through the reference's _apply_op_dct: bit exact."""
     g = golden("g16_ops2.npz")
     for k in range(int(g["ncases"])):
         oy, oc = O.apply_op(g["Y"], g["C"], str(g[f"case{k}_name"]), float(g[f"case{k}_mag"]))
