@@ -19,6 +19,7 @@ from torch import nn
 
 from . import dct_ops as dops
 from . import lib as L
+from .flatparams import FlatParamModule, align
 
 WS = 8
 
@@ -58,23 +59,23 @@ def _gemm_tn(dY, X, want_bias):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b  (x [M,K] in the compute dtype, W fp32 master [N,K], b fp32 or None)."""
+    """y = x W^T + b  (x [M,K] in the compute dtype, W fp32 master [N,K], b fp32 or None).  sh = (W, W^T) in the
+    compute dtype from the per-step shadow buffer (rgbnm_prep_weights): no per-layer cast / transpose kernels."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
-        Wc = W.detach().to(x.dtype).contiguous()
-        y, _ = _gemm_nt(L.EPI_NONE, x, Wc, None if b is None else b.detach().float().contiguous())
-        ctx.save_for_backward(x, Wc)
-        ctx.has_b = b is not None
+    def forward(ctx, x, W, b, sh):
+        y, _ = _gemm_nt(L.EPI_NONE, x, sh[0], None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(x)
+        ctx.sh, ctx.has_b = sh, b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, Wc = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
         dy = dy.contiguous()
         dW, db = _gemm_tn(dy, x, ctx.has_b)
-        dx, _ = _gemm_nt(L.EPI_NONE, dy, Wc.t().contiguous())
-        return dx, dW, db
+        dx, _ = _gemm_nt(L.EPI_NONE, dy, ctx.sh[1])
+        return dx, dW, db, None
 
 
 class _MlpFn(torch.autograd.Function):
@@ -82,22 +83,22 @@ class _MlpFn(torch.autograd.Function):
     fused into fc2's dX GEMM (swinv2.py:19-35)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2):
-        W1c, W2c = W1.detach().to(x.dtype).contiguous(), W2.detach().to(x.dtype).contiguous()
-        g, gp = _gemm_nt(L.EPI_GELU, x, W1c, b1.detach().float().contiguous(), want_c2=True)
-        y, _ = _gemm_nt(L.EPI_NONE, g, W2c, b2.detach().float().contiguous())
-        ctx.save_for_backward(x, W1c, W2c, g, gp)
+    def forward(ctx, x, W1, b1, W2, b2, sh1, sh2):
+        g, gp = _gemm_nt(L.EPI_GELU, x, sh1[0], b1.detach().float().contiguous(), want_c2=True)
+        y, _ = _gemm_nt(L.EPI_NONE, g, sh2[0], b2.detach().float().contiguous())
+        ctx.save_for_backward(x, g, gp)
+        ctx.sh1, ctx.sh2 = sh1, sh2
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W1c, W2c, g, gp = ctx.saved_tensors
+        x, g, gp = ctx.saved_tensors
         dy = dy.contiguous()
         dW2, db2 = _gemm_tn(dy, g, True)
-        du, _ = _gemm_nt(L.EPI_DGELU, dy, W2c.t().contiguous(), None, R=gp)
+        du, _ = _gemm_nt(L.EPI_DGELU, dy, ctx.sh2[1], None, R=gp)
         dW1, db1 = _gemm_tn(du, x, True)
-        dx, _ = _gemm_nt(L.EPI_NONE, du, W1c.t().contiguous())
-        return dx, dW1, db1, dW2, db2
+        dx, _ = _gemm_nt(L.EPI_NONE, du, ctx.sh1[1])
+        return dx, dW1, db1, dW2, db2, None, None
 
 
 class _LNFn(torch.autograd.Function):
@@ -280,16 +281,17 @@ class SwinTransformerBlock(nn.Module):
         keep = 1.0 - self.drop_path_p                   # timm DropPath: per-sample Bernoulli(keep) / keep
         return (torch.rand(B, device=dev) < keep).float() / keep
 
-    def run(self, x, B):
+    def run(self, x, B, sh, pre):
         res, C_ = self.input_resolution[0], self.dim
         a = self.attn
         bias, scale = a.bias_and_scale()
         qb = torch.cat((a.q_bias, torch.zeros_like(a.v_bias, requires_grad=False), a.v_bias))
-        qkv = _LinearFn.apply(x, a.qkv.weight, qb)
+        qkv = _LinearFn.apply(x, a.qkv.weight, qb, sh[pre + "attn.qkv"])
         o = _WinAttnFn.apply(qkv, bias, scale, B, res, C_, self.num_heads, self.shift_size)
-        o = _LinearFn.apply(o, a.proj.weight, a.proj.bias)
+        o = _LinearFn.apply(o, a.proj.weight, a.proj.bias, sh[pre + "attn.proj"])
         x = _LNFn.apply(o, self.norm1.weight, self.norm1.bias, x, self._drop_scale(B, x.device), res * res)
-        h = _MlpFn.apply(x, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias)
+        h = _MlpFn.apply(x, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
+                         sh[pre + "mlp.fc1"], sh[pre + "mlp.fc2"])
         return _LNFn.apply(h, self.norm2.weight, self.norm2.bias, x, self._drop_scale(B, x.device), res * res)
 
 
@@ -300,9 +302,9 @@ class PatchMerging(nn.Module):
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False, **kw)
         self.norm = nn.LayerNorm(2 * dim, **kw)
 
-    def run(self, x, B):
+    def run(self, x, B, sh, pre):
         m = _MergeFn.apply(x, B, self.input_resolution[0], self.dim)
-        m = _LinearFn.apply(m, self.reduction.weight, None)
+        m = _LinearFn.apply(m, self.reduction.weight, None, sh[pre + "reduction"])
         return _LNFn.apply(m, self.norm.weight, self.norm.bias, None, None, 1)
 
 
@@ -326,7 +328,7 @@ class PatchEmbedding_DCT_Group(nn.Module):
         self.conv_C = dops.generate_conversion_matrix(2, 4, scale=True, dtype=torch.float32)
 
 
-class SwinTransformerV2(nn.Module):
+class SwinTransformerV2(FlatParamModule):
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=(2, 2, 6, 2),
                  num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True, use_checkpoint=False,
@@ -404,15 +406,50 @@ class SwinTransformerV2(nn.Module):
         L.check(L.lib().rgbnm_swin_embed(L.dt_of(y.dtype), L.dt_of(cdt), y.data_ptr(), cbcr.data_ptr(),
                                          self._conv[0].data_ptr(), self._conv[1].data_ptr(), feat.data_ptr(), B, Hb, Wb,
                                          L.stream()), "swin_embed")
+        sh = self._prep(cdt)
         pe = self.patch_embed
-        x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias)
+        x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias, sh["patch_embed.projection.0"])
         x = _LNFn.apply(x, pe.norm.weight, pe.norm.bias, None, None, 1)
-        for ly in self.layers:
-            for blk in ly.blocks:
-                x = blk.run(x, B)
+        for li, ly in enumerate(self.layers):
+            for bi, blk in enumerate(ly.blocks):
+                x = blk.run(x, B, sh, f"layers.{li}.blocks.{bi}.")
             if ly.downsample is not None:
-                x = ly.downsample.run(x, B)
+                x = ly.downsample.run(x, B, sh, f"layers.{li}.downsample.")
                 res //= 2
         x = _LNFn.apply(x, self.norm.weight, self.norm.bias, None, None, 1)
         x = _MeanFn.apply(x, B, res * res, self.num_features)
-        return _LinearFn.apply(x, self.head.weight, self.head.bias)
+        return _LinearFn.apply(x, self.head.weight, self.head.bias, sh["head"])
+
+    # ---------------------------------------------------------------- flat masters + per-step operand shadows
+    def _flatten(self):
+        """Pack every parameter into one fp32 buffer and describe the Linear layers for rgbnm_prep_weights: one launch
+        per forward writes W and W^T of all 53 Linears in the compute dtype (instead of ~220 cast / transpose kernels)."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise L.RgbnmError("model parameters must live on a HIP device (no CPU fallback)")
+        self._pack_parameters()
+        lin = [n[:-len(".weight")] for n, p in self.named_parameters()
+               if n.endswith(".weight") and p.dim() == 2 and "cpb_mlp" not in n]
+        descs = (L.LinearDesc * len(lin))()
+        self._sh_off, so = {}, 0
+        for k, name in enumerate(lin):
+            Nn, Kk = self._shapes[name + ".weight"]
+            ws, wst = so, so + align(Nn * Kk)
+            so = wst + align(Nn * Kk)
+            descs[k] = L.LinearDesc(self._offs[name + ".weight"], 0, ws, wst, 0, Nn, Kk, 0, 0)
+            self._sh_off[name] = (ws, wst, Nn, Kk)
+        self._ndesc, self._sh_total = len(lin), so
+        self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        self._shadow, self._sh_views = {}, {}
+
+    def _prep(self, cdtype):
+        self._ensure_flat()
+        if cdtype not in self._shadow:
+            buf = torch.zeros(self._sh_total, device=self._flat.device, dtype=cdtype)
+            self._shadow[cdtype] = buf
+            self._sh_views[cdtype] = {n: (buf[ws:ws + Nn * Kk].view(Nn, Kk), buf[wst:wst + Nn * Kk].view(Kk, Nn))
+                                      for n, (ws, wst, Nn, Kk) in self._sh_off.items()}
+        L.check(L.lib().rgbnm_prep_weights(L.dt_of(cdtype), self._descs_dev.data_ptr(), self._ndesc,
+                                           self._flat.data_ptr(), self._shadow[cdtype].data_ptr(), None, L.stream()),
+                "prep_weights")
+        return self._sh_views[cdtype]
