@@ -561,17 +561,35 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
 // prep_weights: per Linear, fp32 master W[N,K] -> shadow Ws[N,K] (T) and WsT[K,N] (T); rows of qkv are
 // de-interleaved so that q|k|v come out as contiguous [heads*64] column blocks of the GEMM output.
 // ------------------------------------------------------------------------------------------------
+// 32 x 32 tiles through LDS so that BOTH shadows are written with coalesced rows (the transposed one was a stride-N
+// scatter before: 57 us per step for JPEG-Ti, 460 us for SwinV2-T's 28 M parameters).
 template <typename T>
-__global__ void prep_weights_kernel(const rgbnm_linear_desc* __restrict__ descs, const float* __restrict__ master,
-                                    T* __restrict__ shadow) {
+__global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_desc* __restrict__ descs,
+                                                           const float* __restrict__ master, T* __restrict__ shadow) {
+  __shared__ float tile[32][33];
   const rgbnm_linear_desc d = descs[blockIdx.y];
-  const long long n = (long long)d.N * d.K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(i / d.K), c = (int)(i % d.K);   // r = shadow (GEMM) row
-    const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
-    const T v = from_f32<T>(master[d.w_off + (size_t)src * d.K + c] + ((d.add_identity && r == c) ? 1.0f : 0.0f));
-    shadow[d.ws_off + i] = v;
-    shadow[d.wst_off + (size_t)c * d.N + r] = v;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
+  const int tr = (d.N + 31) / 32, tc = (d.K + 31) / 32;
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + ty + 8 * k, c = c0 + tx;               // r = shadow (GEMM) row
+      float v = 0.f;
+      if (r < d.N && c < d.K) {
+        const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
+        v = master[d.w_off + (size_t)src * d.K + c] + ((d.add_identity && r == c) ? 1.0f : 0.0f);
+        shadow[d.ws_off + (size_t)r * d.K + c] = from_f32<T>(v);
+      }
+      tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + 8 * k, r = r0 + tx;
+      if (r < d.N && c < d.K) shadow[d.wst_off + (size_t)c * d.N + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+    }
+    __syncthreads();
   }
 }
 
@@ -632,9 +650,9 @@ int rgbnm_prep_weights(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc,
   if (!descs_dev || !master || !shadow || ndesc <= 0) return RGBNM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((prep_weights_kernel<bf16>), dim3(96, ndesc), dim3(256), 0, st, descs_dev, master, (bf16*)shadow);
+    hipLaunchKernelGGL((prep_weights_kernel<bf16>), dim3(64, ndesc), dim3(256), 0, st, descs_dev, master, (bf16*)shadow);
   else if (dtype == DT_F32)
-    hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(96, ndesc), dim3(256), 0, st, descs_dev, master, (float*)shadow);
+    hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(64, ndesc), dim3(256), 0, st, descs_dev, master, (float*)shadow);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
   if (bias_perm) {
