@@ -314,6 +314,14 @@ int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int
 /* mean over tokens [B,N,C] -> [B,C] (backward != 0: [B,C] -> [B,N,C], dy / N). */
 int rgbnm_token_mean(int dtype, const void* in, void* out, int B, int N, int C, int backward, void* stream);
 
+
+/* ---- calibration micro-kernels (measurement only, SURVEY.md section 8d: attainable peaks on the box) ----------------
+ * rgbnm_calib_mfma_bf16: `workgroups` x 4 waves each issue iters x 4 independent 32x32x16 bf16 MFMAs (32768 flop each),
+ * no memory traffic.  rgbnm_calib_stream: 16 B per lane grid-stride; mode 0 copy, 1 read-only, 2 write-only.
+ * `sink` is a 4-byte device word that is never actually written. */
+int rgbnm_calib_mfma_bf16(int workgroups, int iters, float* sink, void* stream);
+int rgbnm_calib_stream(const void* src, void* dst, size_t bytes, int mode, int workgroups, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

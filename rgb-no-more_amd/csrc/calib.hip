@@ -1,0 +1,60 @@
+// Calibration micro-kernels: the attainable MFMA and HBM peaks on the box the bench runs on (SURVEY.md §8d asks for the
+// measured figures next to the nominal ones).  They are not on the product path; tools/calib.py times them with HIP events.
+#include "common.h"
+#include "../../include/rgbnm.h"
+
+namespace rgbnm {
+
+// Every wave issues `iters` rounds of 4 independent 32x32x16 bf16 MFMAs (no memory traffic at all).
+__global__ __launch_bounds__(256) void calib_mfma_kernel(int iters, float* sink) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) {
+        a[i] = (__bf16)(float)(threadIdx.x & 7);
+        b[i] = (__bf16)(float)((threadIdx.x >> 3) & 7);
+    }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    if (s == 12345.678f) sink[0] = s;          // keeps the chain live; never true
+}
+
+// mode 0: dst = src; mode 1: read only (sum into sink); mode 2: write only.  16 B per lane, grid-stride.
+__global__ __launch_bounds__(256) void calib_stream_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                                           int mode, unsigned* sink) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    unsigned acc = 0;
+    if (mode == 0)
+        for (; i < n16; i += step) dst[i] = src[i];
+    else if (mode == 1) {
+        for (; i < n16; i += step) { uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+        if (acc == 0x9e3779b9u) sink[0] = acc;
+    } else {
+        uint4 v = {1u, 2u, 3u, 4u};
+        for (; i < n16; i += step) dst[i] = v;
+    }
+}
+
+}  // namespace rgbnm
+
+extern "C" int rgbnm_calib_mfma_bf16(int workgroups, int iters, float* sink, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (workgroups <= 0 || iters <= 0 || !sink) return RGBNM_EINVAL;
+    hipLaunchKernelGGL(rgbnm::calib_mfma_kernel, dim3(workgroups), dim3(256), 0, stream, iters, sink);
+    return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
+}
+
+extern "C" int rgbnm_calib_stream(const void* src, void* dst, size_t bytes, int mode, int workgroups, void* sink,
+                                  void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (bytes % 16 || workgroups <= 0 || mode < 0 || mode > 2 || !sink) return RGBNM_EINVAL;
+    if ((mode != 2 && !src) || (mode != 1 && !dst)) return RGBNM_EINVAL;
+    hipLaunchKernelGGL(rgbnm::calib_stream_kernel, dim3(workgroups), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst,
+                       bytes / 16, mode, (unsigned*)sink);
+    return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
+}
