@@ -514,6 +514,38 @@ int submit_tn_reduce(const GemmTN& p, float* dW, float* db, int S, int perm_head
   return rgbnm_reduce_submit(j, st);
 }
 
+// deferred (grouped) weight-gradient launches
+struct TnPending { GemmTN p; float* dW; float* db; int perm_heads, accumulate; };
+bool g_tn_defer = false;
+TnPending g_tn_q[4];
+int g_tn_n = 0;
+
+int tn_flush(hipStream_t st) {
+  const int n = g_tn_n;
+  g_tn_n = 0;
+  if (!n) return RGBNM_OK;
+  RgbnmTnJob jobs[4];
+  for (int i = 0; i < n; ++i) {
+    const GemmTN& p = g_tn_q[i].p;
+    jobs[i].dY = p.dY; jobs[i].X = p.X; jobs[i].part = p.part; jobs[i].bpart = g_tn_q[i].db ? p.bpart : nullptr;
+    jobs[i].ldy = p.ldy; jobs[i].ldx = p.ldx; jobs[i].M = p.M; jobs[i].No = p.No; jobs[i].Ki = p.Ki;
+  }
+  int S = 0;
+  const int rc = rgbnm_launch_tn_pipe_group(jobs, n, &S, st);
+  if (rc != RGBNM_OK) return rc < 0 ? rc : RGBNM_EINVAL;     // eligibility was checked when the jobs were queued
+  for (int i = 0; i < n; ++i) {
+    const int rr = submit_tn_reduce(g_tn_q[i].p, g_tn_q[i].dW, g_tn_q[i].db, S, g_tn_q[i].perm_heads,
+                                    g_tn_q[i].accumulate, st);
+    if (rr != RGBNM_OK) return rr;
+  }
+  return RGBNM_OK;
+}
+
+bool tn_groupable(const GemmTN& p) {
+  return rgbnm_get_option("tn_pipe") && !rgbnm_get_option("tn_square") && p.M % 64 == 0 && p.M >= 64 &&
+         p.Ki % 192 == 0 && p.No % 8 == 0 && p.ldy % 8 == 0 && p.ldx % 8 == 0;
+}
+
 template <typename T>
 int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hipStream_t st) {
   const int epv = 16 / (int)sizeof(T);
@@ -524,6 +556,11 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   p.ctiles = nb3 ? p.Ki / 192 : cdiv(p.Ki, 128);
   const int tiles = p.rtiles * p.ctiles;
   if constexpr (sizeof(T) == 2) {
+    if (g_tn_defer && tn_groupable(p)) {
+      if (g_tn_n && g_tn_q[0].p.M != p.M) { const int rf = tn_flush(st); if (rf != RGBNM_OK) return rf; }
+      g_tn_q[g_tn_n++] = TnPending{p, dW, db, perm_heads, accumulate};
+      return g_tn_n == 4 ? tn_flush(st) : RGBNM_OK;
+    }
     if (rgbnm_get_option("tn_pipe")) {
       int Sp = 0;
       const int rc = rgbnm_launch_tn_pipe(p.dY, p.ldy, p.X, p.ldx, p.part, db ? p.bpart : nullptr, p.M, p.No, p.Ki,
@@ -602,6 +639,12 @@ __global__ void gather_bias_kernel(const rgbnm_linear_desc* __restrict__ descs, 
 }
 
 }  // namespace
+
+void rgbnm_tn_defer_begin() { g_tn_defer = true; }
+int rgbnm_tn_defer_flush(hipStream_t st) {
+  g_tn_defer = false;
+  return tn_flush(st);
+}
 
 // ================================================================================================
 // C ABI

@@ -34,6 +34,16 @@ struct TnPipe {
   int ldy, ldx, M, No, Ki, S, kt_per_split, rtiles, ctiles;
 };
 
+// Up to 4 weight-gradient GEMMs over the same token axis share one launch: with T tiles in total every job is split
+// S = 256 / T ways, so the fp32 partials (S x No x Ki per job: the traffic that bounds these kernels next to the operand
+// reads) shrink with the number of jobs grouped, and the write burst at the end of the launch happens once.
+constexpr int TN_MAXJOBS = 4;
+struct TnGroup {
+  TnPipe j[TN_MAXJOBS];
+  int tile_end[TN_MAXJOBS];       // running sum of rtiles * ctiles
+  int njobs, S, tiles;
+};
+
 __device__ __forceinline__ bf16x8 pack8(u32x2 lo, u32x2 hi) {
   u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(bf16x8, v);
@@ -65,12 +75,20 @@ __device__ __forceinline__ void tr_chunk(unsigned aA, unsigned aB0, unsigned aB1
   fb[2].v = pack8(b2l, b2h);
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnPipe p) {
+__global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int ntile = p.rtiles * p.ctiles;
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int tile = jj % ntile, s = (jj / ntile) * 8 + xcd;
-  if (s >= p.S) return;
+  // 256 workgroups, block b runs on XCD b % 8: unit u = (b % 8) * 32 + b / 8 keeps consecutive units -- the tiles of one
+  // token range s, which read the same operand rows -- on one XCD's L2
+  const int u = (blockIdx.x & 7) * 32 + (blockIdx.x >> 3);
+  if (u >= grp.S * grp.tiles) return;
+  const int s = u / grp.tiles;
+  int tile = u % grp.tiles, job = 0;
+  while (tile >= grp.tile_end[job]) ++job;
+  if (job) tile -= grp.tile_end[job - 1];
+  TnPipe p = grp.j[0];             // uniform selects (no dynamic indexing of the kernel argument)
+  if (job == 1) p = grp.j[1];
+  if (job == 2) p = grp.j[2];
+  if (job == 3) p = grp.j[3];
   const int rt = tile / p.ctiles, ct = tile % p.ctiles;
   const int r0 = rt * 128, c0 = ct * 192;
   const int kt0 = s * p.kt_per_split;
@@ -342,25 +360,72 @@ __global__ __launch_bounds__(384) void gemm_tn_pipe_q_kernel(TnPipe p) {
 
 }  // namespace
 
-int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
-                         int Ki, int* S_out, hipStream_t st) {
+namespace {
+
+int tn_fill(TnPipe& p, const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No, int Ki,
+            bool square) {
   if (M % TK || Ki % 192 || No % 8 || ldy % 8 || ldx % 8 || M < TK) return 1;
+  p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.part = part; p.bpart = bpart;
+  p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki;
+  p.rtiles = cdiv(No, square ? 192 : 128);
+  p.ctiles = Ki / 192;
+  return 0;
+}
+
+}  // namespace
+
+// jobs[0..n): same M; returns 1 when a job is not eligible (nothing launched), S (common split count) through S_out
+int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st) {
+  if (n < 1 || n > TN_MAXJOBS) return RGBNM_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_tn_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return RGBNM_ELAUNCH;
     attr_set = true;
   }
-  TnPipe p;
-  p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.part = part; p.bpart = bpart;
-  p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki;
+  TnGroup g;
+  int tiles = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const RgbnmTnJob& j = jobs[i];
+    if (j.M != jobs[0].M) return 1;
+    if (tn_fill(g.j[i], j.dY, j.ldy, j.X, j.ldx, j.part, j.bpart, j.M, j.No, j.Ki, false)) return 1;
+    tiles += g.j[i].rtiles * g.j[i].ctiles;
+    g.tile_end[i] = tiles;
+    flops += 2.0 * j.M * (double)j.No * j.Ki;
+    bytes += ((double)j.M * j.No + (double)j.M * j.Ki) * 2.0 + (double)j.No * j.Ki * 4.0;
+  }
+  for (int i = n; i < TN_MAXJOBS; ++i) { g.j[i] = g.j[0]; g.tile_end[i] = tiles; }
+  if (tiles > 256) return 1;
+  const int ktiles = jobs[0].M / TK;
+  // one workgroup per CU (120 KB LDS) and at most 256 of them: a 257th would wait for a whole first round
+  int S = 256 / tiles;
+  if (S > RGBNM_TN_MAX_SPLIT) S = RGBNM_TN_MAX_SPLIT;
+  if (S > ktiles) S = ktiles;
+  const int kt_per = cdiv(ktiles, S);
+  S = cdiv(ktiles, kt_per);
+  for (int i = 0; i < TN_MAXJOBS; ++i) { g.j[i].S = S; g.j[i].kt_per_split = kt_per; }
+  g.njobs = n; g.S = S; g.tiles = tiles;
+  *S_out = S;
+  const int slot = rgbnm_trace_begin(TR_TN, flops, bytes, st);
+  hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(256), dim3(512), SMEM, st, g);
+  rgbnm_trace_end(slot, st);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
+                         int Ki, int* S_out, hipStream_t st) {
   const bool square = rgbnm_get_option("tn_square") && cdiv(No, 192) * (Ki / 192) >= 3;
-  p.rtiles = cdiv(No, square ? 192 : 128);
-  p.ctiles = Ki / 192;
+  if (!square) {
+    RgbnmTnJob j;
+    j.dY = dY; j.X = X; j.part = part; j.bpart = bpart; j.ldy = ldy; j.ldx = ldx; j.M = M; j.No = No; j.Ki = Ki;
+    return rgbnm_launch_tn_pipe_group(&j, 1, S_out, st);
+  }
+  TnPipe p;
+  if (tn_fill(p, dY, ldy, X, ldx, part, bpart, M, No, Ki, true)) return 1;
   const int tiles = p.rtiles * p.ctiles;
   const int ktiles = M / TK;
-  // one workgroup per CU (120 / 144 KB LDS): at most 256 workgroups so the grid is a single wave of the chip
-  // (counting the padding of the XCD map: a 257th workgroup would wait for a whole first round and double the time)
   int S = 256 / tiles;
   if (S >= 8) S = S / 8 * 8;
   if (S < 1) S = 1;
@@ -371,17 +436,13 @@ int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float*
   p.S = S;
   *S_out = S;
   const int slot = rgbnm_trace_begin(TR_TN, 2.0 * M * (double)No * Ki, ((double)M * No + (double)M * Ki) * 2.0 + (double)No * Ki * 4.0, st);
-  if (square) {
-    static bool attr_q = false;
-    if (!attr_q) {
-      if (hipFuncSetAttribute((const void*)gemm_tn_pipe_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM) != hipSuccess)
-        return RGBNM_ELAUNCH;
-      attr_q = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_pipe_q_kernel, dim3(tiles * ((S + 7) / 8) * 8), dim3(384), Q_SMEM, st, p);
-  } else {
-    hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(tiles * ((S + 7) / 8) * 8), dim3(512), SMEM, st, p);
+  static bool attr_q = false;
+  if (!attr_q) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_pipe_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr_q = true;
   }
+  hipLaunchKernelGGL(gemm_tn_pipe_q_kernel, dim3(tiles * ((S + 7) / 8) * 8), dim3(384), Q_SMEM, st, p);
   rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;

@@ -5,6 +5,16 @@
 constexpr int RGBNM_TN_MAX_SPLIT = 128;   // token-axis splits of a weight-gradient GEMM (workspace is sized for it)
 // Pipelined bf16 weight-gradient GEMM (gemm_tn_pipe.hip).  Returns RGBNM_OK, or 1 if the shape is not eligible
 // (caller falls back to the generic kernel), or a negative error.
+// One weight-gradient GEMM of a grouped launch (gemm_tn_pipe.hip): part[s][No][Ki], bpart[s][No] (or null).
+struct RgbnmTnJob {
+  const void* dY; const void* X; float* part; float* bpart;
+  int ldy, ldx, M, No, Ki;
+};
+int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st);
+// Queue the eligible bf16 rgbnm_gemm_tn calls that follow and run them as one grouped launch at flush (or when 4 are
+// queued); their partial reductions are submitted at flush.  Used by rgbnm_vit_block_bwd to pair fc2/fc1 and proj/qkv.
+void rgbnm_tn_defer_begin();
+int rgbnm_tn_defer_flush(hipStream_t st);
 int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
                          int Ki, int* S_out, hipStream_t st);
 

@@ -27,7 +27,7 @@ hipEvent_t take_event() {
   return e;
 }
 struct Opt { const char* name; int value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"trace", 0}, {"tn_wgs", 512}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -192,10 +192,15 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   rgbnm_reduce_defer_begin();     // the 12 partial reductions of this block run as one launch at the end
   const int rc = [&]() -> int {
   // ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ------------------------------------
+  // tn_group: the four dW GEMMs run one per launch (0), as pairs fc2 + fc1 / proj + qkv (1) or all in one launch at the
+  // end of the block (2): T tiles in a launch -> 256 / T splits of the token axis -> that many fp32 partial tiles
+  const int group = rgbnm_get_option("tn_group");
+  if (group) rgbnm_tn_defer_begin();
   TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DGELU, dy, E, p->w2_t, E, s->du, 4 * E, 0, a->u, 4 * E, 0, 0, 0, 0, M, 4 * E, E, 0,
                     st));
   TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, WS(1), st));
+  if (group == 1) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
   // dx_mid = dy + LN2'(du . W1): LayerNorm backward fused into the GEMM epilogue when eligible
   if (!fused_dx_lnbwd(dt, s->du, 4 * E, p->w1_t, 4 * E, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid,
                       g->dln2_g, g->dln2_b, M, E, 4 * E, WS(4), (hipStream_t)st)) {
@@ -205,10 +210,12 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
                             M, E, 0, WS(4), st));
   }
   // ---- attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in)))) -------------------------------
+  if (group == 1) rgbnm_tn_defer_begin();
   TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, WS(2), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dx_mid, E, p->wproj_t, E, s->dattn, I, 0, 0, 0, 0, 0, 0, 0, M, I, E, 0, st));
   TRY(rgbnm_attention_bwd(dt, a->qkv, a->attn, s->dattn, a->lse, s->dqkv, c->B, c->N, c->heads, c->attn_scale, st));
   TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
+  if (group) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
   if (!fused_dx_lnbwd(dt, s->dqkv, 3 * I, p->wqkv_t, 3 * I, a->x_in, p->ln1_g, a->mean1, a->rstd1, s->dx_mid, dx,
                       g->dln1_g, g->dln1_b, M, E, 3 * I, WS(5), (hipStream_t)st)) {
     TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dqkv, 3 * I, p->wqkv_t, 3 * I, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E,
@@ -219,8 +226,9 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   return RGBNM_OK;
   }();
 #undef WS
+  const int rt = rgbnm_tn_defer_flush((hipStream_t)st);      // no-op unless an error left the queue open
   const int rf = rgbnm_reduce_defer_flush((hipStream_t)st);
-  return rc != RGBNM_OK ? rc : rf;
+  return rc != RGBNM_OK ? rc : (rt != RGBNM_OK ? rt : rf);
 }
 
 int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* c, int in_dtype, const void* y, const void* cbcr, const float* conv16,

@@ -207,6 +207,38 @@ def test_bf16_backward_with_and_without_fused_layernorm_backward(B):
         assert rel < 1e-4, (n, rel)
 
 
+def test_bf16_weight_gradients_grouped_and_ungrouped_launches():
+    """tn_group: the dW GEMMs of an encoder block run one per launch (0), in pairs fc2+fc1 / proj+qkv (1) or all four in
+    one launch (2, default).  Only the split count of the token axis changes, i.e. the grouping of the fp32 partial
+    sums: activations-side results are bit-identical, weight gradients agree to fp32 rounding."""
+    from rgb_no_more_amd import lib as L
+    lib = L.lib()
+    B = 64
+    m, sd, _, _, _ = build("ti_d2", torch.bfloat16)
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 83)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 84)).to(DEV)
+    old = lib.rgbnm_get_option(b"tn_group")
+    grads = {}
+    try:
+        for mode in (0, 1, 2):
+            L.check(lib.rgbnm_set_option(b"tn_group", mode))
+            m.zero_grad(set_to_none=True)
+            m.train()
+            out = m(y, c)
+            out.float().square().mean().backward()
+            grads[mode] = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()}
+    finally:
+        lib.rgbnm_set_option(b"tn_group", old)
+    for mode in (1, 2):
+        for n in grads[0]:
+            a, b = grads[0][n], grads[mode][n]
+            assert torch.isfinite(b).all()
+            rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
+            assert rel < 2e-6, (mode, n, rel)
+            if "lrnorm" in n:                 # LayerNorm gradients do not go through the dW GEMMs
+                assert torch.equal(a, b), (mode, n)
+
+
 @pytest.mark.parametrize("tag,emb,heads", [("ti_d2_v2", 192, 3), ("s_d2_v2", 384, 6)])
 def test_embed_type2_fp32_and_bf16_vs_reference_golden(golden, tag, emb, heads):
     """ver=2 (embed_type 2, PatchEmbedding_DCT_Separate_subblock: train.py's default patch embedding).  fp32 logits
