@@ -321,6 +321,10 @@ int rgbnm_token_mean(int dtype, const void* in, void* out, int B, int N, int C, 
  * `sink` is a 4-byte device word that is never actually written. */
 int rgbnm_calib_mfma_bf16(int workgroups, int iters, float* sink, void* stream);
 int rgbnm_calib_stream(const void* src, void* dst, size_t bytes, int mode, int workgroups, void* sink, void* stream);
+/* One wave issues 16 back-to-back 1 KB stores (mode 0) / loads (mode 1), 8 rows x 128 B at row stride ld bytes:
+ * out[(wg * waves + w) * 2 + {0, 1}] = cycles to issue them / cycles until they have all completed. */
+int rgbnm_calib_vmem_issue(int mode, int workgroups, int waves, void* buf, size_t wave_bytes, int ld,
+                           unsigned long long* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ constexpr int NPAD = NTILE * 32;          // 224 token rows per LDS array
 constexpr int ROWB = 128;                 // bytes per token row
 constexpr int ARR = NPAD * ROWB;          // 28 KB
 constexpr int NTHREADS = NTILE * 64;
+constexpr int NTHREADS3 = NTHREADS + 64;   // attn3_bwd_kernel: 7 compute waves + 1 DMA wave
 
 __device__ __forceinline__ int fswz(int row) {
   return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
@@ -39,6 +40,17 @@ __device__ __forceinline__ void dma_matrix(const bf16* __restrict__ src, int ld,
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = w + 7 * j;
+    const int row = 8 * i + (lane >> 3), pc = lane & 7;
+    const int lc = pc ^ fswz(row);
+    const int srow = row < N ? row : N - 1;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)srow * ld + lc * 8), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+  }
+}
+
+// The same 28 instructions issued by ONE wave (the DMA wave of attn3_bwd_kernel).
+__device__ __forceinline__ void dma_matrix_all(const bf16* __restrict__ src, int ld, int N, unsigned char* dst, int lane) {
+#pragma unroll 4
+  for (int i = 0; i < 28; ++i) {
     const int row = 8 * i + (lane >> 3), pc = lane & 7;
     const int lc = pc ^ fswz(row);
     const int srow = row < N ? row : N - 1;
@@ -443,13 +455,18 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
 // stamps): 23 % of a workgroup's life is the initial DMA wait and 8 % the store drain, with one workgroup per CU
 // (116 KB of LDS) nothing hides either.  Here each of (at most) 256 workgroups walks several (image, head) pairs and
 // the two LDS array pairs are refilled a full phase ahead:
-//     phase A(h) reads K,V (all rows)  + own Q,dO,O rows from REGISTERS (fragment loads issued after phase B(h-1))
+//     phase A(h) reads K,V (all rows)  + own Q,dO,O rows (coalesced register loads issued after phase B(h-1), turned
+//                into fragments through the wave's private LDS tile)
 //     -- barrier -- K,V(h+1) DMA starts
 //     phase B(h) reads Q,dO (all rows) + own K,V rows (registers, taken from LDS before the barrier)
 //     -- barrier -- Q,dO(h+1) DMA starts
-// vmcnt retires in order, so every wait is "everything except the youngest DMA group".  The exponent is one FMA +
-// exp2 (log2 e folded into scale and lse), `scale` multiplies dQ/dK once at the end, lse/D rows are read as float4,
-// and the key/query mask is applied on the ragged last tile only.
+// 7 compute waves + 1 DMA wave.  Cycle stamps of the first persistent version showed 40 % of a pair's time going to the
+// ISSUE of vmem instructions -- 24 scattered stores, 13 fragment-shaped loads and 16 LDS-DMAs per wave, 700-1000 cycles
+// each, because every CU reaches its burst at the same moment and the fragment loads thrashed L1.  Now the DMA wave
+// issues every LDS-DMA and every global store (it can stall for thousands of cycles without holding anybody up) and the
+// compute waves touch global memory only through 13 coalesced loads per pair: 69 -> 57 us per launch at B = 256.
+// The exponent is one FMA + exp2 (log2 e folded into scale and lse), `scale` multiplies dQ/dK once at the end, lse/D
+// rows are read as float4, and the key/query mask is applied on the ragged last tile only.
 template <int NTOK, int T> __device__ __forceinline__ bool tile_on(int N) {
   if constexpr (NTOK > 0) return T * 32 < NTOK;
   else return T * 32 < N;
@@ -462,8 +479,74 @@ template <int NTOK, int T> __device__ __forceinline__ bool tile_ragged(int N) {
 // NTOK > 0: the token count is a compile-time constant (196 for JPEG-Ti/S): every tile test folds away and only the
 // ragged last tile carries a mask.  (With a runtime N the compiler kept 14 tile predicates and 100+ lane masks alive in
 // SGPRs and spilled them through v_writelane / v_readlane: 650 of the kernel's 2900 VALU instructions.)
+// Gradient rows leave the persistent backward as full 128-byte lines, and not from the compute waves.  In the swapped
+// orientation a lane owns one token and 4 consecutive head-dim values per accumulator quad, so direct stores are 8 bytes
+// per lane at a 1152-byte stride; worse, every CU reaches its store / load burst at the same time and a vmem instruction
+// then takes ~700-1000 cycles to ISSUE (cycle stamps: 40 % of a pair's time went to issuing 24 stores, 13 loads and 16
+// LDS-DMAs per wave).  So the compute waves only park their 32 x 64 bf16 tiles in LDS (8-byte writes, conflict free):
+//   dQ -> the wave's own rows of Ks (free after the mid barrier),  dK -> a private 4.5 KB tile,  dV -> own rows of Gs
+// and the DMA wave reads them back as 16 B per lane, 8 lanes per row, and issues every global store (whole lines).
+constexpr int STG_PITCH = 144;
+constexpr int STG_WAVE = 32 * STG_PITCH;       // 4.5 KB per wave
+__device__ __forceinline__ void tile_park_private(unsigned char* stg, const f32x16 (&acc)[2], float mul, const LaneGeo& L) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 v = {acc[dt][rq * 4 + 0], acc[dt][rq * 4 + 1], acc[dt][rq * 4 + 2], acc[dt][rq * 4 + 3]};
+      store4<bf16>(reinterpret_cast<bf16*>(stg + L.l31 * STG_PITCH) + dt * 32 + rq * 8 + L.g * 4, v * mul);
+    }
+}
+// rows w*32 .. w*32+31 of a 128-byte-pitch array; 16-byte chunk c of row r sits at chunk c ^ (r & 7)
+__device__ __forceinline__ void tile_park_rows(unsigned char* arr, int w, const f32x16 (&acc)[2], float mul, const LaneGeo& L) {
+  // one opaque base offset, chunk selected by XOR with a constant: the 8 swizzled addresses are loop invariants that the
+  // compiler otherwise hoists to the kernel prologue and then SPILLS (each reload a serialised scratch round trip)
+  int ln = L.lane;
+  asm volatile("" : "+v"(ln));     // (and off0 itself is recomputed from the lane id here, not kept live across the pair)
+  const unsigned off0 = (unsigned)((w * 32 + (ln & 31)) * ROWB + ((ln & 7) << 4) + (ln >> 5) * 8);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 v = {acc[dt][rq * 4 + 0], acc[dt][rq * 4 + 1], acc[dt][rq * 4 + 2], acc[dt][rq * 4 + 3]};
+      store4<bf16>(reinterpret_cast<bf16*>(arr + (off0 ^ (unsigned)((dt * 4 + rq) << 4))), v * mul);
+    }
+}
+// DMA wave: the parked tiles of all compute waves -> registers -> global rows (column block of 64 at g0, row stride ld)
+template <bool PRIVATE>
+__device__ __forceinline__ void tiles_read(const unsigned char* src, int N, int lane, u32x4 (&v)[NTILE][4]) {
+  const int rl = lane >> 3, seg = lane & 7;
+#pragma unroll
+  for (int wv = 0; wv < NTILE; ++wv) {
+    if (wv * 32 < N) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = i * 8 + rl;
+        v[wv][i] = PRIVATE ? *reinterpret_cast<const u32x4*>(src + wv * STG_WAVE + r * STG_PITCH + seg * 16)
+                           : *reinterpret_cast<const u32x4*>(src + (wv * 32 + r) * ROWB + ((seg ^ (r & 7)) << 4));
+      }
+    }
+  }
+}
+__device__ __forceinline__ void tiles_write(const u32x4 (&v)[NTILE][4], bf16* __restrict__ g0, size_t ld, int N, int lane) {
+  const int rl = lane >> 3, seg = lane & 7;
+#pragma unroll
+  for (int wv = 0; wv < NTILE; ++wv)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wv * 32 + i * 8 + rl;
+      if (row < N) *reinterpret_cast<u32x4*>(g0 + (size_t)row * ld + seg * 8) = v[wv][i];
+    }
+}
+template <bool PRIVATE>
+__device__ __forceinline__ void tiles_to_global(const unsigned char* src, bf16* __restrict__ g0, size_t ld, int N, int lane) {
+  u32x4 v[NTILE][4];
+  tiles_read<PRIVATE>(src, N, lane, v);
+  tiles_write(v, g0, ld, N, lane);
+}
+
 template <int NTOK>
-__global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+__global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                              const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, bf16* __restrict__ dqkv,
                                                              int N_rt, int heads, int nbh, float scale) {
@@ -478,36 +561,45 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
   const int inner = heads * HD, ld = 3 * inner;
   const LaneGeo L = lane_geo();
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* stg = smem + 4 * ARR + 2 * NPAD * (int)sizeof(float) + w * STG_WAVE;   // this wave's store tile
   const int row = w * 32 + L.l31;            // this lane's query (phase A) / key (phase B)
   const int rc = row < N ? row : N - 1;
   const bool active = w * 32 < N;
   const float LOG2E = 1.4426950408889634f;
   const float c2 = scale * LOG2E;
 
-  auto issue_kv = [&](int bh) {
+  auto issue_kv = [&](int bh) {             // DMA wave only: 56 instructions
     const bf16* Q = qkv + (size_t)(bh / heads) * N * ld + (bh % heads) * HD;
-    dma_matrix(Q + inner, ld, N, Ks, w, L.lane);
-    dma_matrix(Q + 2 * inner, ld, N, Vs, w, L.lane);
+    dma_matrix_all(Q + inner, ld, N, Ks, L.lane);
+    dma_matrix_all(Q + 2 * inner, ld, N, Vs, L.lane);
   };
   auto issue_qg = [&](int bh) {
     const bf16* Q = qkv + (size_t)(bh / heads) * N * ld + (bh % heads) * HD;
-    dma_matrix(Q, ld, N, Qs, w, L.lane);
-    dma_matrix(dout + (size_t)(bh / heads) * N * inner + (bh % heads) * HD, inner, N, Gs, w, L.lane);
+    dma_matrix_all(Q, ld, N, Qs, L.lane);
+    dma_matrix_all(dout + (size_t)(bh / heads) * N * inner + (bh % heads) * HD, inner, N, Gs, L.lane);
   };
-  Frag<bf16> qf[4], gf[4], of[4];
+  // Own rows (phase A operands Q, dO and O for D): 12 COALESCED loads per lane -- lane = (row i*8 + lane/8, 16-byte
+  // segment lane%8), 8 whole lines per instruction -- parked in the private LDS tile at the top of the pair and read back
+  // as MFMA fragments.  (Fragment-shaped loads touched 32 lines per instruction, 4 instructions per line: the 84 KB of own
+  // rows per pair thrashed the 32 KB L1 and pulled up to 4x that from L2 while every store and DMA queued behind them.)
+  u32x4 qraw[4], graw[4], oraw[4];
   float lq = 0.f;
   auto load_own = [&](int bh) {              // 13 loads per lane
     const int b = bh / heads, h = bh % heads;
-    const bf16* Qr = qkv + ((size_t)b * N + rc) * ld + h * HD + L.g * 8;
-    const bf16* Gr = dout + ((size_t)b * N + rc) * inner + h * HD + L.g * 8;
-    const bf16* Or = out + ((size_t)b * N + rc) * inner + h * HD + L.g * 8;
+    int lane_ = L.lane;
+    asm volatile("" : "+v"(lane_));          // opaque: the 12 row addresses are recomputed here, not hoisted and spilled
+    const int seg = lane_ & 7;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      qf[c] = load_frag<bf16>(Qr + c * 16);
-      gf[c] = load_frag<bf16>(Gr + c * 16);
-      of[c] = load_frag<bf16>(Or + c * 16);
+    for (int i = 0; i < 4; ++i) {
+      int r = w * 32 + i * 8 + (lane_ >> 3);
+      r = r < N ? r : N - 1;
+      qraw[i] = *reinterpret_cast<const u32x4*>(qkv + ((size_t)b * N + r) * ld + h * HD + seg * 8);
+      graw[i] = *reinterpret_cast<const u32x4*>(dout + ((size_t)b * N + r) * inner + h * HD + seg * 8);
+      oraw[i] = *reinterpret_cast<const u32x4*>(out + ((size_t)b * N + r) * inner + h * HD + seg * 8);
     }
-    lq = lse[(size_t)bh * N + rc];
+    int rq_ = w * 32 + (lane_ & 31);
+    rq_ = rq_ < N ? rq_ : N - 1;
+    lq = lse[(size_t)bh * N + rq_];
   };
 
   int bh = blockIdx.x;
@@ -518,36 +610,89 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
 #else
 #define APROF3(i) do {} while (0)
 #endif
-  issue_kv(bh);
-  issue_qg(bh);
+  if (w == NTILE) {
+    // ---- DMA wave: every LDS-DMA of the workgroup.  Issuing these instructions stalls for thousands of cycles when all
+    // CUs hit their load / store bursts together (cycle stamps: 8 DMA instructions per compute wave took 6.3 k cycles to
+    // issue); a wave with nothing else to do absorbs that stall while the compute waves go straight into the next phase.
+    // Four barriers per pair; what each one tells the other side:
+    //   mid : compute waves are done with K,V; dQ tiles are parked (private tiles) | Q,dO of this pair have landed
+    //   mid2:                                                 | the dQ tiles are in registers, the private tiles are free
+    //   end : compute waves are done with Q,dO, D_s, L2_s; dK tiles are parked | K,V of the next pair have landed
+    //   end2: dV tiles are parked in the Gs rows              | the dK tiles are in registers, the private tiles are free
+    const unsigned char* stg0 = smem + 4 * ARR + 2 * NPAD * (int)sizeof(float);
+    issue_kv(bh);
+    issue_qg(bh);
+    asm volatile("s_waitcnt vmcnt(56)" ::: "memory");     // K,V landed: only the younger Q,dO group may be in flight
+    __builtin_amdgcn_s_barrier();                          // start
+    for (; bh < nbh; bh += gridDim.x) {
+      const int nxt = bh + gridDim.x;
+      bf16* g0 = dqkv + (size_t)(bh / heads) * N * ld + (bh % heads) * HD;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // Q,dO landed (and the previous pair's stores are done)
+      __builtin_amdgcn_s_barrier();                        // mid
+      u32x4 tq[NTILE][4];
+      tiles_read<true>(stg0, N, L.lane, tq);               // dQ tiles -> registers
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // mid2
+      tiles_write(tq, g0, ld, N, L.lane);
+      if (nxt < nbh) issue_kv(nxt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // K,V of the next pair landed (during phase B)
+      __builtin_amdgcn_s_barrier();                        // end
+      tiles_read<true>(stg0, N, L.lane, tq);               // dK tiles -> registers (the private tiles are free again)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // end2
+      tiles_write(tq, g0 + inner, ld, N, L.lane);
+      tiles_read<false>(Gs, N, L.lane, tq);                // dV
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (nxt < nbh) issue_qg(nxt);                        // Q,dO of the next pair first: phase B needs them
+      tiles_write(tq, g0 + 2 * inner, ld, N, L.lane);
+    }
+    return;
+  }
   load_own(bh);
-  bool first = true;
+  __builtin_amdgcn_s_barrier();                            // start: K,V of the first pair are in LDS
   for (; bh < nbh; bh += gridDim.x) {
     const int b = bh / heads, h = bh % heads;
     const int nxt = bh + gridDim.x;
-    // K,V of this pair have landed once only the youngest DMA group (Q,dO: 8 per wave) is outstanding
-    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    first = false;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own rows (and the previous pair's stores)
     APROF3(0);
-    __builtin_amdgcn_s_barrier();
     APROF3(1);
 
     // ================= phase A: wave = 32 queries -> dQ, D =================
     Frag<bf16> kf[4], vf[4];
     if (active) {
       f32x16 dq[2];
-      float Dq = 0.f;
+      Frag<bf16> qf[4], gf[4];
+      const int rl = L.lane >> 3, seg = L.lane & 7;
+      // D = rowsum(dO * O) straight from the row-major pieces: 8 products per lane, 8 lanes per row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 gv = __builtin_bit_cast(bf16x8, graw[i]), ov = __builtin_bit_cast(bf16x8, oraw[i]);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += (float)gv[e] * (float)ov[e];
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (seg == 0) D_s[w * 32 + i * 8 + rl] = d;
+      }
+      // Q, dO: row-major pieces -> private tile -> fragments (lane <-> row l31, 16-byte chunk 2c + g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = qraw[i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int c = 0; c < 4; ++c)
+        qf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Dq += (float)gf[c].v[e] * (float)of[c].v[e];
-      Dq += __shfl_xor(Dq, 32, 64);
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = graw[i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        gf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
+      const float Dq = D_s[row];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const float lq2 = lq * LOG2E;
-      if (L.g == 0) {
-        D_s[row] = Dq;
-        L2_s[row] = lq2;
-      }
+      if (L.g == 0) L2_s[row] = lq2;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -585,16 +730,7 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
           mma(dq[1], kk[3], sf);
         }
       });
-      if (row < N) {        // 8 store instructions per active wave (counted by the wait below)
-        bf16* drow = dqkv + ((size_t)b * N + row) * ld + h * HD;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            f32x4 v = {dq[dt][rq * 4 + 0], dq[dt][rq * 4 + 1], dq[dt][rq * 4 + 2], dq[dt][rq * 4 + 3]};
-            store4<bf16>(drow + dt * 32 + rq * 8 + L.g * 4, v * scale);
-          }
-      }
+      tile_park_private(stg, dq, scale, L);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {          // own K,V rows for phase B, before the arrays are refilled
         kf[c] = rowfrag(Ks, w, L.l31, c, L.g, L.fl);
@@ -602,12 +738,10 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
       }
     }
     APROF3(2);
-    // Q,dO of this pair have landed once only this wave's 8 dQ stores (younger) are outstanding
-    if (active) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // D_s / L2_s complete; every wave is done with K,V
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // mid: D_s / L2_s complete; every wave is done with K,V; dQ tiles parked
+    __builtin_amdgcn_s_barrier();            // mid2: the DMA wave has taken the dQ tiles (the private tile is free for dK)
     APROF3(3);
-    if (nxt < nbh) issue_kv(nxt);
 
     // ================= phase B: wave = 32 keys -> dK, dV =================
     if (active) {
@@ -663,28 +797,20 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
           mma(dk[1], gg[3], f);
         }
       });
-      if (row < N) {
-        bf16* krow = dqkv + ((size_t)b * N + row) * ld + inner + h * HD;
-        bf16* vrow = krow + inner;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            f32x4 a = {dk[dt][rq * 4 + 0], dk[dt][rq * 4 + 1], dk[dt][rq * 4 + 2], dk[dt][rq * 4 + 3]};
-            f32x4 c = {dv[dt][rq * 4 + 0], dv[dt][rq * 4 + 1], dv[dt][rq * 4 + 2], dv[dt][rq * 4 + 3]};
-            store4<bf16>(krow + dt * 32 + rq * 8 + L.g * 4, a * scale);
-            store4<bf16>(vrow + dt * 32 + rq * 8 + L.g * 4, c);
-          }
-      }
-    }
-    APROF3(4);
-    if (nxt < nbh) {
-      load_own(nxt);                         // (issuing these during phase B would spill: 256-register budget)
+      APROF3(4);
+      tile_park_private(stg, dk, scale, L);
+      APROF3(5);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // every wave is done with Q,dO, D_s, L2_s
-      issue_qg(nxt);
+      __builtin_amdgcn_s_barrier();          // end: every wave is done with Q,dO, D_s, L2_s; dK tiles parked
+      APROF3(6);
+      tile_park_rows(Gs, w, dv, 1.0f, L);
+    } else {
+      __builtin_amdgcn_s_barrier();          // end
     }
-    APROF3(5);
+    if (nxt < nbh) load_own(nxt);            // (any earlier and the 256-register budget spills)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // end2: dV tiles parked
+    APROF3(7);
 #ifdef ATTN_PROF
     ++pit;
 #endif
@@ -694,6 +820,7 @@ __global__ __launch_bounds__(NTHREADS) void attn3_bwd_kernel(const bf16* __restr
 constexpr int SMEM_FWD = 2 * ARR;
 #define ATTN_PROF_END 1
 constexpr int SMEM_BWD = 4 * ARR + 2 * NPAD * (int)sizeof(float);
+constexpr int SMEM_BWD3 = SMEM_BWD + NTILE * STG_WAVE;      // + the per-wave store tiles of attn3_bwd_kernel
 
 }  // namespace
 
@@ -727,17 +854,17 @@ int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, c
   if (rgbnm_get_option("attn_persist")) {
     static bool attr3 = false;
     if (!attr3) {
-      if (hipFuncSetAttribute((const void*)attn3_bwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess ||
-          hipFuncSetAttribute((const void*)attn3_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)attn3_bwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD3) != hipSuccess ||
+          hipFuncSetAttribute((const void*)attn3_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD3) != hipSuccess)
         return RGBNM_ELAUNCH;
       attr3 = true;
     }
     const int nbh = B * heads;
     if (N == 196)
-      hipLaunchKernelGGL(attn3_bwd_kernel<196>, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv,
+      hipLaunchKernelGGL(attn3_bwd_kernel<196>, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS3), SMEM_BWD3, st, (const bf16*)qkv,
                          (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, heads, nbh, scale);
     else
-      hipLaunchKernelGGL(attn3_bwd_kernel<0>, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv,
+      hipLaunchKernelGGL(attn3_bwd_kernel<0>, dim3(nbh < 256 ? nbh : 256), dim3(NTHREADS3), SMEM_BWD3, st, (const bf16*)qkv,
                          (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, heads, nbh, scale);
   } else {
     hipLaunchKernelGGL(attn2_bwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_BWD, st, (const bf16*)qkv, (const bf16*)out,

@@ -58,3 +58,44 @@ extern "C" int rgbnm_calib_stream(const void* src, void* dst, size_t bytes, int 
                        bytes / 16, mode, (unsigned*)sink);
     return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
 }
+
+// ---- how fast can ONE wave issue back-to-back 1 KB vmem instructions?  (experiment behind the DMA-wave design of the
+// attention backward).  mode 0: global_store_dwordx4, 8 rows x 128 B per instruction, row stride `ld` bytes;
+// mode 1: global_load_dwordx4 of the same footprint.  out[wg*waves + w] = {cycles to issue 16, cycles until vmcnt(0)}.
+namespace rgbnm {
+__global__ __launch_bounds__(512) void calib_vmem_issue_kernel(int mode, unsigned char* buf, size_t wave_bytes, int ld,
+                                                               unsigned long long* out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned char* base = buf + ((size_t)blockIdx.x * nw + w) * wave_bytes + (size_t)(lane >> 3) * ld + (lane & 7) * 16;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 v[16];
+    for (int i = 0; i < 16; ++i) v[i] = u4{(unsigned)lane, (unsigned)i, (unsigned)w, 7u};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    if (mode == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<u4*>(base + (size_t)i * 8 * ld) = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(base + (size_t)i * 8 * ld));
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t2 = __builtin_readcyclecounter();
+    unsigned acc = 0;
+    for (int i = 0; i < 16; ++i) acc += v[i][0];
+    if (lane == 0) {
+        out[((size_t)blockIdx.x * nw + w) * 2 + 0] = t1 - t0 + (acc == 0x7fffffffu);
+        out[((size_t)blockIdx.x * nw + w) * 2 + 1] = t2 - t0;
+    }
+}
+}  // namespace rgbnm
+
+extern "C" int rgbnm_calib_vmem_issue(int mode, int workgroups, int waves, void* buf, size_t wave_bytes, int ld,
+                                      unsigned long long* out, void* stream) {
+    if (mode < 0 || mode > 1 || workgroups <= 0 || waves < 1 || waves > 8 || !buf || !out || ld < 128) return RGBNM_EINVAL;
+    if (wave_bytes < (size_t)128 * ld) return RGBNM_EINVAL;
+    hipLaunchKernelGGL(rgbnm::calib_vmem_issue_kernel, dim3(workgroups), dim3(64 * waves), 0, (hipStream_t)stream, mode,
+                       (unsigned char*)buf, wave_bytes, ld, out);
+    return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
+}

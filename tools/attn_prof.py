@@ -22,9 +22,12 @@ print('avg kernel+launch us:', e0.elapsed_time(e1) * 1000 / 200)
 buf = np.zeros(768 * 8 * 8, dtype=np.uint64)
 f = L.lib().rgbnm_debug_attn_prof; f.restype = C.c_int; f.argtypes = [C.c_void_p]
 assert f(buf.ctypes.data) == 0
-p = buf.reshape(768, 8, 8).astype(np.int64)[:, :7, :7]
-names = ["top_wait_done", "barrier1", "phaseA(+own kf/vf)", "mid wait+barrier", "phaseB(+stores)", "own loads+end barrier+issue"]
-print("persistent kernel: second (image, head) pair of every workgroup")
-for i in range(1, 6):
+p = buf.reshape(768, 8, 8).astype(np.int64)[:256, :7, :]      # 256 persistent workgroups x 7 waves x 8 stamps
+names = ["top wait done", "-", "phase A + park dQ (+own kf/vf)", "mid + mid2", "phase B loop", "park dK",
+         "end barrier", "park dV + own loads issue + end2"]
+print("persistent kernel: second (image, head) pair of every workgroup; per-wave cycle deltas")
+for i in range(1, 8):
     d = p[:, :, i] - p[:, :, i - 1]
-    print(f"{names[i]:22s} delta mean={d.mean():8.0f} min={d.min():8.0f} max={d.max():8.0f}   since start mean={(p[:, :, i] - p[:, :, 0]).mean():9.0f}")
+    per_wave = " ".join(f"{d[:, w].mean():7.0f}" for w in range(7))
+    print(f"{names[i]:24s} mean={d.mean():8.0f} max={d.max():8.0f} | per wave: {per_wave}")
+print("pair total", (p[:, :, 7] - p[:, :, 0]).mean())
