@@ -47,6 +47,15 @@ __device__ __forceinline__ void dma_matrix(const bf16* __restrict__ src, int ld,
   }
 }
 
+// rowfrag with the per-lane part folded into one offset rb = l31 * ROWB + ((g ^ fswz(l31)) << 4): chunk c of the row is at
+// rb ^ (c << 5) because (2c + g) ^ fl = 2c ^ (g ^ fl).  rb is re-derived (made opaque) at the start of each phase so the
+// per-array, per-chunk addresses are not kept in registers -- or spilled -- across the whole persistent loop.
+__device__ __forceinline__ Frag<bf16> rowfrag_x(const unsigned char* arr, unsigned rb, int t, int c) {
+  Frag<bf16> f;
+  f.v = *reinterpret_cast<const bf16x8*>(arr + (rb ^ (unsigned)(c << 5)) + t * 32 * ROWB);
+  return f;
+}
+
 // The same 28 instructions issued by ONE wave (the DMA wave of attn3_bwd_kernel).
 __device__ __forceinline__ void dma_matrix_all(const bf16* __restrict__ src, int ld, int N, unsigned char* dst, int lane) {
 #pragma unroll 4
@@ -501,8 +510,7 @@ __device__ __forceinline__ void tile_park_private(unsigned char* stg, const f32x
 __device__ __forceinline__ void tile_park_rows(unsigned char* arr, int w, const f32x16 (&acc)[2], float mul, const LaneGeo& L) {
   // one opaque base offset, chunk selected by XOR with a constant: the 8 swizzled addresses are loop invariants that the
   // compiler otherwise hoists to the kernel prologue and then SPILLS (each reload a serialised scratch round trip)
-  int ln = L.lane;
-  asm volatile("" : "+v"(ln));     // (and off0 itself is recomputed from the lane id here, not kept live across the pair)
+  const int ln = lane_id_here();   // (and off0 itself is recomputed here, not kept live across the pair)
   const unsigned off0 = (unsigned)((w * 32 + (ln & 31)) * ROWB + ((ln & 7) << 4) + (ln >> 5) * 8);
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -562,6 +570,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
   const LaneGeo L = lane_geo();
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* stg = smem + 4 * ARR + 2 * NPAD * (int)sizeof(float) + w * STG_WAVE;   // this wave's store tile
+  const unsigned rb0 = (unsigned)(L.l31 * ROWB + ((L.g ^ L.fl) << 4));
   const int row = w * 32 + L.l31;            // this lane's query (phase A) / key (phase B)
   const int rc = row < N ? row : N - 1;
   const bool active = w * 32 < N;
@@ -586,8 +595,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
   float lq = 0.f;
   auto load_own = [&](int bh) {              // 13 loads per lane
     const int b = bh / heads, h = bh % heads;
-    int lane_ = L.lane;
-    asm volatile("" : "+v"(lane_));          // opaque: the 12 row addresses are recomputed here, not hoisted and spilled
+    const int lane_ = lane_id_here();        // the 12 row addresses are recomputed here, not hoisted and spilled
     const int seg = lane_ & 7;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -697,7 +705,9 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-      const unsigned kt = (unsigned)(size_t)Ks + L.tr0;
+      unsigned rb = rb0, tr = L.tr0;
+      asm volatile("" : "+v"(rb), "+v"(tr));
+      const unsigned kt = (unsigned)(size_t)Ks + tr;
       TileLoop<NTILE>::run([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         if (tile_on<NTOK, t>(N)) {
@@ -706,8 +716,8 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
           for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            mma(sa, rowfrag(Ks, t, L.l31, c, L.g, L.fl), qf[c]);
-            mma(da, rowfrag(Vs, t, L.l31, c, L.g, L.fl), gf[c]);
+            mma(sa, rowfrag_x(Ks, rb, t, c), qf[c]);
+            mma(da, rowfrag_x(Vs, rb, t, c), gf[c]);
           }
           float ds[16];
 #pragma unroll
@@ -733,8 +743,8 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
       tile_park_private(stg, dq, scale, L);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {          // own K,V rows for phase B, before the arrays are refilled
-        kf[c] = rowfrag(Ks, w, L.l31, c, L.g, L.fl);
-        vf[c] = rowfrag(Vs, w, L.l31, c, L.g, L.fl);
+        kf[c] = rowfrag_x(Ks, rb, w, c);
+        vf[c] = rowfrag_x(Vs, rb, w, c);
       }
     }
     APROF3(2);
@@ -750,7 +760,9 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-      const unsigned qt_ = (unsigned)(size_t)Qs + L.tr0, gt_ = (unsigned)(size_t)Gs + L.tr0;
+      unsigned rb = rb0, tr = L.tr0;
+      asm volatile("" : "+v"(rb), "+v"(tr));
+      const unsigned qt_ = (unsigned)(size_t)Qs + tr, gt_ = (unsigned)(size_t)Gs + tr;
       TileLoop<NTILE>::run([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         if (tile_on<NTOK, t>(N)) {
@@ -759,8 +771,8 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
           for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            mma(sa, rowfrag(Qs, t, L.l31, c, L.g, L.fl), kf[c]);   // rows = queries, cols = keys
-            mma(da, rowfrag(Gs, t, L.l31, c, L.g, L.fl), vf[c]);
+            mma(sa, rowfrag_x(Qs, rb, t, c), kf[c]);   // rows = queries, cols = keys
+            mma(da, rowfrag_x(Gs, rb, t, c), vf[c]);
           }
           float pp[16], ds[16];
 #pragma unroll

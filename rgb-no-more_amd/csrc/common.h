@@ -77,6 +77,17 @@ template <typename T> __device__ __forceinline__ f32x4 load4(const T* p) {
   f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return o;
 }
+// Lane id recomputed on the spot (2 VALU ops) and opaque to the optimiser.  Per-lane address arithmetic written against
+// it stays where it is used; written against a long-lived `lane` it is hoisted out of the main loop as an invariant and,
+// in register-heavy kernels, SPILLED: every reload is a scratch round trip behind an s_waitcnt vmcnt(0), which also
+// drains whatever prefetch / store traffic the wave had in flight (measured: the difference between 0 and 13 k cycles per
+// (image, head) pair in the attention backward).
+__device__ __forceinline__ int lane_id_here() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v) {
   typename Vec4<T>::type o;
   o[0] = (T)v[0]; o[1] = (T)v[1]; o[2] = (T)v[2]; o[3] = (T)v[3];

@@ -95,11 +95,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_wres_kernel(WresArgs p) {
 
   // ---- per-lane addressing.  Load j of a tile: 16-byte chunk pidx = 64 j + lane -> (row, chunk) = (pidx/24, pidx%24)
   // (3 loads = 8 rows: the source pattern repeats every 3 loads, the swizzled destination every 6)
-  int a_src[3], a_dst[6];
+  int a_dst[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int pidx = 64 * j + lane, row = pidx / 24, pc = pidx % 24;
-    if (j < 3) a_src[j] = row * p.lda + pc * 8;
     a_dst[j] = row * ROWB + (pchunk(pc, row) << 4);
   }
   // output vector i of a lane: idx = lane + 64 i -> (row, vec) = (idx / 12, idx % 12); i + 3 is 16 rows further down
@@ -113,15 +112,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_wres_kernel(WresArgs p) {
     s_lane[i] = row * CP + vec * 8;
   }
   const int fl = fswz(l31);
-  int woff[4];                                        // fragment c of row l31: woff[c % 4] + 128 (c / 4)
-#pragma unroll
-  for (int c = 0; c < 4; ++c) woff[c] = l31 * ROWB + (((2 * c + g) ^ fl) << 4);
+  // fragment c of row l31 sits at l31 * ROWB + (((2c + g) ^ fl) << 4) = woff0 ^ (c << 5) (c < 4; + 128 per 4 chunks):
+  // one base, chunk selected by XOR with a constant, re-derived per tile so that four hoisted copies per LDS array do
+  // not sit in registers through the epilogue (the DGELU / RES variants spilled one of them and reloaded it in the MFMA
+  // phase behind an s_waitcnt that drained the next tile's prefetch)
+  const int woff0 = l31 * ROWB + ((g ^ fl) << 4);
 
   bf16x8 a[NCH];                                       // the NEXT tile, in flight while the current one is computed
   auto load_tile = [&](int tt) {
     const bf16* ab = p.A + (size_t)tt * BMT * p.lda;
+    // the three source offsets are recomputed from lane_id_here(): as loop invariants they get hoisted, and in the
+    // register-heavy epilogue variants SPILLED -- the reload then sits in front of these loads behind an s_waitcnt
+    // vmcnt(0) that drains the wave's in-flight stores and R loads on every tile
+    const int ln = lane_id_here();
+    int src[3];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) a[j] = *reinterpret_cast<const bf16x8*>(ab + a_src[j % 3] + (j / 3) * 8 * p.lda);
+    for (int j = 0; j < 3; ++j) {
+      const int pidx = 64 * j + ln;
+      src[j] = (pidx / 24) * p.lda + (pidx % 24) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) a[j] = *reinterpret_cast<const bf16x8*>(ab + src[j % 3] + (j / 3) * 8 * p.lda);
   };
   auto grab = [&]() -> int {                           // next unclaimed tile of this workgroup (wave-uniform)
     int v = 0;
@@ -165,10 +176,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_wres_kernel(WresArgs p) {
     for (int b = 0; b < 6; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    int wbase = woff0;
+    asm volatile("" : "+v"(wbase));
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       Frag<bf16> fa, fb[6];
-      const int wo = woff[c % 4] + 128 * (c / 4);
+      const int wo = (wbase ^ ((c % 4) << 5)) + 128 * (c / 4);
       fa.v = *reinterpret_cast<const bf16x8*>(Aw + wo);
 #pragma unroll
       for (int b = 0; b < 6; ++b) fb[b].v = *reinterpret_cast<const bf16x8*>(Ws + 32 * b * ROWB + wo);
