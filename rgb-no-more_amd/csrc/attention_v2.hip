@@ -192,8 +192,21 @@ template <> struct TileLoop<0> {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
+template <int NTOK, int T> __device__ __forceinline__ bool tile_on(int N) {
+  if constexpr (NTOK > 0) return T * 32 < NTOK;
+  else return T * 32 < N;
+}
+template <int NTOK, int T> __device__ __forceinline__ bool tile_ragged(int N) {
+  if constexpr (NTOK > 0) return T * 32 + 32 > NTOK;
+  else return T * 32 + 32 > N;
+}
+
+// NTOK > 0: compile-time token count (196): only the ragged last key tile carries a mask.  The exponent is one FMA +
+// exp2 (log2 e folded into the scale), and 1/sum multiplies the 32 output values instead of the 112 probabilities.
+template <int NTOK>
 __global__ __launch_bounds__(NTHREADS) void attn2_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                             float* __restrict__ lse, int N, int heads, float scale) {
+                                                             float* __restrict__ lse, int N_rt, int heads, float scale) {
+  const int N = NTOK > 0 ? NTOK : N_rt;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + ARR;
@@ -218,35 +231,29 @@ __global__ __launch_bounds__(NTHREADS) void attn2_fwd_kernel(const bf16* __restr
   __builtin_amdgcn_s_barrier();
   if (w * 32 >= N) return;
 
-  float s[NTILE][16];
+  // Two passes over the key tiles, S recomputed in the second one (4 extra MFMAs per tile, the MFMA pipe is mostly idle
+  // here): keeping the 7 x 16 scores of a lane alive between the passes cost 112 registers and with them the second
+  // workgroup per CU (155 VGPRs -> 3 waves per SIMD -> one 7-wave workgroup); now 2 workgroups overlap DMA and compute.
   float m = -INFINITY;
+  TileLoop<NTILE>::run([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if (tile_on<NTOK, t>(N)) {
+      f32x16 acc;
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) {
-    f32x16 acc;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int c = 0; c < 4; ++c) mma(acc, rowfrag(Ks, t, L.l31, c, L.g, L.fl), qf[c]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) mma(acc, rowfrag(Ks, t, L.l31, c, L.g, L.fl), qf[c]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kk = t * 32 + acc_row(r, L.lane);
-      s[t][r] = kk < N ? acc[r] : -INFINITY;
-      m = fmaxf(m, s[t][r]);
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if (tile_ragged<NTOK, t>(N) && t * 32 + acc_row(r, L.lane) >= N) v = -INFINITY;
+        m = fmaxf(m, v);
+      }
     }
-  }
+  });
   m = fmaxf(m, __shfl_xor(m, 32, 64));
+  const float c2 = scale * 1.4426950408889634f, mc2 = m * c2;
   float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[t][r] = __expf((s[t][r] - m) * scale);
-      sum += s[t][r];
-    }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.f / sum;
-  if (L.g == 0 && q < N) lse[(size_t)bh * N + q] = m * scale + __logf(sum);
-
   f32x16 o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -255,17 +262,32 @@ __global__ __launch_bounds__(NTHREADS) void attn2_fwd_kernel(const bf16* __restr
   const unsigned vt = (unsigned)(size_t)Vs + L.tr0;
   TileLoop<NTILE>::run([&](auto tc) {
     constexpr int t = decltype(tc)::value;
+    if (tile_on<NTOK, t>(N)) {
+      f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[t][r] *= inv;
-    Frag<bf16> vv[4];
-    tfrag4<t>(vt, vv);
-    Frag<bf16> pf = pfrag(s[t], 0);
-    mma(o[0], vv[0], pf);
-    mma(o[1], vv[1], pf);
-    pf = pfrag(s[t], 1);
-    mma(o[0], vv[2], pf);
-    mma(o[1], vv[3], pf);
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mma(acc, rowfrag(Ks, t, L.l31, c, L.g, L.fl), qf[c]);
+      float pr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mc2));
+        if (tile_ragged<NTOK, t>(N) && t * 32 + acc_row(r, L.lane) >= N) pr[r] = 0.f;
+        sum += pr[r];
+      }
+      Frag<bf16> vv[4];
+      tfrag4<t>(vt, vv);
+      Frag<bf16> pf = pfrag(pr, 0);
+      mma(o[0], vv[0], pf);
+      mma(o[1], vv[1], pf);
+      pf = pfrag(pr, 1);
+      mma(o[0], vv[2], pf);
+      mma(o[1], vv[3], pf);
+    }
   });
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  if (L.g == 0 && q < N) lse[(size_t)bh * N + q] = m * scale + __logf(sum);
   if (q < N) {
     bf16* orow = out + ((size_t)b * N + q) * inner + h * HD;
 #pragma unroll
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(NTHREADS) void attn2_fwd_kernel(const bf16* __restr
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         f32x4 v = {o[dt][rq * 4 + 0], o[dt][rq * 4 + 1], o[dt][rq * 4 + 2], o[dt][rq * 4 + 3]};
-        store4<bf16>(orow + dt * 32 + rq * 8 + L.g * 4, v);
+        store4<bf16>(orow + dt * 32 + rq * 8 + L.g * 4, v * inv);
       }
   }
 }
@@ -476,14 +498,6 @@ __global__ __launch_bounds__(NTHREADS) void attn2_bwd_kernel(const bf16* __restr
 // compute waves touch global memory only through 13 coalesced loads per pair: 69 -> 57 us per launch at B = 256.
 // The exponent is one FMA + exp2 (log2 e folded into scale and lse), `scale` multiplies dQ/dK once at the end, lse/D
 // rows are read as float4, and the key/query mask is applied on the ragged last tile only.
-template <int NTOK, int T> __device__ __forceinline__ bool tile_on(int N) {
-  if constexpr (NTOK > 0) return T * 32 < NTOK;
-  else return T * 32 < N;
-}
-template <int NTOK, int T> __device__ __forceinline__ bool tile_ragged(int N) {
-  if constexpr (NTOK > 0) return T * 32 + 32 > NTOK;
-  else return T * 32 + 32 > N;
-}
 
 // NTOK > 0: the token count is a compile-time constant (196 for JPEG-Ti/S): every tile test folds away and only the
 // ragged last tile carries a mask.  (With a runtime N the compiler kept 14 tile predicates and 100+ lane masks alive in
@@ -840,14 +854,19 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
                            hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)attn2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attn2_fwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn2_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD) != hipSuccess)
       return RGBNM_ELAUNCH;
     attr = true;
   }
   const double bhn = (double)B * heads * N;
   const int slot = rgbnm_trace_begin(TR_ATTN_FWD, 4.0 * bhn * N * HD, bhn * HD * 2.0 * 4.0, st);
-  hipLaunchKernelGGL(attn2_fwd_kernel, dim3(B * heads), dim3(NTHREADS), SMEM_FWD, st, (const bf16*)qkv, (bf16*)out, lse,
-                     N, heads, scale);
+  if (N == 196)
+    hipLaunchKernelGGL(attn2_fwd_kernel<196>, dim3(B * heads), dim3(NTHREADS), SMEM_FWD, st, (const bf16*)qkv, (bf16*)out,
+                       lse, N, heads, scale);
+  else
+    hipLaunchKernelGGL(attn2_fwd_kernel<0>, dim3(B * heads), dim3(NTHREADS), SMEM_FWD, st, (const bf16*)qkv, (bf16*)out, lse,
+                       N, heads, scale);
   rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
