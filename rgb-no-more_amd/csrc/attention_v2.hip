@@ -843,7 +843,156 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
   }
 }
 
+// ------------------------------------------------------------------------ forward, persistent
+// The backward's recipe applied to the forward: <= 256 workgroups walk the (image, head) pairs; K,V are double buffered
+// (4 x 28 KB) and a DMA wave fetches the next pair's while the 7 compute waves work on the current one -- ONE barrier
+// per pair: "K,V of this pair have landed" / "every compute wave has left the previous pair (its buffer is free)".
+// A compute wave's own Q rows come as 4 coalesced loads issued a pair ahead and are turned into fragments through its
+// private LDS tile; the same tile takes the output rows, which leave as whole 128-byte lines.
+template <int NTOK>
+__global__ __launch_bounds__(NTHREADS3) void attn3_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                             float* __restrict__ lse, int N_rt, int heads, int nbh,
+                                                             float scale) {
+  const int N = NTOK > 0 ? NTOK : N_rt;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int inner = heads * HD, ld = 3 * inner;
+  const LaneGeo L = lane_geo();
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bh = blockIdx.x;
+  if (bh >= nbh) return;
+
+  if (w == NTILE) {                                     // ---- DMA wave
+    auto issue_kv = [&](int p, int buf) {
+      const bf16* Q = qkv + (size_t)(p / heads) * N * ld + (p % heads) * HD;
+      dma_matrix_all(Q + inner, ld, N, smem + buf * 2 * ARR, L.lane);
+      dma_matrix_all(Q + 2 * inner, ld, N, smem + buf * 2 * ARR + ARR, L.lane);
+    };
+    int buf = 0;
+    issue_kv(bh, 0);
+    for (; bh < nbh; bh += gridDim.x) {
+      const int nxt = bh + gridDim.x;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf ^= 1;
+      if (nxt < nbh) issue_kv(nxt, buf);
+    }
+    return;
+  }
+
+  unsigned char* stg = smem + 4 * ARR + w * STG_WAVE;
+  const int q = w * 32 + L.l31;
+  const bool active = w * 32 < N;
+  const float c2 = scale * 1.4426950408889634f;
+  u32x4 qraw[4];
+  auto load_own = [&](int p) {
+    const int lane_ = lane_id_here();
+    const int b = p / heads, h = p % heads;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int r = w * 32 + i * 8 + (lane_ >> 3);
+      r = r < N ? r : N - 1;
+      qraw[i] = *reinterpret_cast<const u32x4*>(qkv + ((size_t)b * N + r) * ld + h * HD + (lane_ & 7) * 8);
+    }
+  };
+  if (active) load_own(bh);
+  int buf = 0;
+  for (; bh < nbh; bh += gridDim.x) {
+    const int b = bh / heads, h = bh % heads;
+    const int nxt = bh + gridDim.x;
+    const unsigned char* Ks = smem + buf * 2 * ARR;
+    const unsigned char* Vs = Ks + ARR;
+    buf ^= 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own Q rows (and the previous pair's stores)
+    __builtin_amdgcn_s_barrier();
+    if (!active) continue;
+    Frag<bf16> qf[4];
+    {
+      const int rl = L.lane >> 3, seg = L.lane & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = qraw[i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        qf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (nxt < nbh) load_own(nxt);
+    unsigned rb = (unsigned)(L.l31 * ROWB + ((L.g ^ L.fl) << 4)), tr = L.tr0;
+    asm volatile("" : "+v"(rb), "+v"(tr));
+
+    float m = -INFINITY;
+    TileLoop<NTILE>::run([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if (tile_on<NTOK, t>(N)) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mma(acc, rowfrag_x(Ks, rb, t, c), qf[c]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[r];
+          if (tile_ragged<NTOK, t>(N) && t * 32 + acc_row(r, L.lane) >= N) v = -INFINITY;
+          m = fmaxf(m, v);
+        }
+      }
+    });
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mc2 = m * c2;
+    float sum = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    const unsigned vt = (unsigned)(size_t)Vs + tr;
+    TileLoop<NTILE>::run([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if (tile_on<NTOK, t>(N)) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mma(acc, rowfrag_x(Ks, rb, t, c), qf[c]);
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pr[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mc2));
+          if (tile_ragged<NTOK, t>(N) && t * 32 + acc_row(r, L.lane) >= N) pr[r] = 0.f;
+          sum += pr[r];
+        }
+        Frag<bf16> vv[4];
+        tfrag4<t>(vt, vv);
+        Frag<bf16> pf = pfrag(pr, 0);
+        mma(o[0], vv[0], pf);
+        mma(o[1], vv[1], pf);
+        pf = pfrag(pr, 1);
+        mma(o[0], vv[2], pf);
+        mma(o[1], vv[3], pf);
+      }
+    });
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (L.g == 0 && q < N) lse[(size_t)bh * N + q] = m * scale + __logf(sum);
+    // output rows: private tile -> 4 stores of whole lines
+    tile_park_private(stg, o, inv, L);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int lane_ = lane_id_here();
+      const int rl = lane_ >> 3, seg = lane_ & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = i * 8 + rl;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * STG_PITCH + seg * 16);
+        if (w * 32 + r < N)
+          *reinterpret_cast<u32x4*>(out + ((size_t)b * N + w * 32 + r) * inner + h * HD + seg * 8) = v;
+      }
+    }
+  }
+}
+
 constexpr int SMEM_FWD = 2 * ARR;
+constexpr int SMEM_FWD3 = 4 * ARR + NTILE * STG_WAVE;
 #define ATTN_PROF_END 1
 constexpr int SMEM_BWD = 4 * ARR + 2 * NPAD * (int)sizeof(float);
 constexpr int SMEM_BWD3 = SMEM_BWD + NTILE * STG_WAVE;      // + the per-wave store tiles of attn3_bwd_kernel
@@ -861,7 +1010,22 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
   }
   const double bhn = (double)B * heads * N;
   const int slot = rgbnm_trace_begin(TR_ATTN_FWD, 4.0 * bhn * N * HD, bhn * HD * 2.0 * 4.0, st);
-  if (N == 196)
+  if (rgbnm_get_option("attn_persist") && B * heads >= 256) {
+    static bool attr3 = false;
+    if (!attr3) {
+      if (hipFuncSetAttribute((const void*)attn3_fwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD3) != hipSuccess ||
+          hipFuncSetAttribute((const void*)attn3_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD3) != hipSuccess)
+        return RGBNM_ELAUNCH;
+      attr3 = true;
+    }
+    const int nbh = B * heads;
+    if (N == 196)
+      hipLaunchKernelGGL(attn3_fwd_kernel<196>, dim3(256), dim3(NTHREADS3), SMEM_FWD3, st, (const bf16*)qkv, (bf16*)out, lse, N,
+                         heads, nbh, scale);
+    else
+      hipLaunchKernelGGL(attn3_fwd_kernel<0>, dim3(256), dim3(NTHREADS3), SMEM_FWD3, st, (const bf16*)qkv, (bf16*)out, lse, N,
+                         heads, nbh, scale);
+  } else if (N == 196)
     hipLaunchKernelGGL(attn2_fwd_kernel<196>, dim3(B * heads), dim3(NTHREADS), SMEM_FWD, st, (const bf16*)qkv, (bf16*)out,
                        lse, N, heads, scale);
   else
