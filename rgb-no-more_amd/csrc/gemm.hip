@@ -275,9 +275,11 @@ int launch_nt_sel(const GemmNT& p, int epi, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     const bool ok = !p.c_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!p.R || p.ldr % 8 == 0) &&
                     (!p.C2 || p.ldc2 % 8 == 0) && rgbnm_get_option("nt_staged");
-    if (ok && !p.pos && !p.C2 && rgbnm_get_option("nt_kpipe")) {
-      // N = 192 with a long reduction: one row panel per CU, k-tiles through an LDS-DMA ring (gemm_nt_kpipe.hip)
-      const int rc = rgbnm_launch_nt_kpipe(epi, p.A, p.lda, p.W, p.ldw, p.C, p.ldc, p.bias, p.R, p.ldr, p.M, p.N, p.K, st);
+    if (ok && !p.pos && rgbnm_get_option("nt_kpipe")) {
+      // N % 192 == 0 with a long reduction (K >= 256): 224-row panels x 192-column tiles, k-tiles through an LDS-DMA ring
+      // (gemm_nt_kpipe.hip); N = 192: one row panel per CU
+      const int rc = rgbnm_launch_nt_kpipe(epi, p.A, p.lda, p.W, p.ldw, p.C, p.ldc, p.bias, p.R, p.ldr, p.C2, p.ldc2, p.M,
+                                           p.N, p.K, st);
       if (rc != 1) return rc;
     }
     if (ok && !p.pos && rgbnm_get_option("nt_wres")) {

@@ -30,7 +30,7 @@ constexpr int NVEC = (BM * (BN / 8) + NTHREADS - 1) / NTHREADS;      // 12 outpu
 static_assert(BM * CP * 2 <= NSTAGE * STAGE, "staging tile lives in the ring");
 static_assert(SMEM <= 160 * 1024, "LDS");
 
-enum { EPI_NONE = 0, EPI_RES = 1, EPI_LNBWD = 2, EPI_RES_LN = 3 };
+enum { EPI_NONE = 0, EPI_RES = 1, EPI_LNBWD = 2, EPI_RES_LN = 3, EPI_GELU = 4, EPI_DGELU = 5 };
 constexpr int LN_E = 192, LN_GROUPS = NTHREADS / 16, LN_ITERS = BM / LN_GROUPS;   // 28 row groups of 16 lanes, 8 rounds
 constexpr int RED_OFF = 90112;                // column-reduction scratch behind the staging tile
 static_assert(BM * CP * 2 <= RED_OFF && RED_OFF + LN_GROUPS * (LN_E + 4) * 4 <= NSTAGE * STAGE, "LN scratch");
@@ -39,6 +39,8 @@ struct KpArgs {
   const bf16* A; const bf16* W; bf16* C; const float* bias; const bf16* R;
   int lda, ldw, ldc, ldr;
   int M, K, rows_per_wg, npanels;
+  int ntiles;                  // N / 192 column tiles (LayerNorm epilogues: 1); block -> (panel, tile) map is XCD aware
+  bf16* C2; int ldc2;          // EPI_GELU: C = gelu(u), C2 = gelu'(u);  EPI_DGELU: C = (A.W^T) * R
   // EPI_LNBWD: C = [R +] LayerNorm'(A.W^T) w.r.t. its input X (saved mean / rstd), partial dgamma/dbeta per panel
   const bf16* X; const float* gamma; const float* mean; const float* rstd; float* part;
   int ldx;
@@ -60,7 +62,12 @@ template <int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Bs = reinterpret_cast<float*>(smem + BIAS_OFF);
-  const int panel = blockIdx.x;
+  // blocks that share an A row panel (its column tiles) are neighbours on one XCD (block b runs on XCD b % 8): the
+  // panel's k-tiles come from HBM once and from that XCD's L2 for the other tiles
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int panel = (jj / p.ntiles) * 8 + xcd;
+  if (panel >= p.npanels) return;
+  const int n0 = (jj % p.ntiles) * BN;
   const int m0 = panel * p.rows_per_wg;
   const int rows = min(p.rows_per_wg, p.M - m0);          // valid rows of this panel (<= 224)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -69,12 +76,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
 
   // ---- residual rows of this panel, straight into registers (oldest loads: they never delay a k-tile wait)
   bf16x8 rv[NVEC];
-  if (EPI == EPI_RES) {
+  if (EPI == EPI_RES || EPI == EPI_DGELU) {
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int idx = tid + NTHREADS * i, row = idx / (BN / 8), vec = idx % (BN / 8);
       const int rr = row < rows ? row : rows - 1;
-      rv[i] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)(m0 + rr) * p.ldr + vec * 8);
+      rv[i] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)(m0 + rr) * p.ldr + n0 + vec * 8);
     }
   }
   // EPI_LNBWD: the LayerNorm input rows, their statistics and the residual gradient, also ahead of the loop
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
     }
   }
   if (w < BN / 64) {
-    if (p.bias) __builtin_amdgcn_global_load_lds((glb_ptr)(p.bias + 64 * w + lane), (lds_ptr)(Bs + 64 * w), 4, 0, 0);
+    if (p.bias) __builtin_amdgcn_global_load_lds((glb_ptr)(p.bias + n0 + 64 * w + lane), (lds_ptr)(Bs + 64 * w), 4, 0, 0);
     else Bs[64 * w + lane] = 0.f;
   }
 
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
       src[j] = p.A + (size_t)(m0 + rr) * p.lda + lc * 8;
       dst[j] = i * 1024;
     } else {
-      src[j] = p.W + (size_t)r8 * p.ldw + lc * 8;
+      src[j] = p.W + (size_t)(n0 + r8) * p.ldw + lc * 8;
       dst[j] = A_STAGE + (i - 28) * 1024;
     }
   }
@@ -328,7 +335,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) cv[e] = (bf16)((float)cv[e] + (float)rv[i][e]);
     }
-    *reinterpret_cast<bf16x8*>(p.C + (size_t)(m0 + row) * p.ldc + vec * 8) = cv;
+    if (EPI == EPI_DGELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cv[e] = (bf16)((float)cv[e] * (float)rv[i][e]);
+    }
+    if (EPI == EPI_GELU) {     // one erfc / exp2 evaluation yields gelu(u) (-> C) and gelu'(u) (-> C2), as in gemm.hip
+      bf16x8 dv;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f32x2 u = {(float)cv[e], (float)cv[e + 1]};
+        f32x2 gv, dgv;
+        gelu_pair_fast(u, gv, dgv);
+        dv[e] = (bf16)dgv[0];
+        dv[e + 1] = (bf16)dgv[1];
+        cv[e] = (bf16)gv[0];
+        cv[e + 1] = (bf16)gv[1];
+      }
+      *reinterpret_cast<bf16x8*>(p.C2 + (size_t)(m0 + row) * p.ldc2 + n0 + vec * 8) = dv;
+    }
+    *reinterpret_cast<bf16x8*>(p.C + (size_t)(m0 + row) * p.ldc + n0 + vec * 8) = cv;
   }
 }
 
@@ -341,7 +366,7 @@ int launch(const KpArgs& p, hipStream_t st) {
       return RGBNM_ELAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kpipe_kernel<EPI>), dim3(p.npanels), dim3(NTHREADS), SMEM, st, p);
+  hipLaunchKernelGGL((gemm_nt_kpipe_kernel<EPI>), dim3(cdiv(p.npanels, 8) * 8 * p.ntiles), dim3(NTHREADS), SMEM, st, p);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
@@ -358,6 +383,7 @@ int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw,
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
   p.X = nullptr; p.mean = p.rstd = nullptr; p.part = nullptr; p.ldx = 0;
   p.gamma = gamma; p.beta = beta; p.Y2 = (bf16*)y; p.mean_o = mean; p.rstd_o = rstd; p.eps = eps; p.ldy2 = ldy;
+  p.ntiles = 1; p.C2 = nullptr; p.ldc2 = 0;
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;
   p.rows_per_wg = rows;
@@ -381,6 +407,7 @@ int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, 
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
   p.X = (const bf16*)X; p.gamma = gamma; p.mean = mean; p.rstd = rstd; p.part = part; p.ldx = ldx;
   p.beta = nullptr; p.Y2 = nullptr; p.mean_o = p.rstd_o = nullptr; p.eps = 0.f; p.ldy2 = 0;
+  p.ntiles = 1; p.C2 = nullptr; p.ldc2 = 0;
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;
   p.rows_per_wg = rows;
@@ -395,24 +422,30 @@ int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, 
 
 // returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
-                          const void* R, int ldr, int M, int N, int K, hipStream_t st) {
-  if (N != BN || K % 64 || K < 256 || lda % 8 || ldw % 8 || ldc % 8 || M < 8192) return 1;
-  if (epi != EPI_NONE && epi != EPI_RES) return 1;
-  if (epi == EPI_RES && (!R || ldr % 8)) return 1;
+                          const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st) {
+  // epi uses the numbering of gemm.hip: 0 none, 1 residual, 2 GELU (+ GELU' into C2), 4 dGELU product
+  if (N % BN || K % 64 || K < 256 || lda % 8 || ldw % 8 || ldc % 8 || M < 8192) return 1;
+  if (epi != 0 && epi != 1 && epi != 2 && epi != 4) return 1;
+  if ((epi == 1 || epi == 4) && (!R || ldr % 8)) return 1;
+  if (epi == 2 && (!C2 || ldc2 % 8)) return 1;
   KpArgs p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)C; p.bias = bias; p.R = (const bf16*)R;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;
   p.X = nullptr; p.gamma = p.mean = p.rstd = nullptr; p.part = nullptr; p.ldx = 0;
   p.beta = nullptr; p.Y2 = nullptr; p.mean_o = p.rstd_o = nullptr; p.eps = 0.f; p.ldy2 = 0;
-  // one panel per CU when it fits (M / 256 rows, at most 224); otherwise whole rounds of 224-row panels
-  int rows = cdiv(M, 256);
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2;
+  p.ntiles = N / BN;
+  // N = 192: one panel per CU when it fits (M / 256 rows, at most 224: one balanced round).  Several column tiles: full
+  // 224-row panels (the workgroup's arithmetic intensity against the L2 -> CU fabric is what bounds these shapes)
+  int rows = p.ntiles == 1 ? cdiv(M, 256) : BM;
   if (rows > BM) rows = BM;
   p.rows_per_wg = rows;
   p.npanels = cdiv(M, rows);
   const double mn = (double)M * N;
   const int slot = rgbnm_trace_begin(TR_NT, 2.0 * mn * K, ((double)M * K + (double)N * K) * 2.0 + mn * 2.0 +
-                                                              (epi != EPI_NONE ? mn * 2.0 : 0.0), st);
-  const int rc = epi == EPI_RES ? launch<EPI_RES>(p, st) : launch<EPI_NONE>(p, st);
+                                                              (epi != 0 ? mn * 2.0 : 0.0), st);
+  const int rc = epi == 1 ? launch<EPI_RES>(p, st) : epi == 2 ? launch<EPI_GELU>(p, st)
+               : epi == 4 ? launch<EPI_DGELU>(p, st) : launch<EPI_NONE>(p, st);
   rgbnm_trace_end(slot, st);
   return rc;
 }

@@ -397,6 +397,30 @@ def test_gemm_nt_bf16_row_panel_path(option, M, K):
         assert torch.equal(gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], outs[1][2])
 
 
+@pytest.mark.parametrize("M,N,K", [(224 * 40 + 17, 384, 384), (50176, 1152, 384), (12544, 1536, 384), (9000, 384, 1536)])
+def test_gemm_nt_bf16_row_panel_column_tiles(option, M, N, K):
+    """N a multiple of 192 (JPEG-S: 384 / 1152 / 1536 wide Linears): the row-panel kernel walks 224-row panels x
+    192-column tiles, with the residual, GELU (+ GELU') and dGELU epilogues.  Same bits as the tile-per-workgroup kernel
+    (same k order and rounding points), ragged last panel included."""
+    dt = torch.bfloat16
+    A = dev(detfill.normalish((M, K), 51), dt)
+    W = dev(detfill.uniform((N, K), 52, -0.1, 0.1), dt)
+    b = dev(detfill.uniform((N,), 53))
+    R = dev(detfill.normalish((M, N), 54), dt)
+    outs = {}
+    for kp in (0, 1):
+        option("nt_kpipe", kp)
+        g = gemm_nt(dt, L.EPI_GELU, A, W, b)
+        outs[kp] = [gemm_nt(dt, L.EPI_NONE, A, W, b)[0], gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], g[0], g[1],
+                    gemm_nt(dt, L.EPI_DGELU, A, W, None, R=R)[0]]
+        sync()
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    base = A.float() @ W.float().T
+    assert relerr(outs[1][0], base + b) < 4e-3
+    assert relerr(outs[1][4], base * R.float()) < 8e-3
+
+
 @pytest.mark.parametrize("persist", [0, 1])
 def test_attention_bf16_backward_schedules(option, persist):
     """attn_persist=1: persistent backward (several (image, head) pairs per workgroup, operands prefetched a phase
