@@ -161,6 +161,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_wres_kernel(WresArgs p) {
   int pstep = 0;
 #endif
 
+#ifdef WRES_SIXWAVES
+  if (w == 6) return;
+#endif
   while (t < tend) {
     // park the tile in the private buffer (previous tile's staging reads are older LDS instructions of this wave:
     // LDS executes a wave in order), then immediately refill the registers with the tile after it
