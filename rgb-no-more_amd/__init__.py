@@ -13,3 +13,4 @@ from . import dct_manip  # noqa: F401,E402
 from . import parallel  # noqa: F401,E402
 from . import swinv2  # noqa: F401,E402
 from .swinv2 import SwinTransformerV2  # noqa: F401,E402
+from . import eval  # noqa: F401,E402,A004
