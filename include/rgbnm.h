@@ -36,8 +36,14 @@ extern "C" {
 #define RGBNM_EPI_DTANH 6  /* C = (A.W^T) * (1 - R^2)                                             */
 
 int rgbnm_abi_version(void);
-/* runtime switches (A/B testing, profiling): "nt_staged" (coalesced LDS-staged GEMM epilogue, default 1),
- * "tn_tr" (ds_read_b64_tr_b16 fragment loads in the weight-gradient GEMM, default 1), "trace" (0). */
+/* runtime switches (A/B testing, profiling; every alternative path is parity-tested):
+ *   "nt_staged" 1   coalesced LDS-staged GEMM epilogue          "nt_wres"  1  weight-resident persistent NT GEMM (K = 192)
+ *   "nt_kpipe"  1   row-panel NT GEMM with the k-tile DMA ring   "ln_fuse"  1  LayerNorm fwd / bwd in the GEMM epilogues
+ *   "tn_tr"     1   ds_read_b64_tr_b16 fragments in the dW GEMM  "tn_pipe"  1  pipelined dW GEMM
+ *   "tn_group"  2   dW GEMMs of a block: 0 one per launch, 1 pairs, 2 all four in one launch
+ *   "tn_square" 0   192 x 192 dW tile                            "attn_v2"  1  second-generation attention kernels
+ *   "attn_persist" 1  persistent attention fwd / bwd with a DMA wave (>= 256 (image, head) pairs)
+ *   "trace"     0   see rgbnm_trace_collect                      "tn_wgs" 512  workgroup budget of the generic dW GEMM */
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
 /* With option "trace" = (1 << tag) the launchers bracket kernels of that class with HIP events recorded on the launch
