@@ -43,6 +43,7 @@ int rgbnm_abi_version(void);
  *   "tn_group"  2   dW GEMMs of a block: 0 one per launch, 1 pairs, 2 all four in one launch
  *   "tn_square" 0   192 x 192 dW tile                            "attn_v2"  1  second-generation attention kernels
  *   "attn_persist" 1  persistent attention fwd / bwd with a DMA wave (>= 256 (image, head) pairs)
+ *   "nt_dmawave" 0  row-panel GEMM with a dedicated DMA wave (measured: no gain there)
  *   "trace"     0   see rgbnm_trace_collect                      "tn_wgs" 512  workgroup budget of the generic dW GEMM */
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);

@@ -10,6 +10,7 @@
 // memory -> coalesced 16-byte row pieces, bias and the residual (prefetched into registers before the loop) fused.
 #include "common.h"
 #include "internal.h"
+#include "../../include/rgbnm.h"
 
 namespace {
 
@@ -58,8 +59,11 @@ __device__ __forceinline__ int fswz(int row) {
   return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
+// DMAW: an eighth wave issues every LDS-DMA of the ring (52 per k-tile).  The seven compute waves are barrier-synchronised
+// per k-tile, so their 8 DMA issues each used to fall into the same window -- no MFMA runs while every wave of the CU
+// is stalled in vmem issue (the attention backward showed 700-1000 cycles per instruction in such bursts).
+template <int EPI, bool DMAW>
+__global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Bs = reinterpret_cast<float*>(smem + BIAS_OFF);
   // blocks that share an A row panel (its column tiles) are neighbours on one XCD (block b runs on XCD b % 8): the
@@ -73,6 +77,39 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
+
+  if (DMAW && w == NWAVES) {
+    const int rl = lane >> 3, pc = lane & 7;
+    const int lc0 = (pc ^ fswz(rl)) * 8, lc1 = (pc ^ fswz(rl + 8)) * 8;    // slot i covers rows 8 i + rl: bit 3 = i & 1
+    const int T = p.K / 64;
+    auto issue_all = [&](int stage, int k0) {
+      unsigned char* st = smem + stage * STAGE;
+#pragma unroll 4
+      for (int i = 0; i < BM / 8; ++i) {
+        int r8 = i * 8 + rl;
+        r8 = r8 < rows ? r8 : rows - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(p.A + (size_t)(m0 + r8) * p.lda + ((i & 1) ? lc1 : lc0) + k0),
+                                         (lds_ptr)(st + i * 1024), 16, 0, 0);
+      }
+#pragma unroll 4
+      for (int i = 0; i < BN / 8; ++i)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(p.W + (size_t)(n0 + i * 8 + rl) * p.ldw + ((i & 1) ? lc1 : lc0) + k0),
+                                         (lds_ptr)(st + A_STAGE + i * 1024), 16, 0, 0);
+    };
+    issue_all(0, 0);
+    if (T > 1) issue_all(1, 64);
+    int st_issue = 2;
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");   // k-tile t landed; t + 1 may be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < T) {
+        issue_all(st_issue, (t + 2) * 64);
+        st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
+      }
+    }
+    return;                                  // ended waves drop out of the workgroup barrier
+  }
 
   // ---- residual rows of this panel, straight into registers (oldest loads: they never delay a k-tile wait)
   bf16x8 rv[NVEC];
@@ -164,17 +201,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
 
   const int T = p.K / 64;
   int st_issue = 0, st_comp = 0;
-  issue(0);
-  st_issue = 1;
-  if (T > 1) {
-    issue(1);
-    st_issue = 2;
+  if (!DMAW) {
+    issue(0);
+    st_issue = 1;
+    if (T > 1) {
+      issue(1);
+      st_issue = 2;
+    }
   }
   for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!DMAW) {
+      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();        // k-tile t landed for every wave; every wave is done with k-tile t-1
-    if (t + 2 < T) {
+    if (!DMAW && t + 2 < T) {
       issue(st_issue);
       st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
     }
@@ -191,6 +232,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
       for (int b = 0; b < 6; ++b) mma(acc[b], fb[b], fa);     // swapped: D rows <-> features, D cols <-> tokens
     }
   }
+  if (DMAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the bias DMA of waves 0..2 (nothing else waited for it)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();          // every wave is done reading the ring: it becomes the staging tile
 
@@ -357,18 +399,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kpipe_kernel(KpArgs p) {
   }
 }
 
-template <int EPI>
-int launch(const KpArgs& p, hipStream_t st) {
+template <int EPI, bool DMAW>
+int launch_v(const KpArgs& p, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_kpipe_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+    if (hipFuncSetAttribute((const void*)gemm_nt_kpipe_kernel<EPI, DMAW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return RGBNM_ELAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kpipe_kernel<EPI>), dim3(cdiv(p.npanels, 8) * 8 * p.ntiles), dim3(NTHREADS), SMEM, st, p);
+  hipLaunchKernelGGL((gemm_nt_kpipe_kernel<EPI, DMAW>), dim3(cdiv(p.npanels, 8) * 8 * p.ntiles),
+                     dim3(DMAW ? NTHREADS + 64 : NTHREADS), SMEM, st, p);
   LAUNCH_CHECK();
   return RGBNM_OK;
+}
+template <int EPI>
+int launch(const KpArgs& p, hipStream_t st) {
+  return rgbnm_get_option("nt_dmawave") ? launch_v<EPI, true>(p, st) : launch_v<EPI, false>(p, st);
 }
 
 }  // namespace

@@ -395,6 +395,11 @@ def test_gemm_nt_bf16_row_panel_path(option, M, K):
     assert relerr(outs[1][2], base + b + R.float()) < 6e-3
     for _ in range(3):
         assert torch.equal(gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], outs[1][2])
+    # nt_dmawave=1: an eighth wave issues the ring's LDS-DMAs (measured: no faster, the kernel is bounded by the L2 -> CU
+    # fabric, not by vmem issue; kept as a parity-tested alternative)
+    option("nt_dmawave", 1)
+    assert torch.equal(gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], outs[1][2])
+    assert torch.equal(gemm_nt(dt, L.EPI_NONE, A, W, b)[0], outs[1][1])
 
 
 @pytest.mark.parametrize("M,N,K", [(224 * 40 + 17, 384, 384), (50176, 1152, 384), (12544, 1536, 384), (9000, 384, 1536)])
