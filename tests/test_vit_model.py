@@ -282,3 +282,29 @@ def test_embed_type2_fp32_and_bf16_vs_reference_golden(golden, tag, emb, heads):
     gnb = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
     rel = np.abs(gnb - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
     assert np.median(rel) < 2e-2 and rel.max() < 0.15
+
+
+def test_bf16_training_memorises_a_fixed_batch():
+    """Optimisation sanity for the whole fused bf16 path (grouped dW launches, fused LayerNorm epilogues, persistent
+    attention, clip + AdamW + WeightDecay): 60 steps on one fixed batch of 64 images must drive the loss from ln(1000)
+    to well below half of it."""
+    torch.manual_seed(0)
+    m = rg.ViT(3, 16, 192, depth=4, n_classes=1000, drop_p=0.0, device=DEV, num_heads=3, head_size=64,
+               pixel_space="DCT", ver=1, use_subblock=True)
+    m.compute_dtype = torch.bfloat16
+    opt = rg.custom_optims.FusedClipAdamWWD(m, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
+    B = 64
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 91)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 92)).to(DEV)
+    lab = torch.from_numpy(detfill.integers((B,), 93, 0, 999, np.int64)).to(DEV)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad(set_to_none=True)
+        loss = rg.cls_transforms.cross_entropy(m(y, c), lab, grad_dtype=torch.bfloat16)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print("loss: first %.3f  step 20 %.3f  last %.3f" % (losses[0], losses[20], losses[-1]))
+    assert abs(losses[0] - np.log(1000)) < 0.3
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.5 * losses[0]
