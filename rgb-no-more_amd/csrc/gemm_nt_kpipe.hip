@@ -32,9 +32,17 @@ static_assert(BM * CP * 2 <= NSTAGE * STAGE, "staging tile lives in the ring");
 static_assert(SMEM <= 160 * 1024, "LDS");
 
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_LNBWD = 2, EPI_RES_LN = 3, EPI_GELU = 4, EPI_DGELU = 5 };
-constexpr int LN_E = 192, LN_GROUPS = NTHREADS / 16, LN_ITERS = BM / LN_GROUPS;   // 28 row groups of 16 lanes, 8 rounds
+// LayerNorm epilogues: 8 lanes per row, lane l8 holds elements v * 64 + l8 * 8 + (0..7), v = 0..2 -- three 16-byte vectors,
+// so rows move as 16 B per lane (half the vmem instructions of the 16-lane / 8-byte layout of layernorm.hip; in these
+// epilogues every wave of the CU stores at once and a store costs ~200 cycles to issue).  Each lane plays the two
+// "virtual" lanes 2 l8 and 2 l8 + 1 of the 16-lane layout and the reductions follow that butterfly (xor 8, 4, 2 across
+// lanes, xor 1 inside the lane), so statistics and outputs keep the bits of ln_fwd_kernel / ln_bwd_kernel.
+constexpr int LN_E = 192, LN_GROUPS = NTHREADS / 8, LN_ITERS = BM / LN_GROUPS;   // 56 row groups of 8 lanes, 4 rounds
+// (EPI_LNBWD keeps the 16-lane layout: with one output it issues half the stores of EPI_RES_LN, and the 8-lane form needs
+// 48 more accumulator registers for dgamma / dbeta -- measured slower)
+constexpr int LB_GROUPS = NTHREADS / 16, LB_ITERS = BM / LB_GROUPS;              // 28 row groups of 16 lanes, 8 rounds
 constexpr int RED_OFF = 90112;                // column-reduction scratch behind the staging tile
-static_assert(BM * CP * 2 <= RED_OFF && RED_OFF + LN_GROUPS * (LN_E + 4) * 4 <= NSTAGE * STAGE, "LN scratch");
+static_assert(BM * CP * 2 <= RED_OFF && RED_OFF + LB_GROUPS * (LN_E + 4) * 4 <= NSTAGE * STAGE, "LN scratch");
 
 struct KpArgs {
   const bf16* A; const bf16* W; bf16* C; const float* bias; const bf16* R;
@@ -53,6 +61,15 @@ __device__ __forceinline__ float group16_sum(float v) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// sum over the 16 virtual lanes of a row: s0 / s1 = partial sums of virtual lanes 2 l8 / 2 l8 + 1
+__device__ __forceinline__ float group8_pair_sum(float s0, float s1) {
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  return s0 + s1;
 }
 
 __device__ __forceinline__ int fswz(int row) {
@@ -121,32 +138,29 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
       rv[i] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)(m0 + rr) * p.ldr + n0 + vec * 8);
     }
   }
-  // EPI_LNBWD: the LayerNorm input rows, their statistics and the residual gradient, also ahead of the loop
-  const int l16 = tid & 15, grp = tid >> 4;
-  bf16x4 lx[LN_ITERS][3], lr[LN_ITERS][3];
-  float lmu[LN_ITERS], lrs[LN_ITERS];
-  f32x4 gm[3];
-  f32x4 bt[3];
-  if (EPI == EPI_RES_LN) {     // residual rows in the 16-lanes-per-row layout of the LayerNorm pass
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      gm[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
-      bt[v] = *reinterpret_cast<const f32x4*>(p.beta + (v * 16 + l16) * 4);
-    }
+  // EPI_RES_LN: residual rows in the 8-lanes-per-row layout of its LayerNorm pass (gamma / beta: after the loop)
+  const int l8 = tid & 7, grp = tid >> 3;
+  bf16x8 lr[LN_ITERS][3];
+  if (EPI == EPI_RES_LN) {
 #pragma unroll
     for (int it = 0; it < LN_ITERS; ++it) {
       const int row = it * LN_GROUPS + grp, rr = m0 + (row < rows ? row : rows - 1);
 #pragma unroll
       for (int v = 0; v < 3; ++v)
-        lr[it][v] = *reinterpret_cast<const bf16x4*>(p.R + (size_t)rr * p.ldr + (v * 16 + l16) * 4);
+        lr[it][v] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)rr * p.ldr + v * 64 + l8 * 8);
     }
   }
+  // EPI_LNBWD (16 lanes per row): the LayerNorm input rows, their statistics and gamma, also ahead of the loop
+  const int l16 = tid & 15, grp16 = tid >> 4;
+  bf16x4 lx[LB_ITERS][3], lrb[LB_ITERS][3];
+  float lmu[LB_ITERS], lrs[LB_ITERS];
+  f32x4 gmb[3];
   if (EPI == EPI_LNBWD) {
 #pragma unroll
-    for (int v = 0; v < 3; ++v) gm[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
+    for (int v = 0; v < 3; ++v) gmb[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
 #pragma unroll
-    for (int it = 0; it < LN_ITERS; ++it) {
-      const int row = it * LN_GROUPS + grp, rr = m0 + (row < rows ? row : rows - 1);
+    for (int it = 0; it < LB_ITERS; ++it) {
+      const int row = it * LB_GROUPS + grp16, rr = m0 + (row < rows ? row : rows - 1);
       lmu[it] = p.mean[rr];
       lrs[it] = p.rstd[rr];
 #pragma unroll
@@ -248,55 +262,71 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
       v += *reinterpret_cast<const f32x4*>(Bs + nl);
       store4<bf16>(Cs + ml * CP + nl, v);
     }
+  f32x4 gm[3][2], bt[3][2];        // EPI_RES_LN: gamma / beta of this lane's 24 elements, requested now (accumulators dead)
+  if (EPI == EPI_RES_LN) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        gm[v][hf] = *reinterpret_cast<const f32x4*>(p.gamma + v * 64 + l8 * 8 + hf * 4);
+        bt[v][hf] = *reinterpret_cast<const f32x4*>(p.beta + v * 64 + l8 * 8 + hf * 4);
+      }
+  }
   if (EPI == EPI_LNBWD && p.R) {   // residual gradient rows: requested now (the accumulators are dead), used below
 #pragma unroll
-    for (int it = 0; it < LN_ITERS; ++it) {
-      const int row = it * LN_GROUPS + grp, rr = m0 + (row < rows ? row : rows - 1);
+    for (int it = 0; it < LB_ITERS; ++it) {
+      const int row = it * LB_GROUPS + grp16, rr = m0 + (row < rows ? row : rows - 1);
 #pragma unroll
       for (int v = 0; v < 3; ++v)
-        lr[it][v] = *reinterpret_cast<const bf16x4*>(p.R + (size_t)rr * p.ldr + (v * 16 + l16) * 4);
+        lrb[it][v] = *reinterpret_cast<const bf16x4*>(p.R + (size_t)rr * p.ldr + (v * 16 + l16) * 4);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (EPI == EPI_RES_LN) {
-    // ---- residual add, then LayerNorm forward of the finished rows (same arithmetic as ln_fwd_kernel)
+    // ---- residual add, then LayerNorm forward of the finished rows: the arithmetic of ln_fwd_kernel (layernorm.hip) --
+    // same operations, same summation order, contraction off and every FMA explicit -- so both produce the same bits
+#pragma clang fp contract(off)
 #pragma unroll
     for (int it = 0; it < LN_ITERS; ++it) {
       const int row = it * LN_GROUPS + grp;
       if (row < rows) {
-        f32x4 xv[3];
-        float sm = 0.f;
+        float xv[3][8];
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-          const bf16x4 cb = *reinterpret_cast<const bf16x4*>(Cs + row * CP + (v * 16 + l16) * 4);
-          bf16x4 xb;
+          const bf16* cp = Cs + row * CP + v * 64 + l8 * 8;            // 8-byte aligned (CP * 2 = 392)
+          const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(cp), c1 = *reinterpret_cast<const bf16x4*>(cp + 4);
+          bf16x8 xb;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            xb[i] = (bf16)((float)cb[i] + (float)lr[it][v][i]);     // the residual stream is stored in bf16 ...
-            xv[v][i] = (float)xb[i];                                // ... and LayerNorm sees exactly those values
+          for (int i = 0; i < 8; ++i) {
+            xb[i] = (bf16)((float)(i < 4 ? c0[i & 3] : c1[i & 3]) + (float)lr[it][v][i]);   // the residual stream is bf16 ...
+            xv[v][i] = (float)xb[i];                                                       // ... and LayerNorm sees those values
           }
-          *reinterpret_cast<bf16x4*>(p.C + (size_t)(m0 + row) * p.ldc + (v * 16 + l16) * 4) = xb;
-          sm += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+          *reinterpret_cast<bf16x8*>(p.C + (size_t)(m0 + row) * p.ldc + v * 64 + l8 * 8) = xb;
+          s0 += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+          s1 += xv[v][4] + xv[v][5] + xv[v][6] + xv[v][7];
         }
-        const float mu = group16_sum(sm) * (1.f / LN_E);
-        float q = 0.f;
+        const float mu = group8_pair_sum(s0, s1) * (1.f / LN_E);
+        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
         for (int v = 0; v < 3; ++v)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float d = xv[v][i] - mu;
-            q += d * d;
+            const float d0 = xv[v][i] - mu, d1 = xv[v][4 + i] - mu;
+            q0 = __builtin_fmaf(d0, d0, q0);
+            q1 = __builtin_fmaf(d1, d1, q1);
           }
-        const float rs = rsqrtf(group16_sum(q) * (1.f / LN_E) + p.eps);
+        const float rs = rsqrtf(__builtin_fmaf(group8_pair_sum(q0, q1), 1.f / LN_E, p.eps));
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-          f32x4 o;
+          bf16x8 ob;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = (xv[v][i] - mu) * rs * gm[v][i] + bt[v][i];
-          store4<bf16>(p.Y2 + (size_t)(m0 + row) * p.ldy2 + (v * 16 + l16) * 4, o);
+          for (int i = 0; i < 8; ++i)
+            ob[i] = (bf16)__builtin_fmaf((xv[v][i] - mu) * rs, gm[v][i >> 2][i & 3], bt[v][i >> 2][i & 3]);
+          *reinterpret_cast<bf16x8*>(p.Y2 + (size_t)(m0 + row) * p.ldy2 + v * 64 + l8 * 8) = ob;
         }
-        if (l16 == 0) {
+        if (l8 == 0) {
           p.mean_o[m0 + row] = mu;
           p.rstd_o[m0 + row] = rs;
         }
@@ -313,8 +343,8 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
       db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int it = 0; it < LN_ITERS; ++it) {
-      const int row = it * LN_GROUPS + grp;
+    for (int it = 0; it < LB_ITERS; ++it) {
+      const int row = it * LB_GROUPS + grp16;
       if (row < rows) {
         const float mu = lmu[it], rs = lrs[it];
         f32x4 xh[3], gv[3];
@@ -326,7 +356,7 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
           for (int i = 0; i < 4; ++i) {
             const float dv = (float)dvb[i];
             xh[v][i] = ((float)lx[it][v][i] - mu) * rs;
-            gv[v][i] = dv * gm[v][i];
+            gv[v][i] = dv * gmb[v][i];
             s1 += gv[v][i];
             s2 += gv[v][i] * xh[v][i];
             dg[v][i] += dv * xh[v][i];
@@ -341,7 +371,7 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
           for (int i = 0; i < 4; ++i) o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2);
           if (p.R) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] += (float)lr[it][v][i];
+            for (int i = 0; i < 4; ++i) o[i] += (float)lrb[it][v][i];
           }
           store4<bf16>(p.C + (size_t)(m0 + row) * p.ldc + (v * 16 + l16) * 4, o);
         }
@@ -354,12 +384,12 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
 #pragma unroll
       for (int v = 0; v < 3; ++v)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[grp * (LN_E + 4) + (v * 16 + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
+        for (int i = 0; i < 4; ++i) red[grp16 * (LN_E + 4) + (v * 16 + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
       __syncthreads();
       for (int e = tid; e < LN_E; e += NTHREADS) {
         float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < LN_GROUPS; ++r) a += red[r * (LN_E + 4) + e];
+        for (int r = 0; r < LB_GROUPS; ++r) a += red[r * (LN_E + 4) + e];
         p.part[((size_t)panel * 2 + pass) * LN_E + e] = a;
       }
     }
@@ -424,7 +454,7 @@ int launch(const KpArgs& p, hipStream_t st) {
 int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* R,
                                  int ldr, void* x, int ldc, const float* gamma, const float* beta, void* y, int ldy,
                                  float* mean, float* rstd, float eps, int M, int N, int K, hipStream_t st) {
-  if (N != BN || K % 64 || K < 128 || lda % 8 || ldw % 8 || ldc % 4 || ldr % 4 || ldy % 4 || M < 8192) return 1;
+  if (N != BN || K % 64 || K < 128 || lda % 8 || ldw % 8 || ldc % 8 || ldr % 8 || ldy % 8 || M < 8192) return 1;
   KpArgs p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = (bf16*)x; p.bias = bias; p.R = (const bf16*)R;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.M = M; p.K = K;

@@ -30,6 +30,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     bt[v] = *reinterpret_cast<const f32x4*>(beta + (v * 16 + l16) * 4);
   }
   for (int row = blockIdx.x * 16 + grp; row < M; row += gridDim.x * 16) {
+    // every fused multiply-add is spelled out and contraction is off: the residual + LayerNorm epilogue of the row-panel
+    // GEMM (gemm_nt_kpipe.hip, EPI_RES_LN) repeats this arithmetic in another lane layout and must produce the same bits
+#pragma clang fp contract(off)
     f32x4 xv[NV];
     float s = 0.f;
 #pragma unroll
@@ -44,14 +47,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float d = xv[v][i] - mu;
-        q += d * d;
+        q = __builtin_fmaf(d, d, q);
       }
-    const float rs = rsqrtf(group16_sum(q) * (1.f / E) + eps);
+    const float rs = rsqrtf(__builtin_fmaf(group16_sum(q), 1.f / E, eps));
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       f32x4 o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (xv[v][i] - mu) * rs * gm[v][i] + bt[v][i];
+      for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf((xv[v][i] - mu) * rs, gm[v][i], bt[v][i]);
       store4<T>(y + (size_t)row * E + (v * 16 + l16) * 4, o);
     }
     if (l16 == 0) {
