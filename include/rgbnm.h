@@ -240,7 +240,8 @@ typedef struct rgbnm_block_scratch {     /* backward temporaries, caller-owned, 
   size_t ws_bytes;
 } rgbnm_block_scratch;
 
-size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* cfg);
+size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* cfg);                      /* heads of up to 1024 classes */
+size_t rgbnm_vit_workspace_ex(const rgbnm_vit_cfg* cfg, int n_classes);    /* any head width (n_classes % 8 == 0) */
 int rgbnm_vit_block_fwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, const rgbnm_block_acts* a,
                         void* stream);
 /* Chained forward over consecutive blocks: when rgbnm_vit_ln_chain(cfg) is 1 the epilogue of this block's fc2 can

@@ -1001,22 +1001,22 @@ constexpr int SMEM_BWD3 = SMEM_BWD + NTILE * STG_WAVE;      // + the per-wave st
 
 int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, float scale,
                            hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static DevOnce attr;
+  if (attr.need()) {
     if (hipFuncSetAttribute((const void*)attn2_fwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD) != hipSuccess ||
         hipFuncSetAttribute((const void*)attn2_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD) != hipSuccess)
       return RGBNM_ELAUNCH;
-    attr = true;
+    attr.done();
   }
   const double bhn = (double)B * heads * N;
   const int slot = rgbnm_trace_begin(TR_ATTN_FWD, 4.0 * bhn * N * HD, bhn * HD * 2.0 * 4.0, st);
   if (rgbnm_get_option("attn_persist") && B * heads >= 256) {
-    static bool attr3 = false;
-    if (!attr3) {
+    static DevOnce attr3;
+    if (attr3.need()) {
       if (hipFuncSetAttribute((const void*)attn3_fwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD3) != hipSuccess ||
           hipFuncSetAttribute((const void*)attn3_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD3) != hipSuccess)
         return RGBNM_ELAUNCH;
-      attr3 = true;
+      attr3.done();
     }
     const int nbh = B * heads;
     if (N == 196)
@@ -1038,21 +1038,21 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
 
 int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
                            int N, int heads, float scale, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static DevOnce attr;
+  if (attr.need()) {
     if (hipFuncSetAttribute((const void*)attn2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD) != hipSuccess)
       return RGBNM_ELAUNCH;
-    attr = true;
+    attr.done();
   }
   const double bhn = (double)B * heads * N;
   const int slot = rgbnm_trace_begin(TR_ATTN_BWD, 10.0 * bhn * N * HD, bhn * HD * 2.0 * 8.0, st);
   if (rgbnm_get_option("attn_persist")) {
-    static bool attr3 = false;
-    if (!attr3) {
+    static DevOnce attr3;
+    if (attr3.need()) {
       if (hipFuncSetAttribute((const void*)attn3_bwd_kernel<196>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD3) != hipSuccess ||
           hipFuncSetAttribute((const void*)attn3_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD3) != hipSuccess)
         return RGBNM_ELAUNCH;
-      attr3 = true;
+      attr3.done();
     }
     const int nbh = B * heads;
     if (N == 196)

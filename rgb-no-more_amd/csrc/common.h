@@ -17,6 +17,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
 
+// "hipFuncSetAttribute already done for this kernel on this device": per function and per device, lock-free.  Racing
+// host threads may both set the (idempotent) attribute; nobody launches before it is set.  Keeps the launchers re-entrant.
+#include <atomic>
+struct DevOnce {
+  std::atomic<unsigned long long> mask{0};
+  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+  bool need() const { return !((mask.load(std::memory_order_acquire) >> dev()) & 1ULL); }
+  void done() { mask.fetch_or(1ULL << dev(), std::memory_order_release); }
+};
+
 #define LAUNCH_CHECK()                                  \
   do {                                                  \
     hipError_t e__ = hipGetLastError();                 \

@@ -518,9 +518,9 @@ int submit_tn_reduce(const GemmTN& p, float* dW, float* db, int S, int perm_head
 
 // deferred (grouped) weight-gradient launches
 struct TnPending { GemmTN p; float* dW; float* db; int perm_heads, accumulate; };
-bool g_tn_defer = false;
-TnPending g_tn_q[4];
-int g_tn_n = 0;
+thread_local bool g_tn_defer = false;     // per host thread, like the reduction queue (reduce.hip)
+thread_local TnPending g_tn_q[4];
+thread_local int g_tn_n = 0;
 
 int tn_flush(hipStream_t st) {
   const int n = g_tn_n;

@@ -431,12 +431,12 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
 
 template <int EPI, bool DMAW>
 int launch_v(const KpArgs& p, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static DevOnce attr;
+  if (attr.need()) {
     if (hipFuncSetAttribute((const void*)gemm_nt_kpipe_kernel<EPI, DMAW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return RGBNM_ELAUNCH;
-    attr = true;
+    attr.done();
   }
   hipLaunchKernelGGL((gemm_nt_kpipe_kernel<EPI, DMAW>), dim3(cdiv(p.npanels, 8) * 8 * p.ntiles),
                      dim3(DMAW ? NTHREADS + 64 : NTHREADS), SMEM, st, p);

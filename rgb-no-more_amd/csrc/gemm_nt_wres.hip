@@ -263,12 +263,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_wres_kernel(WresArgs p) {
 
 template <int EPI>
 int launch(const WresArgs& p, int grid, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static DevOnce attr;
+  if (attr.need()) {
     if (hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return RGBNM_ELAUNCH;
-    attr = true;
+    attr.done();
   }
   hipLaunchKernelGGL((gemm_nt_wres_kernel<EPI>), dim3(grid), dim3(NTHREADS), SMEM, st, p);
   LAUNCH_CHECK();

@@ -377,11 +377,11 @@ int tn_fill(TnPipe& p, const void* dY, int ldy, const void* X, int ldx, float* p
 // jobs[0..n): same M; returns 1 when a job is not eligible (nothing launched), S (common split count) through S_out
 int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st) {
   if (n < 1 || n > TN_MAXJOBS) return RGBNM_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     if (hipFuncSetAttribute((const void*)gemm_tn_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return RGBNM_ELAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   TnGroup g;
   int tiles = 0;
@@ -436,11 +436,11 @@ int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float*
   p.S = S;
   *S_out = S;
   const int slot = rgbnm_trace_begin(TR_TN, 2.0 * M * (double)No * Ki, ((double)M * No + (double)M * Ki) * 2.0 + (double)No * Ki * 4.0, st);
-  static bool attr_q = false;
-  if (!attr_q) {
+  static DevOnce attr_q;
+  if (attr_q.need()) {
     if (hipFuncSetAttribute((const void*)gemm_tn_pipe_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM) != hipSuccess)
       return RGBNM_ELAUNCH;
-    attr_q = true;
+    attr_q.done();
   }
   hipLaunchKernelGGL(gemm_tn_pipe_q_kernel, dim3(tiles * ((S + 7) / 8) * 8), dim3(384), Q_SMEM, st, p);
   rgbnm_trace_end(slot, st);

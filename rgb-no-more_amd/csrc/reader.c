@@ -86,8 +86,16 @@ static int read_impl(FILE* fp, const unsigned char* mem, size_t memlen, int32_t*
       return RD_ESHAPE;
     }
   }
+  /* CbCr is ONE [2][Hbc][Wbc] tensor sized from component 1 (dct_manip.py; reference dct_manip.cpp:112-117 does the
+   * same and overruns): component 2 must have component 1's grid, and more than three components have no slot. */
+  if (CbCr && nc >= 3 && (cinfo.comp_info[2].height_in_blocks != cinfo.comp_info[1].height_in_blocks ||
+                          cinfo.comp_info[2].width_in_blocks != cinfo.comp_info[1].width_in_blocks)) {
+    set_err(err, errlen, "Cb and Cr have different block grids (unsupported sampling)");
+    jpeg_destroy_decompress(&cinfo);
+    return RD_ESHAPE;
+  }
   if (dim)
-    for (int c = 0; c < nc; ++c) {
+    for (int c = 0; c < nc && c < 3; ++c) {
       dim[2 * c + 0] = (int32_t)cinfo.comp_info[c].downsampled_height;
       dim[2 * c + 1] = (int32_t)cinfo.comp_info[c].downsampled_width;
     }
@@ -204,9 +212,11 @@ int rgbnm_read_coefficients_batch(const char* const* paths, int n, int threads, 
   if (threads > 256) threads = 256;
   if (threads > n) threads = n;
   pthread_t th[256];
-  for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, batch_worker, &j);
-  batch_worker(&j);
-  for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+  int started[256];
+  for (int t = 1; t < threads; ++t) started[t] = pthread_create(&th[t], NULL, batch_worker, &j) == 0;
+  batch_worker(&j);               /* the caller's thread drains whatever the (possibly fewer) workers leave */
+  for (int t = 1; t < threads; ++t)
+    if (started[t]) pthread_join(th[t], NULL);
   pthread_mutex_destroy(&j.mu);
   int bad = 0;
   for (int i = 0; i < n; ++i) bad += status[i] != 0;

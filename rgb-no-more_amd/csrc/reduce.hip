@@ -13,9 +13,11 @@ struct Jobs {
   RgbnmReduceJob j[MAXJOBS];
 };
 
-bool g_defer = false;
-int g_njobs = 0;
-Jobs g_jobs;
+// the defer bracket opens and closes inside ONE C-ABI call on one host thread: per-thread queues make concurrent calls
+// from other host threads / streams (a second model, an eval pass) independent
+thread_local bool g_defer = false;
+thread_local int g_njobs = 0;
+thread_local Jobs g_jobs;
 
 __device__ __forceinline__ int qkv_row_r(int n, int heads) {     // same map as gemm.hip's qkv_row
   const int inner = heads * 64;

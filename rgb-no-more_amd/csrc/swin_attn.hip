@@ -429,14 +429,14 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
 }
 
 template <typename T> int set_attrs() {
-  static bool done = false;
-  if (done) return RGBNM_OK;
+  static DevOnce done;
+  if (!done.need()) return RGBNM_OK;
   if (hipFuncSetAttribute((const void*)win_attn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           WA<T>::FWD_WAVE * WA<T>::FWD_WAVES) != hipSuccess ||
       hipFuncSetAttribute((const void*)win_attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           WA<T>::BWD_WAVE * WA<T>::BWD_WAVES) != hipSuccess)
     return RGBNM_ELAUNCH;
-  done = true;
+  done.done();
   return RGBNM_OK;
 }
 

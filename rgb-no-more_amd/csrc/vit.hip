@@ -13,9 +13,12 @@
 static inline size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include "internal.h"
 namespace {
+std::mutex g_trace_mu;                    // trace records / event pool: measurement feature, any thread may launch
 // ---- optional per-kernel timing with HIP events recorded on the launch stream (option "trace" = bit mask of tags)
 struct TraceRec { hipEvent_t a, b; int tag; double flops, bytes; };
 std::vector<TraceRec> g_recs;
@@ -26,14 +29,17 @@ hipEvent_t take_event() {
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
 }
-struct Opt { const char* name; int value; };
+// process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
+// they select between parity-tested kernels and are meant to be set before work is enqueued
+struct Opt { const char* name; std::atomic<int> value; };
 Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
   int mask = 0;
-  for (auto& o : g_opts) if (!strcmp(o.name, "trace")) mask = o.value;
+  for (auto& o : g_opts) if (!strcmp(o.name, "trace")) mask = o.value.load(std::memory_order_relaxed);
   if (!((mask >> tag) & 1)) return -1;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
   TraceRec r;
   r.a = take_event();
   r.b = take_event();
@@ -44,6 +50,8 @@ int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
   return (int)g_recs.size() - 1;
 }
 void rgbnm_trace_end(int slot, hipStream_t st) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
   if (slot >= 0 && slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, st);
 }
 
@@ -53,18 +61,19 @@ int rgbnm_abi_version(void) { return RGBNM_ABI_VERSION; }
 
 int rgbnm_set_option(const char* name, int value) {
   for (auto& o : g_opts)
-    if (name && !strcmp(o.name, name)) { o.value = value; return RGBNM_OK; }
+    if (name && !strcmp(o.name, name)) { o.value.store(value, std::memory_order_relaxed); return RGBNM_OK; }
   return RGBNM_EINVAL;
 }
 int rgbnm_get_option(const char* name) {
   for (auto& o : g_opts)
-    if (name && !strcmp(o.name, name)) return o.value;
+    if (name && !strcmp(o.name, name)) return o.value.load(std::memory_order_relaxed);
   return -1;
 }
 
 int rgbnm_trace_collect(int tag, double* ms_total, double* flops_total, double* bytes_total, int* count) {
   double ms = 0, fl = 0, by = 0;
   int n = 0;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
   std::vector<TraceRec> keep;
   for (auto& r : g_recs) {
     if (r.tag != tag) { keep.push_back(r); continue; }
@@ -122,15 +131,18 @@ static size_t block_ws_offsets(int M, int E, int I, size_t (&off)[7]) {
   return off[6];
 }
 
-size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* c) {
+size_t rgbnm_vit_workspace(const rgbnm_vit_cfg* c) { return rgbnm_vit_workspace_ex(c, 1024); }
+
+size_t rgbnm_vit_workspace_ex(const rgbnm_vit_cfg* c, int n_classes) {
   if (!c) return 0;
+  if (n_classes < 1024) n_classes = 1024;
   const int M = c->B * c->N, E = c->E, I = c->heads * 64;
   // a block's backward keeps the partials of its four weight-gradient GEMMs and two LayerNorms side by side until
   // the one batched reduction at its end (block_ws_offsets below)
   size_t off[7];
   size_t w = block_ws_offsets(M, E, I, off);
   w = max_sz(w, rgbnm_gemm_tn_workspace(M, E, 384));
-  w = max_sz(w, rgbnm_gemm_tn_workspace(c->B, 1024, E));
+  w = max_sz(w, rgbnm_gemm_tn_workspace(c->B, n_classes, E));
   w = max_sz(w, rgbnm_layernorm_bwd_workspace(M, E));
   w = max_sz(w, (size_t)c->B * 2 * E * sizeof(float));
   return w;

@@ -5,6 +5,9 @@
   (train.py:163-165 / :170-172) as ONE pass over the model's flat fp32 buffers (rgbnm_clip_adamw_wd_step).
   The decayed set follows the reference's name filter (".weight" in name and "lrnorm" not in name,
   pipeline_utils.py:537).  `param_groups[0]['lr']` is honoured, so torch LR schedulers drive it unchanged.
+  `state_dict()` / `load_state_dict()` carry the Adam moments and the step count in torch.optim.AdamW's own layout
+  (state[i] = {step, exp_avg, exp_avg_sq} per parameter), so train.py's checkpoint / resume (train.py:195,
+  pipeline_utils.py:490-580) works, and a checkpoint written by the reference's AdamW loads here (and vice versa).
 """
 import torch
 from torch.optim.optimizer import Optimizer
@@ -49,6 +52,42 @@ class FusedClipAdamWWD(Optimizer):
             self._norm = torch.zeros(1, device=m._flat.device, dtype=torch.float32)
             self._gather = None
             self._state_ready = True
+            self._publish_state()
+
+    def _publish_state(self):
+        """Expose the flat moment buffers as torch.optim.AdamW-style per-parameter state (views, always current)."""
+        m = self._m
+        self.state.clear()
+        for n, p in m._named.items():
+            self.state[p] = {"step": torch.tensor(float(self._step)), "exp_avg": m._gview(self._exp_avg, n),
+                             "exp_avg_sq": m._gview(self._exp_avg_sq, n)}
+
+    def state_dict(self):
+        self._ensure()
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Restore moments + step (written by this class or by torch.optim.AdamW over the same parameter list)."""
+        self._ensure()
+        super().load_state_dict(state_dict)          # validates groups / sizes, casts to the parameter devices
+        m = self._m
+        steps = set()
+        loaded = dict(self.state)
+        for n, p in m._named.items():
+            st = loaded.get(p)
+            if not st:                               # parameter without state (never stepped): zero moments
+                m._gview(self._exp_avg, n).zero_()
+                m._gview(self._exp_avg_sq, n).zero_()
+                continue
+            m._gview(self._exp_avg, n).copy_(st["exp_avg"])
+            m._gview(self._exp_avg_sq, n).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FusedClipAdamWWD keeps ONE step count for all parameters; the state has {sorted(steps)}")
+        self._step = steps.pop() if steps else 0
+        self._publish_state()
 
     def _flat_grads(self):
         """The flat fp32 gradient buffer: zero-copy when every .grad is the view the backward kernels wrote (the

@@ -74,8 +74,21 @@ class RandomResizedCrop_DCT:
                 i = int(torch.randint(0, height - h + 1, size=(1,)).item() // self.chroma_scale * self.chroma_scale)
                 j = int(torch.randint(0, width - w + 1, size=(1,)).item() // self.chroma_scale * self.chroma_scale)
                 return i, j, h, w
-        w = int(_choose_closest(width, self.even_size_choices, width))
-        h = int(_choose_closest(height, self.even_size_choices, height))
+        return self.fallback_box(height, width)
+
+    def fallback_box(self, height, width):
+        """central crop after 10 failed attempts (custom_transforms.py:612-629); ratio == (1, 1)"""
+        in_ratio = float(width) / float(height)
+        if in_ratio < 1:
+            w = width
+            h = int(round(w / 1))
+        elif in_ratio > 1:
+            h = height
+            w = int(round(h * 1))
+        else:
+            w, h = width, height
+        h = int(_choose_closest(h, self.even_size_choices, height))
+        w = int(_choose_closest(w, self.even_size_choices, width))
         i = (height - h) // 2 // self.chroma_scale * self.chroma_scale
         j = (width - w) // 2 // self.chroma_scale * self.chroma_scale
         return i, j, max(1, h), max(1, w)
@@ -328,21 +341,48 @@ class FastParamSampler:
         self.k_drop = names.index("ChromaDrop") if "ChromaDrop" in names else -1
         self.choices = np.array(t.rrc.even_size_choices)
 
-    def sample(self, B, H, W):
-        t, r = self.t, self.rng
-        out = np.zeros(B, dtype=AUG_DTYPE)
-        u = r.uniform(t.rrc.scale[0], t.rrc.scale[1], B).astype(np.float32).astype(np.float64)
-        w = np.rint(np.sqrt(H * W * u))
+    def sides_from_draws(self, u, H, W):
+        u = np.asarray(u, dtype=np.float32).astype(np.float64)
+        w = np.rint(np.sqrt(H * W * u))          # int(round(math.sqrt(.))): half-even on both sides
         size = self.choices[-1]
-        small = w <= size
         near = self.choices[np.abs(self.choices[None, :] - w[:, None]).argmin(1)]
         big = np.rint((w.astype(np.float32) / np.float32(size))).astype(np.int64) * size
         big = np.where(big > W, big - size, big)
-        w = np.maximum(2, np.where(small, near, big)).astype(np.int64)
-        out["crop"][:, 0] = r.integers(0, H - w + 1) // 2 * 2
-        out["crop"][:, 1] = r.integers(0, W - w + 1) // 2 * 2
-        out["crop"][:, 2] = w
-        out["crop"][:, 3] = w
+        return np.maximum(2, np.where(w <= size, near, big)).astype(np.int64)
+
+    def boxes_from_draws(self, u, ri, rj, H, W):
+        """(i, j, h, w) of a FIRST attempt from explicit draws (u: fp32 uniform; ri / rj: the randint draws in
+        [0, H - h] / [0, W - w]); rows whose box does not fit the grid get h = w = -1 (the reference re-draws)."""
+        w = self.sides_from_draws(u, H, W)
+        fit = (w <= W) & (w <= H)
+        box = np.stack([np.asarray(ri) // 2 * 2, np.asarray(rj) // 2 * 2, w, w], axis=1).astype(np.int64)
+        box[~fit] = -1
+        return box
+
+    def sample_boxes(self, B, H, W):
+        """RandomResizedCrop_DCT.get_params for B samples: up to 10 attempts each, then the central-crop fallback."""
+        t, r = self.t, self.rng
+        box = np.full((B, 4), -1, dtype=np.int64)
+        todo = np.arange(B)
+        for _ in range(10):
+            if todo.size == 0:
+                break
+            u = r.uniform(t.rrc.scale[0], t.rrc.scale[1], todo.size).astype(np.float32)
+            w = self.sides_from_draws(u, H, W)
+            fit = (w <= W) & (w <= H)
+            wf = w[fit]
+            ri = r.integers(0, H - wf + 1)
+            rj = r.integers(0, W - wf + 1)
+            box[todo[fit]] = np.stack([ri // 2 * 2, rj // 2 * 2, wf, wf], axis=1)
+            todo = todo[~fit]
+        if todo.size:
+            box[todo] = np.asarray(t.rrc.fallback_box(H, W), dtype=np.int64)
+        return box
+
+    def sample(self, B, H, W):
+        t, r = self.t, self.rng
+        out = np.zeros(B, dtype=AUG_DTYPE)
+        out["crop"] = self.sample_boxes(B, H, W)
         out["flip"] = r.random(B) <= t.flip_p
         nops = t.num_ops if self.names else 0
         prev = None

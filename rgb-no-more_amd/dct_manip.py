@@ -66,6 +66,8 @@ def _read(path=None, data=None):
         _raise(rc, err)
     nc = info[0]
     hb, wb = info[1], info[2]
+    if nc not in (1, 3):
+        raise libjpeg_exception(f"unsupported JPEG: {nc} components (the DCT path reads grayscale or YCbCr files)")
     dim = torch.empty((nc, 2), dtype=torch.int32)
     quant = torch.empty((nc, 8, 8), dtype=torch.int16)
     Y = torch.empty((1, hb, wb, 8, 8), dtype=torch.int16)

@@ -12,7 +12,7 @@ import torch.distributed as dist
 @torch.no_grad()
 def evaluate_model(model, dataloader, criterion=None, device=None, amp_dtype=None, process_group=None, verbose=False):
     """-> (accuracy, loss).  dataloader yields ((Y, CbCr), labels) or (Y, CbCr, labels); tensors are moved to `device`
-    (default: the model's first parameter).  amp_dtype: torch.bfloat16 / float16 for autocast, None for fp32."""
+    (default: the model's first parameter).  amp_dtype: torch.bfloat16 for autocast (float16, the reference's hard-coded eval dtype, eval.py:36, is executed as bfloat16 by the HIP model), None for fp32."""
     if device is None:
         device = next(model.parameters()).device
     device = torch.device(device)

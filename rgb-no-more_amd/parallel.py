@@ -9,9 +9,16 @@ torch.distributed "nccl"; gloo on CPU in the tests), launched from the autograd 
 the exchange of block i overlaps the backward of blocks i-1 .. 0.  No copies, ~7 collectives of >= 4 MB per step.
 
     sync = FlatGradSync(model)            # broadcasts rank 0's parameters, hooks the model
-    loss.backward(); opt.step()           # FusedClipAdamWWD waits for the collectives before reading the gradients
+    loss.backward()                       # returns with every collective ordered before later work on the stream
+    opt.step()                            # any consumer: GradScaler.unscale_, clip_grad_norm_, AdamW, FusedClipAdamWWD
 
-Contract: gradients are cleared with zero_grad(set_to_none=True) (the default) between steps, as in train.py:154.
+Ordering contract: the LAST autograd node of the model (patch embedding) flushes the final slice and makes the backward
+stream wait for every outstanding collective, so once `backward()` has returned the gradients are final in stream order
+-- `gradscaler.unscale_` / `clip_grad_norm_` / the inf check of train.py:159-166 see reduced gradients, exactly as with DDP.
+The overlap is untouched (nothing but the optimizer runs after the last node).  Not supported, and refused loudly:
+gradient accumulation over several backward passes (the second pass writes a fresh buffer that autograd accumulates
+into .grad while a collective would still own it) -- use torch DDP for that.  A backward that died half-way leaves
+collectives in flight; they are drained at the next forward (`begin_step`).
 """
 import torch
 import torch.distributed as dist
@@ -34,8 +41,22 @@ class FlatGradSync:
         module._grad_sync = self
 
     # ---- called from the autograd nodes (plainvit.py) right after a backward kernel group has written `names`
+    def begin_step(self):
+        """Called by the model at the start of a forward that will be differentiated: nothing of an earlier backward
+        may still be in flight when its kernels start rewriting the flat gradient buffer."""
+        if self._handles or self._pending is not None:
+            self._pending = None
+            for h, _seg in self._handles:
+                h.wait()                      # stale gradients: ordered, not rescaled -- they are about to be overwritten
+            self._handles.clear()
+        self._gbuf = None
+
     def ready(self, gbuf, names, last=False):
         m = self.module
+        if gbuf.data_ptr() != m._gflat.data_ptr():
+            raise RuntimeError("FlatGradSync: this backward writes a side gradient buffer, i.e. gradients of an earlier "
+                               "backward are still attached (gradient accumulation / zero_grad(set_to_none=False)); "
+                               "the flat exchange supports one backward per step -- use torch DDP for accumulation")
         lo = min(m._offs[n] for n in names)
         hi = max(m._offs[n] + _numel(m._shapes[n]) for n in names)
         if self._gbuf is not None and self._gbuf.data_ptr() != gbuf.data_ptr():
@@ -47,7 +68,9 @@ class FlatGradSync:
         else:
             self.flush()
             self._pending = (lo, hi)
-        if last or self._pending[1] - self._pending[0] >= self.bucket_elems:
+        if last:
+            self.wait()                       # gradients are final in stream order when backward() returns
+        elif self._pending[1] - self._pending[0] >= self.bucket_elems:
             self.flush()
 
     def flush(self):

@@ -13,6 +13,7 @@ There is no fallback path: without librgbnm.so / a HIP device `forward` raises.
 """
 import ctypes as C
 import math
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -113,7 +114,7 @@ class _Arena:
                                  mean2=e(M, dt=f32), rstd2=e(M, dt=f32), u=e(M, 4 * E), gl=e(M, 4 * E)))
         self.hmean, self.hrstd = e(M, dt=f32), e(M, dt=f32)
         self.pooled, self.h1 = e(B, E), e(B, E)
-        ws_bytes = L.lib().rgbnm_vit_workspace(C.byref(self.cfg))
+        ws_bytes = L.lib().rgbnm_vit_workspace_ex(C.byref(self.cfg), model.n_classes)
         self.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         if need_grad:
             self.du, self.dxn, self.dx_mid = e(M, 4 * E), e(M, E), e(M, E)
@@ -319,6 +320,9 @@ class ViT(FlatParamModule):
             raise NotImplementedError("HIP kernels cover head_size 64 and emb_size 192/384 (JPEG-Ti / JPEG-S)")
         if dtype != torch.float32:
             raise NotImplementedError("parameters are fp32 masters; choose bf16 compute with autocast")
+        if n_classes < 8 or n_classes % 8:
+            raise NotImplementedError(f"n_classes = {n_classes}: the head GEMMs move 16-byte rows, so the class count must "
+                                      "be a multiple of 8 (ImageNet-1k: 1000)")
         self.pixel_space = pixel_space
         self.emb_size, self.depth, self.n_classes = emb_size, depth, n_classes
         self.num_heads, self.inner = num_heads, num_heads * head_size
@@ -466,11 +470,21 @@ class ViT(FlatParamModule):
         cdtype = self.compute_dtype
         if cdtype is None:
             cdtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        if cdtype == torch.float16 and self.compute_dtype is None:
+            # the reference's eval.py:36 hard-codes autocast(float16) whenever --amp is on, also for bf16 training; the
+            # MI355X path has no fp16 kernels: run that forward in bf16 (same 8-bit-exponent-safe range, fp32 accumulate)
+            if not getattr(self, "_warned_fp16", False):
+                warnings.warn("rgb-no-more_amd: float16 autocast requested (reference eval.py:36); running the HIP "
+                              "forward in bfloat16", stacklevel=2)
+                self._warned_fp16 = True
+            cdtype = torch.bfloat16
         if cdtype not in (torch.float32, torch.bfloat16):
             raise NotImplementedError(f"compute dtype {cdtype}: the MI355X path implements fp32 and bf16")
         self._ensure_flat()
         B = x.shape[0]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad and self._grad_sync is not None:
+            self._grad_sync.begin_step()
         self._prep(cdtype)
         arena = self._acquire_arena(B, cdtype, need_grad)
         st = _FwdState(self, arena, self._grad_buffer() if need_grad else None)

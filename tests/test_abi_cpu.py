@@ -52,7 +52,9 @@ def test_state_dict_surface_matches_reference(golden):
 
 
 def test_no_cpu_fallback():
-    m = rg.ViT(3, 16, 192, depth=1, n_classes=10, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
+    m = rg.ViT(3, 16, 192, depth=1, n_classes=16, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
+    with pytest.raises(NotImplementedError, match="multiple of 8"):      # refused at construction, not in head_bwd
+        rg.ViT(3, 16, 192, depth=1, n_classes=10, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
     y = torch.zeros(1, 1, 28, 28, 8, 8)
     c = torch.zeros(1, 2, 14, 14, 8, 8)
     with pytest.raises(L.RgbnmError):

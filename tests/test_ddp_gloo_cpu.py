@@ -52,6 +52,8 @@ class Toy(FlatParamModule):
 
     def forward(self, x):
         self._ensure_flat()
+        if self._grad_sync is not None and torch.is_grad_enabled():
+            self._grad_sync.begin_step()     # same hook as plainvit.ViT.forward
         n = self._named
         return _Fn.apply(x, self, self._grad_buffer(), n["lin.weight"], n["lin.bias"], n["x_lrnorm.weight"],
                          n["x_lrnorm.bias"])
@@ -112,11 +114,30 @@ def _worker(rank, world, port, out):
     assert torch.equal(torch.cat([p.detach().reshape(-1) for p in m3.parameters()]),
                        torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
     m3(x).square().mean().backward()
-    sync.wait()
+    # contract: when backward() returns the gradients are final (the last autograd node waited for every collective),
+    # so train.py's gradscaler.unscale_ / clip_grad_norm_ (train.py:160-163) see REDUCED gradients -- no sync.wait() here
+    assert not sync._handles and sync._pending is None
     assert sync.collectives >= 2
     g3 = torch.cat([p.grad.reshape(-1) for p in m3.parameters()])
     assert torch.allclose(g3, g, atol=1e-6)              # same averaged gradient as torch DDP
     assert m3.flat_grad_base() == m3._gflat.data_ptr()   # still one flat buffer: optimizer zero-copy path
+    sync.wait()                                          # idempotent (the fused optimizer still calls it)
+    assert torch.allclose(torch.cat([p.grad.reshape(-1) for p in m3.parameters()]), g, atol=1e-6)
+    # gradient accumulation (a second backward while .grad is still attached) is refused loudly, not silently unsynced
+    try:
+        m3(x).square().mean().backward()
+        raise AssertionError("FlatGradSync accepted a second backward without zero_grad")
+    except RuntimeError as e:
+        assert "accumulation" in str(e)
+    # a backward that died half-way leaves a collective in flight: the next forward drains it and the step is right
+    m3.zero_grad(set_to_none=True)
+    sync.ready(m3._gflat, ["x_lrnorm.weight", "x_lrnorm.bias"])
+    sync.flush()
+    assert sync._handles
+    m3(x).square().mean().backward()
+    assert not sync._handles
+    g4 = torch.cat([p.grad.reshape(-1) for p in m3.parameters()])
+    assert torch.allclose(g4, g, atol=1e-6)
     sync.detach()
     # bench.py's timing reduction: MAX over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)

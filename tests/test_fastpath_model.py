@@ -1,0 +1,150 @@
+"""Model-level parity of the FAST-PATH kernel mix -- the code bench.py actually times.
+
+The small-batch goldens (g11, B = 2/4 -> 392/784 tokens) only reach the generic kernels.  Here the batch is 64 and 256
+(12 544 / 50 176 tokens), which makes the bf16 step eligible for the weight-resident GEMM (`gemm_nt_wres`), the row-panel
+GEMM with fused residual+LayerNorm forward and LayerNorm-backward epilogues (`gemm_nt_kpipe`), the chained LN1, the
+persistent DMA-wave attention and the grouped weight-gradient launch.  Reference values: golden g17 (the reference ViT
+itself on detfill weights, tests/golden/make_golden_r2.py) and, for full tensors, the torch fp32 oracle run live.
+
+Tolerances: fp32 mode <= 1e-3 on logits (north_star), gradient norms rtol 1e-3; bf16 mode <= 2.5e-2 on logits and
+<= 2x the error of torch's own bf16 autocast of the oracle, gradient norms median 2e-2 (see tests/test_vit_model.py).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import rgb_no_more_amd as rg
+from rgb_no_more_amd import detfill
+from rgb_no_more_amd import lib as L
+from oracle import vit_torch as V
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CASES = {"ti_d2_b64": (192, 3, 2, 64, False), "ti_d12_b64": (192, 3, 12, 64, False), "s_d2_b64": (384, 6, 2, 64, False),
+         "ti_d12_b256": (192, 3, 12, 256, True)}
+FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe")
+
+
+def build(tag, compute):
+    emb, heads, depth, B, hard = CASES[tag]
+    m = rg.ViT(3, 16, emb, depth=depth, n_classes=1000, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
+               pixel_space="DCT", ver=1, use_subblock=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = detfill.fill_state_dict(shapes, base_seed=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.compute_dtype = compute
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    if hard:
+        tgt = torch.from_numpy(detfill.integers((B,), 74, 0, 998, np.int64)).to(DEV)
+    else:
+        t = detfill.uniform((B, 1000), 73, 0.0, 1.0)
+        tgt = torch.from_numpy(t / t.sum(1, keepdims=True)).to(DEV)
+    return m, sd, y, c, tgt
+
+
+def run(m, y, c, tgt, gdt):
+    m.train()
+    m.zero_grad()
+    logits = m(y, c)
+    loss = rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=gdt)
+    loss.backward()
+    torch.cuda.synchronize()
+    gn = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    return logits.detach().float().cpu().numpy(), loss.item(), gn
+
+
+def test_fast_kernels_are_selected_for_these_shapes():
+    """The shapes of this file really are the fast-path shapes (otherwise the tests below would silently re-test the
+    generic kernels): the library's own eligibility predicate says so, and every fast option is on by default."""
+    lib = L.lib()
+    for o in FAST_OPTS:
+        assert lib.rgbnm_get_option(o.encode()) >= 1, o
+    assert lib.rgbnm_vit_ln_chain(C.byref(L.VitCfg(L.DT_BF16, 64, 196, 192, 3, 1e-5, 0.07))) == 1
+    assert lib.rgbnm_vit_ln_chain(C.byref(L.VitCfg(L.DT_BF16, 256, 196, 192, 3, 1e-5, 0.07))) == 1
+    assert lib.rgbnm_vit_ln_chain(C.byref(L.VitCfg(L.DT_BF16, 4, 196, 192, 3, 1e-5, 0.07))) == 0     # g11's batch
+    assert lib.rgbnm_vit_ln_chain(C.byref(L.VitCfg(L.DT_F32, 64, 196, 192, 3, 1e-5, 0.07))) == 0
+
+
+@pytest.mark.parametrize("tag", ["ti_d2_b64", "ti_d12_b64", "s_d2_b64"])
+def test_fp32_vs_reference_golden(golden, tag):
+    g = golden("g17_fastpath.npz")
+    m, sd, y, c, tgt = build(tag, torch.float32)
+    assert [str(s) for s in g[tag + "_names"]] == list(m.state_dict().keys())
+    logits, loss, gn = run(m, y, c, tgt, torch.float32)
+    err = np.abs(logits[:, ::8] - g[tag + "_logits"]).max()
+    print(f"[{tag}] fp32 max |dlogit| = {err:.3e}  loss {loss:.6f} vs {float(g[tag + '_loss']):.6f}")
+    assert err <= 1e-3 and err <= 1e-4
+    assert abs(loss - float(g[tag + "_loss"])) < 2e-5
+    np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=1e-3, atol=1e-7)
+    named = dict(m.named_parameters())
+    for nm in ("encoder.0.0.fn.eb_mha.qkv.weight", "encoder.1.1.fn.eb_ffb.0.weight", "patchembed.projection.0.weight"):
+        got = named[nm].grad.reshape(-1)[::37].cpu().numpy()
+        np.testing.assert_allclose(got, g[tag + "_grad_" + nm], rtol=2e-3, atol=3e-7, err_msg=nm)
+
+
+@pytest.mark.parametrize("tag", ["ti_d2_b64", "ti_d12_b64", "s_d2_b64", "ti_d12_b256"])
+def test_bf16_fast_path_vs_reference_golden(golden, tag):
+    """bf16 with every fast kernel on (the default = what bench.py runs; ti_d12_b256 IS the bench configuration)."""
+    g = golden("g17_fastpath.npz")
+    m, sd, y, c, tgt = build(tag, torch.bfloat16)
+    logits, loss, gn = run(m, y, c, tgt, torch.bfloat16)
+    ref = g[tag + "_logits"]
+    err = np.abs(logits[:, ::8] - ref).max()
+    rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    print(f"[{tag}] bf16 fast path: max |dlogit| = {err:.3e}, loss {loss:.5f} vs {float(g[tag + '_loss']):.5f}, "
+          f"grad-norm rel err median {np.median(rel):.3e} max {rel.max():.3e}")
+    assert err <= 2.5e-2
+    assert abs(loss - float(g[tag + "_loss"])) < 5e-3
+    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+    named = dict(m.named_parameters())
+    for nm in ("encoder.0.0.fn.eb_mha.qkv.weight", "encoder.1.1.fn.eb_ffb.0.weight", "patchembed.projection.0.weight"):
+        got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
+        want = g[tag + "_grad_" + nm].astype(np.float64)
+        cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
+        assert cos > 0.995, (nm, cos)
+
+
+def test_bf16_fast_path_vs_live_oracle_and_generic_kernels():
+    """B = 64, depth 2: (i) every logit and every gradient ELEMENT against the torch fp32 oracle and against the oracle
+    under torch's own bf16 autocast; (ii) the same step with all fast kernels switched off (generic kernels) must agree
+    with the fast path to bf16 rounding -- so a defect in a fused epilogue cannot hide behind the tolerance."""
+    tag = "ti_d2_b64"
+    emb, heads, depth, B, _ = CASES[tag]
+    m, sd, y, c, tgt = build(tag, torch.bfloat16)
+    lib = L.lib()
+    logits, loss, gn = run(m, y, c, tgt, torch.bfloat16)
+    grads_fast = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
+    ref = V.vit_forward(p, y.cpu(), c.cpu(), depth, heads, emb)
+    V.soft_xent(ref, tgt.cpu()).backward()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lo = V.vit_forward({k: v.detach() for k, v in p.items()}, y.cpu(), c.cpu(), depth, heads, emb).float()
+    err = np.abs(logits - ref.detach().numpy()).max()
+    err_autocast = np.abs(lo.numpy() - ref.detach().numpy()).max()
+    print(f"bf16 fast path vs oracle: max |dlogit| {err:.3e} (torch bf16 autocast of the oracle: {err_autocast:.3e})")
+    assert err <= 2.5e-2 and err <= 2.0 * err_autocast + 2e-3
+    worst = 0.0
+    for n, gfast in grads_fast.items():
+        want = p[n].grad
+        rel = ((gfast.cpu() - want).norm() / (want.norm() + 1e-20)).item()
+        worst = max(worst, rel)
+        assert rel < 6e-2, (n, rel)
+    print(f"worst per-tensor gradient rel error vs oracle: {worst:.3e}")
+    try:
+        for o in FAST_OPTS:
+            L.check(lib.rgbnm_set_option(o.encode(), 0))
+        logits_g, loss_g, gn_g = run(m, y, c, tgt, torch.bfloat16)
+        grads_gen = {n: p_.grad.detach().clone() for n, p_ in m.named_parameters()}
+    finally:
+        for o in FAST_OPTS:
+            L.check(lib.rgbnm_set_option(o.encode(), 1))
+    d = np.abs(logits - logits_g).max()
+    print(f"fast vs generic kernels: max |dlogit| {d:.3e}, loss {loss:.6f} / {loss_g:.6f}")
+    assert d <= 1e-2 and abs(loss - loss_g) < 2e-3
+    for n in grads_fast:
+        rel = ((grads_fast[n] - grads_gen[n]).norm() / (grads_gen[n].norm() + 1e-20)).item()
+        assert rel < 4e-2, (n, rel)

@@ -83,3 +83,31 @@ def test_batch_reader_threads(golden, tmp_path):
     gp.write_bytes(g["g40x56_jpeg"].tobytes())
     with pytest.raises(dm.libjpeg_exception):       # different grid -> shape error for that file
         dm.read_coefficients_batch(paths + [str(gp)], threads=2, grid=(8, 8))
+
+
+def _patch_sof_sampling(data: bytes, comp_index: int, hv: int) -> bytes:
+    """Rewrite the H/V sampling byte of one component in the SOF0 header of a baseline JPEG."""
+    i = data.index(b"\xff\xc0")
+    ncomp = data[i + 9]
+    assert comp_index < ncomp
+    off = i + 10 + 3 * comp_index + 1
+    return data[:off] + bytes([hv]) + data[off + 1:]
+
+
+def test_mismatched_chroma_grids_are_rejected_not_overrun(golden):
+    """A 3-component file whose Cr sampling differs from Cb would be copied past the (2, Hc, Wc) CbCr tensor that is
+    sized from Cb alone (the reference has the same flaw, dct_manip.cpp:112-117): the reader must refuse it."""
+    g = golden("g1_reader.npz")
+    data = g["c64x64_jpeg"].tobytes()
+    dm.read_coefficients_bytes(data)                                    # sanity: the unpatched file reads
+    bad = _patch_sof_sampling(data, 2, 0x21)                            # Cr: 2x1 instead of 1x1 -> twice Cb's width
+    with pytest.raises(RuntimeError, match="different block grids"):
+        dm.read_coefficients_bytes(bad)
+
+
+def test_grayscale_in_batch_gets_zero_chroma(golden, tmp_path):
+    g = golden("g1_reader.npz")
+    gp = tmp_path / "gray.jpg"
+    gp.write_bytes(g["g40x56_jpeg"].tobytes())
+    Y, C, Q = dm.read_coefficients_batch([str(gp)] * 3, threads=64, grid=(5, 7))     # more threads than files
+    assert np.array_equal(Y[2].numpy(), g["g40x56_Y"]) and not C.any() and (Q[:, 1:] == 1).all()
