@@ -44,7 +44,8 @@ int rgbnm_abi_version(void);
  *   "tn_square" 0   192 x 192 dW tile                            "attn_v2"  1  second-generation attention kernels
  *   "attn_persist" 1  persistent attention fwd / bwd with a DMA wave (>= 256 (image, head) pairs)
  *   "nt_dmawave" 0  row-panel GEMM with a dedicated DMA wave (measured: no gain there)
- *   "trace"     0   see rgbnm_trace_collect                      "tn_wgs" 512  workgroup budget of the generic dW GEMM */
+ *   "trace"     0   see rgbnm_trace_collect                      "tn_wgs" 512  workgroup budget of the generic dW GEMM
+ *   "mlp_fuse"  1   FeedForwardBlock forward (fc1 + GELU + fc2 + residual [+ next LayerNorm]) as one launch (bf16, E = 192) */
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
 /* With option "trace" = (1 << tag) the launchers bracket kernels of that class with HIP events recorded on the launch

@@ -34,7 +34,12 @@ def build_lib(force=False, verbose=False):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        extra = []                      # per-file switches: a `// hipcc-flags: ...` line in the first 40 lines of the source
+        with open(s) as fh:
+            for _, line in zip(range(40), fh):
+                if line.startswith("// hipcc-flags:"):
+                    extra += line.split(":", 1)[1].split()
+        cmd = [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -196,7 +196,17 @@ __global__ __launch_bounds__(DMAW ? NTHREADS + 64 : NTHREADS) void gemm_nt_kpipe
   auto issue = [&](int stage) {
     unsigned char* st = smem + stage * STAGE;
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) __builtin_amdgcn_global_load_lds((glb_ptr)(src[j] + k0), (lds_ptr)(st + dst[j]), 16, 0, 0);
+    for (int j = 0; j < NDMA; ++j) {
+#ifdef KP_NOW      // timing experiment only: weight k-tiles beyond the first keep re-reading k-tile 0 (an L1/L2-hot line set)
+      const int i = (w + NWAVES * j) < 52 ? (w + NWAVES * j) : (w + NWAVES * j) - 52;
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src[j] + (i < 28 ? k0 : 0)), (lds_ptr)(st + dst[j]), 16, 0, 0);
+#elif defined(KP_NOA)    // timing experiment only: activation k-tiles keep re-reading k-tile 0
+      const int i = (w + NWAVES * j) < 52 ? (w + NWAVES * j) : (w + NWAVES * j) - 52;
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src[j] + (i < 28 ? 0 : k0)), (lds_ptr)(st + dst[j]), 16, 0, 0);
+#else
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src[j] + k0), (lds_ptr)(st + dst[j]), 16, 0, 0);
+#endif
+    }
     k0 += 64;
   };
 

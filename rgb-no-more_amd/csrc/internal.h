@@ -36,6 +36,12 @@ int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ld
 int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* R,
                                  int ldr, void* x, int ldc, const float* gamma, const float* beta, void* y, int ldy,
                                  float* mean, float* rstd, float eps, int M, int N, int K, hipStream_t st);
+// Fused FeedForwardBlock forward (mlp_fused.hip): x_out = x_mid + fc2(gelu(fc1(xn2))) [+ LayerNorm of x_out], saving
+// gelu(u) -> G and gelu'(u) -> GP for the backward; 1 = not eligible (E != 192, hidden != 768, small M).
+int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2,
+                         const void* R, int ldr, void* G, void* GP, int ldg, void* Y, int ldy, const float* gamma,
+                         const float* beta, void* Y2, int ldy2, float* mean, float* rstd, float eps, int M, int E, int H,
+                         hipStream_t st);
 // fc1 / qkv dX GEMM with the LayerNorm backward fused into the epilogue (gemm_nt_kpipe.hip); 1 = not eligible.
 int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, const void* X, int ldx,
                                 const float* gamma, const float* mean, const float* rstd, const void* dres, int ldr,

@@ -1,0 +1,334 @@
+// Fused FeedForwardBlock forward of JPEG-Ti (reference: models/plainvit.py:481-491 inside ResidualAdd :475-479, followed
+// by the next LayerNorm :513/:522), bf16, E = 192, hidden = 768:
+//     x_out = x_mid + fc2(gelu(fc1(xn2)))      [ ; xn_next = LayerNorm(x_out) ]
+// in ONE launch: the [M,768] hidden activation is produced and consumed on chip; what leaves the CU are the two tensors the
+// backward needs (gelu(u) for dW2, gelu'(u) for dX) and the 192-wide outputs.
+//
+// Why: measured on MI355X (tools/nt_probe.py) a CU ingests ~25 GB/s through the vector-memory path whether the line comes
+// from HBM, the Infinity Cache or its own XCD's L2 -- 256 CUs x 25 GB/s is the whole chip's ~6.4 TB/s -- so a kernel's time
+// is (bytes its CU loads + bytes it stores) and re-reading an intermediate costs exactly what an HBM read costs.  Separate
+// fc1 / fc2 launches load 1044 KB and store 752 KB per image; this kernel loads 740 KB (150 KB activations + both weight
+// matrices, streamed once per image as 48 KB chunks) and stores the same 752 KB minus nothing re-read: the 301 KB read of
+// gelu(u) by fc2 and fc2's second weight/activation pipeline disappear, and one launch boundary per block with them.
+//
+// Structure: one workgroup per image-sized row panel (M / 256 rows, <= 224) = 7 compute waves x 32 rows + 1 DMA wave.
+//   * the wave's 32 x 192 LayerNorm-ed input rows live in registers as 12 MFMA operand fragments for the whole kernel;
+//   * the DMA wave streams hidden chunks of 64: W1[64 x 192] (24 KB) and W2[192 x 64] (24 KB) into a 2-stage LDS ring,
+//     one chunk ahead, swizzled through the DMA source address (conflict-free ds_read_b128, same maps as gemm_nt_wres /
+//     gemm_nt_kpipe), one workgroup barrier per chunk;
+//   * per chunk a wave runs 24 MFMAs of fc1 with swapped operands (D rows = hidden, D cols = tokens), adds the bias,
+//     rounds to bf16 as the unfused path does, evaluates gelu / gelu' once, and feeds gelu(u) STRAIGHT FROM REGISTERS into
+//     the 24 fc2 MFMAs: a lane owns one token and, because the rows of the W1 chunk are stored with index bits 2 and 3
+//     swapped, its 8 accumulator registers of a k-step are 8 consecutive hidden units = one B-operand fragment;
+//   * gelu(u) / gelu'(u) leave through a private 2 x 4 KB staging tile per wave as whole 128-byte row pieces;
+//   * epilogue = the residual + LayerNorm epilogue of gemm_nt_kpipe (same arithmetic, same bits as ln_fwd_kernel).
+// Results are bit-identical to the two-launch path (same operand rounding, same fp32 summation order):
+// tests/test_fastpath_model.py::test_fused_mlp_forward_equals_the_two_gemm_path.
+//
+// Measured (B = 256; per-phase cycle stamps): 78 us against 48 + 37 us for the two launches.  The
+// weight stream is free (a variant that fetches only two chunks: -1 us); the GELU arithmetic costs 17 us and the stores of
+// the two saved tensors 18 us, and they do not hide behind the matrix phases: a wave64 VALU instruction costs ~4 cycles
+// here, so gelu + gelu' (~27 instructions per element) takes 1650 cycles per 16 elements per wave against ~400 for the 12
+// MFMAs that produced them -- the fused block is VALU bound.  Variants tried and measured slower: 32-wide granules in a
+// 4-stage ring with the fc1 MFMAs of granule h + 1 issued next to the GELU of granule h (82 us); the two waves of a SIMD
+// running the phases in opposite order (86 us: the older wave wins the VALU arbitration and the younger one's GELU phase
+// stretches to 3400 cycles); scalar instead of packed fp32 GELU arithmetic (88 us).
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+constexpr int E = 192, H = 768, CH = 64, NCHUNK = H / CH;
+constexpr int NCW = 7, NTHREADS = 64 * (NCW + 1), CTHREADS = 64 * NCW, BM = 32 * NCW;   // 224 panel rows
+constexpr int W1_STAGE = CH * E * 2;                // 24 KB: [64 hidden rows][384 B]
+constexpr int W2_STAGE = E * CH * 2;                // 24 KB: [192 feature rows][128 B]
+constexpr int STAGE = W1_STAGE + W2_STAGE, NSTAGE = 2;
+constexpr int STG_OFF = NSTAGE * STAGE;             // per-wave staging: gelu tile 4 KB | gelu' tile 4 KB
+constexpr int STG_TILE = 32 * CH * 2, STG_WAVE = 2 * STG_TILE;
+constexpr int B1_OFF = STG_OFF + NCW * STG_WAVE;    // 768 floats
+constexpr int B2_OFF = B1_OFF + H * 4;              // 192 floats
+constexpr int SMEM = B2_OFF + E * 4;                // 159,488 B
+constexpr int CP = E + 4;                           // final staging pitch (elements)
+constexpr int LN_GROUPS = CTHREADS / 8, LN_ITERS = BM / LN_GROUPS;      // 56 row groups of 8 lanes, 4 rounds
+static_assert(SMEM <= 160 * 1024, "LDS");
+static_assert(BM * CP * 2 <= NSTAGE * STAGE, "final staging tile lives in the ring");
+
+struct MlpArgs {
+  const bf16* X; const bf16* W1; const float* b1; const bf16* W2; const float* b2; const bf16* R;
+  bf16* G; bf16* GP; bf16* Y;
+  int ldx, ldr, ldg, ldy;
+  int M, rows_per_wg, npanels;
+  const float* gamma; const float* beta; bf16* Y2; float* mean_o; float* rstd_o; float eps; int ldy2;   // gamma == null: no LN
+};
+
+__device__ __forceinline__ int fswz(int row) {
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+}
+__device__ __forceinline__ int pchunk(int lc, int row) { return (lc & ~7) | ((lc & 7) ^ fswz(row)); }
+__device__ __forceinline__ float group8_pair_sum(float s0, float s1) {
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  return s0 + s1;
+}
+
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* B1s = reinterpret_cast<float*>(smem + B1_OFF);
+  float* B2s = reinterpret_cast<float*>(smem + B2_OFF);
+  const int panel = blockIdx.x;
+  if (panel >= p.npanels) return;
+  const int m0 = panel * p.rows_per_wg;
+  const int rows = min(p.rows_per_wg, p.M - m0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+
+  if (w == NCW) {
+    // ---------------- DMA wave: biases once, then one 48 KB weight chunk per barrier, one chunk ahead of the math
+#pragma unroll
+    for (int i = 0; i < H / 64; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(p.b1 + 64 * i + lane), (lds_ptr)(B1s + 64 * i), 4, 0, 0);
+#pragma unroll
+    for (int i = 0; i < E / 64; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(p.b2 + 64 * i + lane), (lds_ptr)(B2s + 64 * i), 4, 0, 0);
+    const int rl = lane >> 3, pc = lane & 7;
+    auto issue = [&](int chunk) {
+      unsigned char* st = smem + (chunk & 1) * STAGE;
+      const bf16* w1 = p.W1 + (size_t)chunk * CH * E;
+#pragma unroll
+      for (int i = 0; i < W1_STAGE / 1024; ++i) {
+        const int pidx = 64 * i + lane, row = pidx / 24, c24 = pidx % 24;
+        const int hrow = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);     // LDS row r holds hidden unit swap23(r)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(w1 + hrow * E + pchunk(c24, row) * 8), (lds_ptr)(st + i * 1024), 16, 0, 0);
+      }
+      const bf16* w2 = p.W2 + chunk * CH;
+#pragma unroll
+      for (int i = 0; i < W2_STAGE / 1024; ++i) {
+        const int r8 = 8 * i + rl;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(w2 + (size_t)r8 * H + ((pc ^ fswz(r8)) * 8)),
+                                         (lds_ptr)(st + W1_STAGE + i * 1024), 16, 0, 0);
+      }
+    };
+    issue(0);
+    for (int c = 0; c < NCHUNK; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c (and, the first time, the biases) landed
+      __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
+      if (c + 1 < NCHUNK) issue(c + 1);
+    }
+    return;                                               // ended waves drop out of the workgroup barrier
+  }
+
+  // ---------------- compute waves
+  const int rloc = 32 * w + l31;
+  const bf16* xrow = p.X + (size_t)(m0 + (rloc < rows ? rloc : rows - 1)) * p.ldx;
+  bf16x8 fa[E / 16];
+#pragma unroll
+  for (int c = 0; c < E / 16; ++c) fa[c] = *reinterpret_cast<const bf16x8*>(xrow + (2 * c + g) * 8);
+
+  f32x16 acc2[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[b][r] = 0.f;
+
+  const int fl = fswz(l31);
+  const int woff0 = l31 * (E * 2) + ((g ^ fl) << 4);      // W1 fragment c of LDS row l31: (woff0 ^ ((c % 4) << 5)) + 128 (c / 4)
+  unsigned char* stg = smem + STG_OFF + w * STG_WAVE;
+
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
+    const unsigned char* sW2 = sW1 + W1_STAGE;
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht) {
+      f32x16 a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+      int wbase = woff0 + ht * 32 * (E * 2);
+      asm volatile("" : "+v"(wbase));
+#pragma unroll
+      for (int c = 0; c < E / 16; ++c) {
+        Frag<bf16> fb, fx;
+        fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+        fx.v = fa[c];
+        mma(a1, fb, fx);                                   // D rows = hidden (LDS row order), D cols = tokens
+      }
+      Frag<bf16> pg[2];
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+        // registers 8 hs .. 8 hs + 7 of this lane = hidden units h0 .. h0 + 7 of the token l31 (rows were stored swap23-ed)
+        const int hl = 32 * ht + 16 * hs + 8 * g;
+        const float* bp = B1s + chunk * CH + hl;
+        const f32x4 bl = *reinterpret_cast<const f32x4*>(bp), bh = *reinterpret_cast<const f32x4*>(bp + 4);
+        bf16x8 gv, dv;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float u0 = a1[8 * hs + j] + (j < 4 ? bl[j] : bh[j - 4]);
+          const float u1 = a1[8 * hs + j + 1] + (j < 4 ? bl[j + 1] : bh[j - 3]);
+          const f32x2 u = {(float)(bf16)u0, (float)(bf16)u1};          // the unfused path rounds u to bf16 before GELU
+          f32x2 ge, dg;
+          gelu_pair_fast(u, ge, dg);
+          gv[j] = (bf16)ge[0];
+          gv[j + 1] = (bf16)ge[1];
+          dv[j] = (bf16)dg[0];
+          dv[j + 1] = (bf16)dg[1];
+        }
+        pg[hs].v = gv;
+        const int pcx = ((2 * (2 * ht + hs) + g) ^ (l31 & 7)) << 4;
+        *reinterpret_cast<bf16x8*>(stg + l31 * (CH * 2) + pcx) = gv;
+        *reinterpret_cast<bf16x8*>(stg + STG_TILE + l31 * (CH * 2) + pcx) = dv;
+      }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+        const int s = 2 * ht + hs;
+        Frag<bf16> fw[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+          fw[b].v = *reinterpret_cast<const bf16x8*>(sW2 + (32 * b + l31) * (CH * 2) + (((2 * s + g) ^ fl) << 4));
+#pragma unroll
+        for (int b = 0; b < 6; ++b) mma(acc2[b], fw[b], pg[hs]);     // D rows = output features, D cols = tokens
+      }
+    }
+    // ---- the chunk's gelu / gelu' tiles: 32 rows x 128 B each, out as whole row pieces (LDS runs a wave in order)
+    const int ln = lane_id_here();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+      const int so = row * (CH * 2) + ((vec ^ (row & 7)) << 4);
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + so);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + STG_TILE + so);
+      if (32 * w + row < rows) {
+        const size_t go = (size_t)(m0 + 32 * w + row) * p.ldg + chunk * CH + vec * 8;
+        *reinterpret_cast<bf16x8*>(p.G + go) = v0;
+        *reinterpret_cast<bf16x8*>(p.GP + go) = v1;
+      }
+    }
+  }
+
+  // ---------------- epilogue: x_out = acc2 + b2 + R [, LayerNorm]: the arithmetic of gemm_nt_kpipe's EPI_RES_LN
+  const int ctid = tid;                                   // compute threads are 0 .. 447
+  const int l8 = ctid & 7, grp = ctid >> 3;
+  bf16x8 lr[LN_ITERS][3];
+#pragma unroll
+  for (int it = 0; it < LN_ITERS; ++it) {
+    const int row = it * LN_GROUPS + grp, rr = m0 + (row < rows ? row : rows - 1);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) lr[it][v] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)rr * p.ldr + v * 64 + l8 * 8);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the staging tile
+  bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = 32 * b + 8 * q + 4 * g;
+      f32x4 v = {acc2[b][4 * q + 0], acc2[b][4 * q + 1], acc2[b][4 * q + 2], acc2[b][4 * q + 3]};
+      v += *reinterpret_cast<const f32x4*>(B2s + nl);
+      store4<bf16>(Cs + rloc * CP + nl, v);
+    }
+  const bool do_ln = p.gamma != nullptr;
+  f32x4 gm[3][2], bt[3][2];
+  if (do_ln) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        gm[v][hf] = *reinterpret_cast<const f32x4*>(p.gamma + v * 64 + l8 * 8 + hf * 4);
+        bt[v][hf] = *reinterpret_cast<const f32x4*>(p.beta + v * 64 + l8 * 8 + hf * 4);
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int it = 0; it < LN_ITERS; ++it) {
+    const int row = it * LN_GROUPS + grp;
+    if (row < rows) {
+      float xv[3][8];
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const bf16* cp = Cs + row * CP + v * 64 + l8 * 8;            // 8-byte aligned (CP * 2 = 392)
+        const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(cp), c1 = *reinterpret_cast<const bf16x4*>(cp + 4);
+        bf16x8 xb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xb[i] = (bf16)((float)(i < 4 ? c0[i & 3] : c1[i & 3]) + (float)lr[it][v][i]);
+          xv[v][i] = (float)xb[i];
+        }
+        *reinterpret_cast<bf16x8*>(p.Y + (size_t)(m0 + row) * p.ldy + v * 64 + l8 * 8) = xb;
+        s0 += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+        s1 += xv[v][4] + xv[v][5] + xv[v][6] + xv[v][7];
+      }
+      if (do_ln) {
+        const float mu = group8_pair_sum(s0, s1) * (1.f / E);
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float d0 = xv[v][i] - mu, d1 = xv[v][4 + i] - mu;
+            q0 = __builtin_fmaf(d0, d0, q0);
+            q1 = __builtin_fmaf(d1, d1, q1);
+          }
+        const float rs = rsqrtf(__builtin_fmaf(group8_pair_sum(q0, q1), 1.f / E, p.eps));
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          bf16x8 ob;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            ob[i] = (bf16)__builtin_fmaf((xv[v][i] - mu) * rs, gm[v][i >> 2][i & 3], bt[v][i >> 2][i & 3]);
+          *reinterpret_cast<bf16x8*>(p.Y2 + (size_t)(m0 + row) * p.ldy2 + v * 64 + l8 * 8) = ob;
+        }
+        if (l8 == 0) {
+          p.mean_o[m0 + row] = mu;
+          p.rstd_o[m0 + row] = rs;
+        }
+      }
+    }
+  }
+  }
+}
+
+}  // namespace
+
+// 1 = shape not eligible (the caller runs fc1 and fc2 as two GEMM launches).
+int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2,
+                         const void* R, int ldr, void* G, void* GP, int ldg, void* Y, int ldy, const float* gamma,
+                         const float* beta, void* Y2, int ldy2, float* mean, float* rstd, float eps, int M, int Edim,
+                         int Hdim, hipStream_t st) {
+  if (Edim != E || Hdim != H || M < 8192 || ldx % 8 || ldr % 8 || ldg % 8 || ldy % 8 || (gamma && ldy2 % 8)) return 1;
+  if (!X || !W1 || !b1 || !W2 || !b2 || !R || !G || !GP || !Y) return RGBNM_EINVAL;
+  if (gamma && (!beta || !Y2 || !mean || !rstd)) return RGBNM_EINVAL;
+  MlpArgs p;
+  p.X = (const bf16*)X; p.W1 = (const bf16*)W1; p.b1 = b1; p.W2 = (const bf16*)W2; p.b2 = b2; p.R = (const bf16*)R;
+  p.G = (bf16*)G; p.GP = (bf16*)GP; p.Y = (bf16*)Y;
+  p.ldx = ldx; p.ldr = ldr; p.ldg = ldg; p.ldy = ldy; p.M = M;
+  p.gamma = gamma; p.beta = beta; p.Y2 = (bf16*)Y2; p.mean_o = mean; p.rstd_o = rstd; p.eps = eps; p.ldy2 = ldy2;
+  int rows = cdiv(M, 256);
+  if (rows > BM) rows = BM;
+  p.rows_per_wg = rows;
+  p.npanels = cdiv(M, rows);
+  static DevOnce attr;
+  if (attr.need()) {
+    if (hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr.done();
+  }
+  const double me = (double)M * E, mh = (double)M * H;
+  // algorithmic bytes: xn2 + x_mid in, gelu + gelu' + x_out (+ xn_next) out, both weight matrices once
+  const int slot = rgbnm_trace_begin(TR_NT, 4.0 * mh * E, (me * (gamma ? 4.0 : 3.0) + mh * 2.0) * 2.0 + 4.0 * E * H, st);
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(p.npanels), dim3(NTHREADS), SMEM, st, p);
+  rgbnm_trace_end(slot, st);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+

@@ -32,7 +32,7 @@ hipEvent_t take_event() {
 // process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
 // they select between parity-tested kernels and are meant to be set before work is enqueued
 struct Opt { const char* name; std::atomic<int> value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -173,11 +173,20 @@ int rgbnm_vit_block_fwd_chain(const rgbnm_vit_cfg* c, const rgbnm_block_params* 
                       I, 0, st));
     TRY(rgbnm_layernorm_fwd(dt, a->x_mid, p->ln2_g, p->ln2_b, a->xn2, a->mean2, a->rstd2, M, E, c->ln_eps, st));
   }
+  const bool to_next = chain && next_p && next_a;
+  if (to_next && next_a->x_in != a->x_out) return RGBNM_EINVAL;
+  // the whole FeedForwardBlock (+ residual [+ the next block's LN1]) in one launch when eligible (mlp_fused.hip)
+  if (dt == RGBNM_DT_BF16 && rgbnm_get_option("mlp_fuse")) {
+    const int rc = rgbnm_launch_mlp_fwd(a->xn2, E, p->w1, p->b1, p->w2, p->b2, a->x_mid, E, a->gl, a->u, 4 * E, a->x_out, E,
+                                        to_next ? next_p->ln1_g : nullptr, to_next ? next_p->ln1_b : nullptr,
+                                        to_next ? next_a->xn1 : nullptr, E, to_next ? next_a->mean1 : nullptr,
+                                        to_next ? next_a->rstd1 : nullptr, c->ln_eps, M, E, 4 * E, (hipStream_t)st);
+    if (rc <= 0) return rc;                                  // done (0) or a real error (< 0); 1 = not eligible
+  }
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_GELU, a->xn2, E, p->w1, E, a->gl, 4 * E, p->b1, 0, 0, a->u, 4 * E, 0, 0, M, 4 * E,
                     E, 0, st));
   // x_out = x_mid + fc2(gl) [; next block's xn1 = LN1(x_out)]
-  if (chain && next_p && next_a) {
-    if (next_a->x_in != a->x_out) return RGBNM_EINVAL;
+  if (to_next) {
     const int rc = rgbnm_launch_nt_kpipe_res_ln(a->gl, 4 * E, p->w2, 4 * E, p->b2, a->x_mid, E, a->x_out, E,
                                                 next_p->ln1_g, next_p->ln1_b, next_a->xn1, E, next_a->mean1,
                                                 next_a->rstd1, c->ln_eps, M, E, 4 * E, (hipStream_t)st);

@@ -71,7 +71,13 @@ class FusedClipAdamWWD(Optimizer):
     def load_state_dict(self, state_dict):
         """Restore moments + step (written by this class or by torch.optim.AdamW over the same parameter list)."""
         self._ensure()
+        own = [dict((k, v) for k, v in g.items() if k != "params") for g in self.param_groups]
         super().load_state_dict(state_dict)          # validates groups / sizes, casts to the parameter devices
+        for g, o in zip(self.param_groups, own):
+            if "base_lr" not in g:                   # a torch.optim.AdamW checkpoint: its weight_decay (0, the decay lives
+                g["weight_decay"] = o["weight_decay"]     # in the reference's separate WeightDecay optimizer) is not ours
+            for k, v in o.items():
+                g.setdefault(k, v)                   # base_lr, max_norm, ... keep this optimizer's values
         m = self._m
         steps = set()
         loaded = dict(self.state)

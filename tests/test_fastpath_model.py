@@ -25,7 +25,7 @@ DEV = "cuda"
 
 CASES = {"ti_d2_b64": (192, 3, 2, 64, False), "ti_d12_b64": (192, 3, 12, 64, False), "s_d2_b64": (384, 6, 2, 64, False),
          "ti_d12_b256": (192, 3, 12, 256, True)}
-FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe")
+FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe", "mlp_fuse")
 
 
 def build(tag, compute):
@@ -148,3 +148,38 @@ def test_bf16_fast_path_vs_live_oracle_and_generic_kernels():
     for n in grads_fast:
         rel = ((grads_fast[n] - grads_gen[n]).norm() / (grads_gen[n].norm() + 1e-20)).item()
         assert rel < 4e-2, (n, rel)
+
+
+def test_fused_mlp_forward_equals_the_two_gemm_path():
+    """mlp_fused.hip (fc1 + GELU + fc2 + residual + next LayerNorm in one launch) against the same block run as the
+    weight-resident fc1 GEMM + row-panel fc2 GEMM: identical operand rounding and the same fp32 summation order, so every
+    saved activation (gelu(u), gelu'(u)), the residual stream, the chained LayerNorm output and its statistics must agree
+    bit for bit -- and therefore the logits and all gradients."""
+    lib = L.lib()
+    m, sd, y, c, tgt = build("ti_d2_b64", torch.bfloat16)
+    m.train()
+
+    def snapshot():
+        m.zero_grad()
+        logits = m(y, c)
+        ar = logits.grad_fn.st.arena
+        torch.cuda.synchronize()
+        snap = {"gl0": ar.blk[0]["gl"].clone(), "gp0": ar.blk[0]["u"].clone(), "x1": ar.x[1].clone(),
+                "xn1_1": ar.blk[1]["xn1"].clone(), "mean1_1": ar.blk[1]["mean1"].clone(), "rstd1_1": ar.blk[1]["rstd1"].clone(),
+                "gl1": ar.blk[1]["gl"].clone(), "x2": ar.x[2].clone(), "logits": logits.detach().clone()}
+        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
+        snap["grads"] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+        return snap
+
+    assert lib.rgbnm_get_option(b"mlp_fuse") == 1
+    fused = snapshot()
+    try:
+        L.check(lib.rgbnm_set_option(b"mlp_fuse", 0))
+        plain = snapshot()
+    finally:
+        L.check(lib.rgbnm_set_option(b"mlp_fuse", 1))
+    for k in fused:
+        a, b = fused[k].float(), plain[k].float()
+        nd = int((a != b).sum())
+        print(f"{k:8s} max |d| {float((a - b).abs().max()):.3e}  differing elements {nd} / {a.numel()}")
+        assert torch.equal(fused[k], plain[k]), k
