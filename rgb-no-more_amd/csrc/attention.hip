@@ -19,10 +19,15 @@
 namespace {
 
 constexpr int HD = 64;        // head dim
-constexpr int NTILE = 7;      // 7 x 32 = 224 >= 196 tokens
-constexpr int NPAD = NTILE * 32;
-constexpr int TP = 260;       // LDS pitch (elements) of transposed images: 130 dwords (bf16) / 260 (f32)
-constexpr int NTHREADS = NTILE * 64;
+// NT = number of 32-token tiles a workgroup covers: 7 (224 >= 196 tokens: embed_type 1 / 2) or 10 (320 >= 294 tokens:
+// embed_type 3, PatchEmbedding_DCT_Concat, plainvit.py:353-410).  One wave per tile.
+template <int NT> struct AN {
+  static constexpr int NTILE = NT;
+  static constexpr int NPAD = NT * 32;
+  static constexpr int TP = NT * 32 + 36;   // LDS pitch (elements) of transposed images: 130 / 162 dwords (bf16), 260 / 356 (f32)
+  static constexpr int NTHREADS = NT * 64;
+};
+constexpr int NT_MAX = 10;
 
 template <typename T> struct AT {
   static constexpr int EPL = Frag<T>::EPL;
@@ -33,8 +38,9 @@ template <typename T> struct AT {
 };
 
 // stage src[tok][HD] (row stride ld) transposed into dst[d][TP]; tokens >= N are zero-filled.
-template <typename T>
+template <typename T, int NT>
 __device__ __forceinline__ void stage_transposed(const T* __restrict__ src, int ld, int N, T* dst) {
+  constexpr int NPAD = AN<NT>::NPAD, TP = AN<NT>::TP, NTHREADS = AN<NT>::NTHREADS;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int VPR = HD / EPV;  // vectors per row
   for (int idx = threadIdx.x; idx < NPAD * VPR; idx += NTHREADS) {
@@ -51,8 +57,9 @@ __device__ __forceinline__ void stage_transposed(const T* __restrict__ src, int 
 }
 
 // A-operand fragment from a transposed LDS image: row d, keys of fragment `fi` of tile `t` for lane group g.
-template <typename T>
+template <typename T, int NT>
 __device__ __forceinline__ Frag<T> tfrag(const T* img, int d, int t, int fi, int g) {
+  constexpr int TP = AN<NT>::TP;
   Frag<T> f;
   if constexpr (sizeof(T) == 2) {
     // regs 8*fi .. 8*fi+7  <->  keys 32t + 16fi + 4g + {0..3}  and  + 8 + {0..3}
@@ -76,10 +83,12 @@ template <typename T> __device__ __forceinline__ Frag<T> pfrag(const float (&p)[
 }
 
 // ------------------------------------------------------------------------------------------- forward
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+template <typename T, int NT>
+__global__ __launch_bounds__(AN<NT>::NTHREADS) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                             float* __restrict__ lse, int N, int heads, float scale) {
   using A = AT<T>;
+  constexpr int NTILE = AN<NT>::NTILE, NPAD = AN<NT>::NPAD, TP = AN<NT>::TP, NTHREADS = AN<NT>::NTHREADS;
+  (void)NPAD; (void)NTHREADS; (void)TP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Vt = reinterpret_cast<T*>(smem_raw);   // [HD][TP]
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const T* __restrict_
   const T* K = Q + inner;
   const T* V = Q + 2 * inner;
 
-  stage_transposed<T>(V, ld, N, Vt);
+  stage_transposed<T, NT>(V, ld, N, Vt);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, qt = threadIdx.x >> 6;
@@ -101,10 +110,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const T* __restrict_
 #pragma unroll
   for (int c = 0; c < A::NCH; ++c) qf[c] = load_frag<T>(Q + (size_t)qc * ld + c * A::CH + g * A::EPL);
 
-  float s[NTILE][16];
-  float m = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t) {
+  // S^T tile t of this wave's 32 queries: rows = keys, cols = queries; keys >= N come back as -inf
+  auto score_tile = [&](int t, float (&sc)[16]) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -118,37 +125,85 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const T* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kk = t * 32 + acc_row(r, lane);
-      s[t][r] = kk < N ? acc[r] : -INFINITY;
-      m = fmaxf(m, s[t][r]);
+      sc[r] = kk < N ? acc[r] : -INFINITY;
     }
-  }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[t][r] = __expf((s[t][r] - m) * scale);
-      sum += s[t][r];
-    }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.f / sum;
-  if (g == 0 && q < N) lse[(size_t)bh * N + q] = m * scale + __logf(sum);
-
+  };
   f32x16 o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  if constexpr (NT <= 7) {
+    // all scores of the query stay in registers (7 x 16): one pass
+    float s[NTILE][16];
+    float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) {
+    for (int t = 0; t < NTILE; ++t) {
+      score_tile(t, s[t]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[t][r] *= inv;
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, s[t][r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
 #pragma unroll
-    for (int fi = 0; fi < A::FPT; ++fi) {
-      const Frag<T> pf = pfrag<T>(s[t], fi);
+    for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) mma(o[dt], tfrag<T>(Vt, dt * 32 + l31, t, fi, g), pf);
+      for (int r = 0; r < 16; ++r) {
+        s[t][r] = __expf((s[t][r] - m) * scale);
+        sum += s[t][r];
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (g == 0 && q < N) lse[(size_t)bh * N + q] = m * scale + __logf(sum);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] *= inv;
+#pragma unroll
+      for (int fi = 0; fi < A::FPT; ++fi) {
+        const Frag<T> pf = pfrag<T>(s[t], fi);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma(o[dt], tfrag<T, NT>(Vt, dt * 32 + l31, t, fi, g), pf);
+      }
+    }
+  } else {
+    // 10 tiles do not fit the register file next to the accumulators: the row maximum first, then the scores are
+    // recomputed tile by tile; P is normalised BEFORE it becomes an MFMA operand, exactly as in the one-pass form
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int t = 0; t < NTILE; ++t) {
+      if (t * 32 >= N) break;
+      float sc[16];
+      score_tile(t, sc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < NTILE; ++t) {
+      if (t * 32 >= N) break;
+      float sc[16];
+      score_tile(t, sc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += __expf((sc[r] - m) * scale);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (g == 0 && q < N) lse[(size_t)bh * N + q] = m * scale + __logf(sum);
+#pragma unroll 1
+    for (int t = 0; t < NTILE; ++t) {
+      if (t * 32 >= N) break;
+      float sc[16];
+      score_tile(t, sc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = __expf((sc[r] - m) * scale) * inv;
+#pragma unroll
+      for (int fi = 0; fi < A::FPT; ++fi) {
+        const Frag<T> pf = pfrag<T>(sc, fi);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma(o[dt], tfrag<T, NT>(Vt, dt * 32 + l31, t, fi, g), pf);
+      }
     }
   }
   // o[dt][r] = O[q][dt*32 + acc_row(r)] : 4 consecutive d per register quad
@@ -166,12 +221,14 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const T* __restrict_
 
 // ------------------------------------------------------------------------------------- backward: dQ
 // wave = 32 queries.  P recomputed from lse; dP^T = V.dO^T; dS = P*(dP - D)*scale; dQ^T = K^T.dS.
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+template <typename T, int NT>
+__global__ __launch_bounds__(AN<NT>::NTHREADS) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                const T* __restrict__ dout,
                                                                const float* __restrict__ lse, T* __restrict__ dqkv,
                                                                int N, int heads, float scale) {
   using A = AT<T>;
+  constexpr int NTILE = AN<NT>::NTILE, NPAD = AN<NT>::NPAD, TP = AN<NT>::TP, NTHREADS = AN<NT>::NTHREADS;
+  (void)NPAD; (void)NTHREADS; (void)TP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Kt = reinterpret_cast<T*>(smem_raw);   // [HD][TP]
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
@@ -182,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const T* __restri
   const T* O = out + (size_t)b * N * inner + h * HD;
   const T* dO = dout + (size_t)b * N * inner + h * HD;
 
-  stage_transposed<T>(K, ld, N, Kt);
+  stage_transposed<T, NT>(K, ld, N, Kt);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, qt = threadIdx.x >> 6;
@@ -236,7 +293,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const T* __restri
     for (int fi = 0; fi < A::FPT; ++fi) {
       const Frag<T> sf = pfrag<T>(ds, fi);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) mma(dq[dt], tfrag<T>(Kt, dt * 32 + l31, t, fi, g), sf);
+      for (int dt = 0; dt < 2; ++dt) mma(dq[dt], tfrag<T, NT>(Kt, dt * 32 + l31, t, fi, g), sf);
     }
   }
   if (q < N) {
@@ -254,17 +311,22 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const T* __restri
 // ---------------------------------------------------------------------------------- backward: dK, dV
 // wave = 32 keys (lane owns key lane&31), loop over query tiles; S[q][key] = Q.K^T (un-swapped), so the
 // lane's registers run over queries.  dV^T = dO^T.P ; dK^T = Q^T.dS  with dO^T / Q^T from transposed LDS.
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+template <typename T, int NT, int WHICH>
+__global__ __launch_bounds__(AN<NT>::NTHREADS) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                 const T* __restrict__ dout,
                                                                 const float* __restrict__ lse, T* __restrict__ dqkv,
                                                                 int N, int heads, float scale) {
   using A = AT<T>;
+  constexpr int NTILE = AN<NT>::NTILE, NPAD = AN<NT>::NPAD, TP = AN<NT>::TP, NTHREADS = AN<NT>::NTHREADS;
+  (void)NPAD; (void)NTHREADS; (void)TP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Qt = reinterpret_cast<T*>(smem_raw);         // [HD][TP]
-  T* dOt = Qt + HD * TP;                          // [HD][TP]
-  float* lse_s = reinterpret_cast<float*>(dOt + HD * TP);   // [NPAD]
-  float* D_s = lse_s + NPAD;                                // [NPAD]
+  // WHICH: 0 = dK and dV (two transposed images), 1 = dV only (dO^T), 2 = dK only (Q^T): fp32 with 10 tiles needs
+  // 2 x 91 KB for both images, more than the CU has, so that shape runs the kernel twice
+  constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
+  T* Qt = reinterpret_cast<T*>(smem_raw);                        // [HD][TP] (DO_K)
+  T* dOt = Qt + (DO_K ? HD * TP : 0);                            // [HD][TP] (DO_V)
+  float* lse_s = reinterpret_cast<float*>(dOt + (DO_V ? HD * TP : 0));   // [NPAD]
+  float* D_s = lse_s + NPAD;                                     // [NPAD]
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
   const int inner = heads * HD, ld = 3 * inner;
   const T* Q = qkv + (size_t)b * N * ld + h * HD;
@@ -273,8 +335,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const T* __restr
   const T* O = out + (size_t)b * N * inner + h * HD;
   const T* dO = dout + (size_t)b * N * inner + h * HD;
 
-  stage_transposed<T>(Q, ld, N, Qt);
-  stage_transposed<T>(dO, inner, N, dOt);
+  if (DO_K) stage_transposed<T, NT>(Q, ld, N, Qt);
+  if (DO_V) stage_transposed<T, NT>(dO, inner, N, dOt);
   for (int i = threadIdx.x; i < NPAD; i += NTHREADS) {
     float d = 0.f, l = 0.f;
     if (i < N) {
@@ -335,8 +397,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const T* __restr
       const Frag<T> pf = pfrag<T>(pp, fi), sf = pfrag<T>(ds, fi);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        mma(dv[dt], tfrag<T>(dOt, dt * 32 + l31, t, fi, g), pf);
-        mma(dk[dt], tfrag<T>(Qt, dt * 32 + l31, t, fi, g), sf);
+        if (DO_V) mma(dv[dt], tfrag<T, NT>(dOt, dt * 32 + l31, t, fi, g), pf);
+        if (DO_K) mma(dk[dt], tfrag<T, NT>(Qt, dt * 32 + l31, t, fi, g), sf);
       }
     }
   }
@@ -349,36 +411,46 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const T* __restr
       for (int rq = 0; rq < 4; ++rq) {
         f32x4 a = {dk[dt][rq * 4 + 0], dk[dt][rq * 4 + 1], dk[dt][rq * 4 + 2], dk[dt][rq * 4 + 3]};
         f32x4 c = {dv[dt][rq * 4 + 0], dv[dt][rq * 4 + 1], dv[dt][rq * 4 + 2], dv[dt][rq * 4 + 3]};
-        store4<T>(krow + dt * 32 + rq * 8 + g * 4, a);
-        store4<T>(vrow + dt * 32 + rq * 8 + g * 4, c);
+        if (DO_K) store4<T>(krow + dt * 32 + rq * 8 + g * 4, a);
+        if (DO_V) store4<T>(vrow + dt * 32 + rq * 8 + g * 4, c);
       }
   }
 }
 
-template <typename T>
+template <typename T, int NT>
 int attn_fwd_t(const void* qkv, void* out, float* lse, int B, int N, int heads, float scale, hipStream_t st) {
-  const size_t smem = (size_t)HD * TP * sizeof(T);
-  if (hipFuncSetAttribute((const void*)attn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return RGBNM_ELAUNCH;
-  hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * heads), dim3(NTHREADS), smem, st, (const T*)qkv, (T*)out, lse, N,
-                     heads, scale);
+  const size_t smem = (size_t)HD * AN<NT>::TP * sizeof(T);
+  if (hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return RGBNM_ELAUNCH;
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NT>), dim3(B * heads), dim3(AN<NT>::NTHREADS), smem, st, (const T*)qkv, (T*)out,
+                     lse, N, heads, scale);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
 
-template <typename T>
-int attn_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
-               int heads, float scale, hipStream_t st) {
-  const size_t smem1 = (size_t)HD * TP * sizeof(T);
-  const size_t smem2 = (size_t)2 * HD * TP * sizeof(T) + 2 * NPAD * sizeof(float);
-  if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1) != hipSuccess) return RGBNM_ELAUNCH;
-  if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess) return RGBNM_ELAUNCH;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(B * heads), dim3(NTHREADS), smem1, st, (const T*)qkv, (const T*)out,
-                     (const T*)dout, lse, (T*)dqkv, N, heads, scale);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(B * heads), dim3(NTHREADS), smem2, st, (const T*)qkv,
-                     (const T*)out, (const T*)dout, lse, (T*)dqkv, N, heads, scale);
+template <typename T, int NT, int WHICH>
+int attn_dkv_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
+                    int heads, float scale, hipStream_t st) {
+  const size_t smem = (size_t)(WHICH == 0 ? 2 : 1) * HD * AN<NT>::TP * sizeof(T) + 2 * AN<NT>::NPAD * sizeof(float);
+  if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, NT, WHICH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return RGBNM_ELAUNCH;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NT, WHICH>), dim3(B * heads), dim3(AN<NT>::NTHREADS), smem, st,
+                     (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, N, heads, scale);
   LAUNCH_CHECK();
   return RGBNM_OK;
+}
+
+template <typename T, int NT>
+int attn_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
+               int heads, float scale, hipStream_t st) {
+  const size_t smem1 = (size_t)HD * AN<NT>::TP * sizeof(T);
+  if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1) != hipSuccess) return RGBNM_ELAUNCH;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NT>), dim3(B * heads), dim3(AN<NT>::NTHREADS), smem1, st, (const T*)qkv,
+                     (const T*)out, (const T*)dout, lse, (T*)dqkv, N, heads, scale);
+  LAUNCH_CHECK();
+  if ((size_t)2 * HD * AN<NT>::TP * sizeof(T) + 2 * AN<NT>::NPAD * sizeof(float) <= 160 * 1024)
+    return attn_dkv_launch<T, NT, 0>(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
+  const int rc = attn_dkv_launch<T, NT, 1>(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
+  if (rc != RGBNM_OK) return rc;
+  return attn_dkv_launch<T, NT, 2>(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
 }
 
 }  // namespace
@@ -387,21 +459,32 @@ extern "C" {
 
 int rgbnm_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int heads, float scale,
                         void* stream) {
-  if (!qkv || !out || !lse || B <= 0 || heads <= 0 || N <= 0 || N > NPAD) return RGBNM_EINVAL;
-  if (dtype == DT_BF16 && rgbnm_get_option("attn_v2"))
-    return rgbnm_launch_attn2_fwd(qkv, out, lse, B, N, heads, scale, (hipStream_t)stream);
-  if (dtype == DT_BF16) return attn_fwd_t<bf16>(qkv, out, lse, B, N, heads, scale, (hipStream_t)stream);
-  if (dtype == DT_F32) return attn_fwd_t<float>(qkv, out, lse, B, N, heads, scale, (hipStream_t)stream);
+  if (!qkv || !out || !lse || B <= 0 || heads <= 0 || N <= 0 || N > AN<NT_MAX>::NPAD) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (N > AN<7>::NPAD) {       // 225 .. 320 tokens (embed_type 3: 294): generic kernels with 10 tiles
+    if (dtype == DT_BF16) return attn_fwd_t<bf16, 10>(qkv, out, lse, B, N, heads, scale, st);
+    if (dtype == DT_F32) return attn_fwd_t<float, 10>(qkv, out, lse, B, N, heads, scale, st);
+    return RGBNM_EINVAL;
+  }
+  if (dtype == DT_BF16 && rgbnm_get_option("attn_v2")) return rgbnm_launch_attn2_fwd(qkv, out, lse, B, N, heads, scale, st);
+  if (dtype == DT_BF16) return attn_fwd_t<bf16, 7>(qkv, out, lse, B, N, heads, scale, st);
+  if (dtype == DT_F32) return attn_fwd_t<float, 7>(qkv, out, lse, B, N, heads, scale, st);
   return RGBNM_EINVAL;
 }
 
 int rgbnm_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                         int B, int N, int heads, float scale, void* stream) {
-  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || heads <= 0 || N <= 0 || N > NPAD) return RGBNM_EINVAL;
+  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || heads <= 0 || N <= 0 || N > AN<NT_MAX>::NPAD) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (N > AN<7>::NPAD) {
+    if (dtype == DT_BF16) return attn_bwd_t<bf16, 10>(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
+    if (dtype == DT_F32) return attn_bwd_t<float, 10>(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
+    return RGBNM_EINVAL;
+  }
   if (dtype == DT_BF16 && rgbnm_get_option("attn_v2"))
-    return rgbnm_launch_attn2_bwd(qkv, out, dout, lse, dqkv, B, N, heads, scale, (hipStream_t)stream);
-  if (dtype == DT_BF16) return attn_bwd_t<bf16>(qkv, out, dout, lse, dqkv, B, N, heads, scale, (hipStream_t)stream);
-  if (dtype == DT_F32) return attn_bwd_t<float>(qkv, out, dout, lse, dqkv, B, N, heads, scale, (hipStream_t)stream);
+    return rgbnm_launch_attn2_bwd(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
+  if (dtype == DT_BF16) return attn_bwd_t<bf16, 7>(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
+  if (dtype == DT_F32) return attn_bwd_t<float, 7>(qkv, out, dout, lse, dqkv, B, N, heads, scale, st);
   return RGBNM_EINVAL;
 }
 

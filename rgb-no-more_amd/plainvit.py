@@ -76,6 +76,50 @@ class PatchEmbedding_DCT_Separate_subblock(nn.Module):
         self.conv_Y = dops.generate_conversion_matrix(8, patch_size // 8, scale=True, dtype=torch.float32)
 
 
+class PatchEmbedding_DCT_Separate(nn.Module):
+    """plainvit.py:220-278 (ver=2 / embed_type 2 WITHOUT sub-block conversion): one Linear(64, E/6) per 8x8 block of the
+    patch (Y_1..Y_4 in '(pdh pdw)' order, Cb, Cr), GELU on the concatenation, Linear(E, E), sin-cos.  Parameter holder; the
+    reference registers LinearMix twice (as `LinearMix` and inside `projection`), so both state_dict keys exist here too.
+    Compute is _PatchEmbedSepFn: the six small Linears run as ONE block-diagonal [E, 384] GEMM on the patch features."""
+
+    def __init__(self, patch_size=16, emb_size=768, chroma_scale=2, device="cpu", dtype=torch.float32):
+        super().__init__()
+        assert not (patch_size & (patch_size - 1)) and patch_size >= 2, \
+            f"Patch size should be 2^n (n>0, n=int). Current value: {patch_size}"
+        assert patch_size // chroma_scale >= 8, \
+            (f"Patch size for both Y and CbCr should be larger than 8 for this embedding method. Current patch size (Y): "
+             f"{patch_size}, chroma scale: {chroma_scale}, patch_size (CbCr): {patch_size // chroma_scale}")
+        if patch_size != 16 or chroma_scale != 2:
+            raise NotImplementedError("HIP path covers patch_size=16, 4:2:0 (JPEG-Ti/S configs)")
+        self.patch_size = patch_size
+        kw = dict(device=device, dtype=dtype)
+        nb = 6                                                # 4 luma + 2 chroma blocks per 16x16 patch
+        self.LinearY = nn.ModuleList([nn.Linear(64, emb_size // nb, **kw) for _ in range(4)])
+        self.LinearC = nn.ModuleList([nn.Linear(64, emb_size // nb, **kw) for _ in range(2)])
+        self.PreMixActivation = nn.Identity()
+        self.LinearMix = nn.Linear((emb_size // nb) * nb, emb_size, **kw)
+        self.projection = nn.Sequential(self.PreMixActivation, self.LinearMix)
+
+
+class PatchEmbedding_DCT_Concat(nn.Module):
+    """plainvit.py:353-410 (ver=3 / embed_type 3): Y and CbCr are embedded SEPARATELY with the same 16x16 sub-block patches
+    -- 14x14 luma tokens + 2 x 7x7 chroma tokens = 294 tokens, each with its own sin-cos table -- and concatenated along
+    the token axis.  Parameter holder; compute is _PatchEmbedConcatFn."""
+
+    def __init__(self, patch_size=16, emb_size=768, use_subblock=True, device="cpu", dtype=torch.float32):
+        super().__init__()
+        assert not (patch_size & (patch_size - 1)) and patch_size >= 2, \
+            f"Patch size should be 2^n (n>0, n=int). Current value: {patch_size}"
+        if patch_size != 16 or not use_subblock:
+            raise NotImplementedError("HIP path covers patch_size=16 with sub-block conversion (JPEG-Ti/S configs)")
+        self.patch_size = patch_size
+        kw = dict(device=device, dtype=dtype)
+        self.projectionY = nn.Sequential(nn.Identity(), nn.Linear(patch_size ** 2, emb_size, **kw))
+        self.projectionC = nn.Sequential(nn.Identity(), nn.Linear(patch_size ** 2, emb_size, **kw))
+        self.convMat = dops.generate_conversion_matrix(8, patch_size // 8, scale=True, dtype=torch.float32)
+        self.conv_Y = self.convMat
+
+
 def sincos_table(h, w, e, device="cpu"):
     """SinCosEmbedding (plainvit.py:90-121) as a constant (h*w, e) fp32 table."""
     hg, wg = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
@@ -100,7 +144,10 @@ class _Arena:
         f32 = torch.float32
         self.cfg = L.VitCfg(L.dt_of(T), B, N, E, model.num_heads, 1e-5, 1.0 / math.sqrt(E))
         self.feat = e(M, 384)
-        if model.ver == 2:
+        if model.embed_kind == "concat":
+            self.featC = e(B * 98, 384)
+            self.pe_ty, self.pe_tc = e(B * 196, E), e(B * 98, E)
+        elif model.embed_kind != "group":
             self.pe_g, self.pe_gp = e(M, E), e(M, E)
             if need_grad:
                 self.pe_dh = e(M, E)
@@ -236,6 +283,117 @@ class _PatchEmbed2Fn(torch.autograd.Function):
         return (None, None, None) + tuple(gr)
 
 
+_PES_NAMES = ([f"patchembed.LinearY.{i}.{k}" for i in range(4) for k in ("weight", "bias")] +
+              [f"patchembed.LinearC.{i}.{k}" for i in range(2) for k in ("weight", "bias")] +
+              ["patchembed.LinearMix.weight", "patchembed.LinearMix.bias"])
+
+
+class _PatchEmbedSepFn(torch.autograd.Function):
+    """ver=2, use_subblock=False (reference: PatchEmbedding_DCT_Separate.forward, plainvit.py:257-278) on the C-ABI kernels:
+    feat = the 2x2 luma blocks of a patch gathered as a 16x16 tile | Cb | Cr  (rgbnm_subblock_embed with the identity as
+    conversion matrix: a pure index shuffle);  h = gelu(feat Wbd^T + b)  with Wbd the block-diagonal [E, 384] arrangement of
+    the six Linear(64, E/6) (GELU epilogue);  x0 = h Wmix^T + bmix + sincos.  Backward: the dense [E, 384] weight gradient is
+    computed by the dW GEMM and its six diagonal blocks are the parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, y, cbcr, st, *params):
+        m, a = st.model, st.arena
+        lib, dt, M, E = L.lib(), a.cfg.dtype, a.cfg.B * a.cfg.N, a.cfg.E
+        Hb, Wb = y.shape[2], y.shape[3]
+        if (Hb // 2) * (Wb // 2) != a.cfg.N:
+            raise ValueError("expected a 28 x 28 block grid")
+        L.check(lib.rgbnm_subblock_embed(L.dt_of(y.dtype), dt, y.data_ptr(), cbcr.data_ptr(), m._eye16.data_ptr(),
+                                         a.feat.data_ptr(), a.cfg.B, Hb, Wb, 0, L.stream()), "subblock_embed")
+        wbd, bcat = m._sep_operands(a.cdtype)
+        g, gp = a.pe_g, a.pe_gp
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_GELU, a.feat.data_ptr(), 384, wbd.data_ptr(), 384, g.data_ptr(), E,
+                                  bcat.data_ptr(), None, 0, gp.data_ptr(), E, None, 0, M, E, 384, 0, L.stream()), "pe-sep blocks")
+        bm = m._named["patchembed.LinearMix.bias"]
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_POS, g.data_ptr(), E, m._sh_ptr("peMix", "ws"), E, a.xbuf(0).data_ptr(), E,
+                                  bm.data_ptr(), None, 0, None, 0, m._pos.data_ptr(), a.cfg.N, M, E, E, 0, L.stream()),
+                "pe-sep mix")
+        ctx.st = st
+        return a.xbuf(0).detach()
+
+    @staticmethod
+    def backward(ctx, dx0):
+        st = ctx.st
+        m, a = st.model, st.arena
+        lib, dt, M, E = L.lib(), a.cfg.dtype, a.cfg.B * a.cfg.N, a.cfg.E
+        dx0 = dx0.contiguous()
+        gr = [m._gview(st.gbuf, n) for n in _PES_NAMES]
+        ws, wsb = a.ws.data_ptr(), a.ws_bytes
+        L.check(lib.rgbnm_gemm_tn(dt, dx0.data_ptr(), E, a.pe_g.data_ptr(), E, gr[12].data_ptr(), gr[13].data_ptr(), M, E,
+                                  E, 0, 0, ws, wsb, L.stream()), "pe-sep dWmix")
+        dh = a.pe_dh
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_DGELU, dx0.data_ptr(), E, m._sh_ptr("peMix", "wst"), E, dh.data_ptr(), E,
+                                  None, a.pe_gp.data_ptr(), E, None, 0, None, 0, M, E, E, 0, L.stream()), "pe-sep dh")
+        dwbd = torch.empty(E, 384, device=dx0.device, dtype=torch.float32)
+        dbcat = torch.empty(E, device=dx0.device, dtype=torch.float32)
+        L.check(lib.rgbnm_gemm_tn(dt, dh.data_ptr(), E, a.feat.data_ptr(), 384, dwbd.data_ptr(), dbcat.data_ptr(), M, E,
+                                  384, 0, 0, ws, wsb, L.stream()), "pe-sep dWbd")
+        e6 = E // 6
+        for i in range(6):                                   # diagonal blocks of the dense gradient = the six Linears
+            gr[2 * i].copy_(dwbd[i * e6:(i + 1) * e6].index_select(1, m._sep_cols[i]))
+            gr[2 * i + 1].copy_(dbcat[i * e6:(i + 1) * e6])
+        if m._grad_sync is not None:
+            m._grad_sync.ready(st.gbuf, _PES_NAMES, last=True)
+        return (None, None, None) + tuple(gr)
+
+
+_PE3_NAMES = ["patchembed.projectionY.1.weight", "patchembed.projectionY.1.bias", "patchembed.projectionC.1.weight",
+              "patchembed.projectionC.1.bias"]
+
+
+class _PatchEmbedConcatFn(torch.autograd.Function):
+    """ver=3 (reference: PatchEmbedding_DCT_Concat.forward, plainvit.py:393-410).  The chroma tensor (B,2,14,14,8,8) is the
+    luma layout of a batch of 2B single-plane images on a 14x14 block grid, so the same sub-block kernel combines its 2x2
+    blocks into 16x16 tiles; token order 'b (c h w)' falls out of that view.  Two GEMMs with the sin-cos epilogue (periods
+    196 and 49), then the two token groups are laid side by side per image."""
+
+    @staticmethod
+    def forward(ctx, y, cbcr, st, wy, by, wc, bc):
+        m, a = st.model, st.arena
+        lib, dt, E, B = L.lib(), a.cfg.dtype, a.cfg.E, a.cfg.B
+        if y.shape[2:4] != (28, 28) or cbcr.shape[2:4] != (14, 14):
+            raise ValueError("expected a 28 x 28 luma / 14 x 14 chroma block grid")
+        idt = L.dt_of(y.dtype)
+        zc = m._zero_chroma(2 * B, y.dtype)
+        L.check(lib.rgbnm_subblock_embed(idt, dt, y.data_ptr(), cbcr.data_ptr(), m._conv16.data_ptr(), a.feat.data_ptr(),
+                                         B, 28, 28, 0, L.stream()), "subblock_embed Y")
+        L.check(lib.rgbnm_subblock_embed(idt, dt, cbcr.data_ptr(), zc.data_ptr(), m._conv16.data_ptr(), a.featC.data_ptr(),
+                                         2 * B, 14, 14, 0, L.stream()), "subblock_embed C")
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_POS, a.feat.data_ptr(), 384, m._sh_ptr("peY3", "ws"), 256, a.pe_ty.data_ptr(), E,
+                                  by.data_ptr(), None, 0, None, 0, m._pos.data_ptr(), 196, B * 196, E, 256, 0, L.stream()),
+                "pe3 Y")
+        L.check(lib.rgbnm_gemm_nt(dt, L.EPI_POS, a.featC.data_ptr(), 384, m._sh_ptr("peC3", "ws"), 256, a.pe_tc.data_ptr(), E,
+                                  bc.data_ptr(), None, 0, None, 0, m._pos7.data_ptr(), 49, B * 98, E, 256, 0, L.stream()),
+                "pe3 C")
+        x0 = a.xbuf(0).view(B, 294, E)
+        x0[:, :196].copy_(a.pe_ty.view(B, 196, E))
+        x0[:, 196:].copy_(a.pe_tc.view(B, 98, E))
+        ctx.st = st
+        return a.xbuf(0).detach()
+
+    @staticmethod
+    def backward(ctx, dx0):
+        st = ctx.st
+        m, a = st.model, st.arena
+        lib, dt, E, B = L.lib(), a.cfg.dtype, a.cfg.E, a.cfg.B
+        dxv = dx0.contiguous().view(B, 294, E)
+        dty = dxv[:, :196].contiguous()
+        dtc = dxv[:, 196:].contiguous()
+        gr = [m._gview(st.gbuf, n) for n in _PE3_NAMES]
+        ws, wsb = a.ws.data_ptr(), a.ws_bytes
+        L.check(lib.rgbnm_gemm_tn(dt, dty.data_ptr(), E, a.feat.data_ptr(), 384, gr[0].data_ptr(), gr[1].data_ptr(),
+                                  B * 196, E, 256, 0, 0, ws, wsb, L.stream()), "pe3 dWy")
+        L.check(lib.rgbnm_gemm_tn(dt, dtc.data_ptr(), E, a.featC.data_ptr(), 384, gr[2].data_ptr(), gr[3].data_ptr(),
+                                  B * 98, E, 256, 0, 0, ws, wsb, L.stream()), "pe3 dWc")
+        if m._grad_sync is not None:
+            m._grad_sync.ready(st.gbuf, _PE3_NAMES, last=True)
+        return (None, None, None) + tuple(gr)
+
+
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, st, idx, *params):
@@ -311,9 +469,11 @@ class ViT(FlatParamModule):
         super().__init__()
         if pixel_space.lower() not in ("dct", "rgb2dct"):
             raise NotImplementedError("rgb-no-more_amd implements the --domain DCT path only")
-        if ver not in (1, 2) or (ver == 2 and not use_subblock):
-            raise NotImplementedError("embed_type 1 (PatchEmbedding_DCT_Group) and 2 with use_subblock "
-                                      "(PatchEmbedding_DCT_Separate_subblock); ver=3 has 294 tokens (SURVEY.md 8f f3)")
+        if ver not in (1, 2, 3):
+            raise NotImplementedError("ver must be 1 (PatchEmbedding_DCT_Group), 2 (PatchEmbedding_DCT_Separate / "
+                                      "_Separate_subblock) or 3 (PatchEmbedding_DCT_Concat)")
+        if ver in (1, 3) and not use_subblock:
+            raise NotImplementedError("embed_type 1 / 3 without sub-block conversion are not in any reference config")
         if drop_p not in (0, 0.0):
             raise NotImplementedError("dropout p must be 0 (cfg.TRAIN.DROP default, configs.py:27)")
         if head_size != 64 or emb_size not in (192, 384) or input_embed >= 0:
@@ -326,12 +486,15 @@ class ViT(FlatParamModule):
         self.pixel_space = pixel_space
         self.emb_size, self.depth, self.n_classes = emb_size, depth, n_classes
         self.num_heads, self.inner = num_heads, num_heads * head_size
-        self.n_tokens = 196
+        self.n_tokens = 294 if ver == 3 else 196          # ver 3: 14x14 luma + 2 x 7x7 chroma tokens
         E = emb_size
         kw = dict(device=device, dtype=dtype)
         self.ver = ver
-        self.patchembed = (PatchEmbedding_DCT_Group(patch_size, E, use_subblock, **kw) if ver == 1 else
-                           PatchEmbedding_DCT_Separate_subblock(patch_size, E, **kw))
+        self.embed_kind = {1: "group", 3: "concat"}.get(ver, "sep_sub" if use_subblock else "sep")
+        self.patchembed = {"group": lambda: PatchEmbedding_DCT_Group(patch_size, E, use_subblock, **kw),
+                           "sep_sub": lambda: PatchEmbedding_DCT_Separate_subblock(patch_size, E, **kw),
+                           "sep": lambda: PatchEmbedding_DCT_Separate(patch_size, E, **kw),
+                           "concat": lambda: PatchEmbedding_DCT_Concat(patch_size, E, use_subblock, **kw)}[self.embed_kind]()
         blocks = []
         for _ in range(depth):
             att = ResidualAdd(nn.Sequential(OrderedDict([
@@ -366,11 +529,15 @@ class ViT(FlatParamModule):
         params = self._pack_parameters()
         offs = self._offs
         # ---- Linear descriptors + shadow layout
-        if self.ver == 1:
+        if self.embed_kind == "group":
             lin = [("pe", "patchembed.projection.0", 0)]
-        else:
+        elif self.embed_kind == "sep_sub":
             lin = [("peY", "patchembed.projection_Y.1", 0), ("peC", "patchembed.projection_C.1", 0),
                    ("peM", "patchembed.linearMix", 0)]
+        elif self.embed_kind == "sep":
+            lin = [("peMix", "patchembed.LinearMix", 0)]
+        else:
+            lin = [("peY3", "patchembed.projectionY.1", 0), ("peC3", "patchembed.projectionC.1", 0)]
         for i in range(self.depth):
             lin += [(f"qkv{i}", f"encoder.{i}.0.fn.eb_mha.qkv", self.num_heads),
                     (f"proj{i}", f"encoder.{i}.0.fn.eb_mha.projection", 0),
@@ -392,8 +559,19 @@ class ViT(FlatParamModule):
         self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         self._bias_perm = torch.zeros(max(bo, 1), device=dev, dtype=torch.float32)
         self._shadow = {}
-        self._conv16 = self.patchembed.conv_Y.to(dev).contiguous()
+        if self.embed_kind == "sep":
+            # feature column of coefficient (p1, p2) of luma block (pdh, pdw) in the 16x16 tile that the sub-block kernel emits
+            self._eye16 = torch.eye(16, device=dev, dtype=torch.float32)
+            p1, p2 = torch.meshgrid(torch.arange(8), torch.arange(8), indexing="ij")
+            cols = [((pdh * 8 + p1) * 16 + pdw * 8 + p2).reshape(-1) for pdh in range(2) for pdw in range(2)]
+            cols += [256 + torch.arange(64), 320 + torch.arange(64)]
+            self._sep_cols = [c.to(dev) for c in cols]
+            self._sep_cache = {}
+        else:
+            self._conv16 = self.patchembed.conv_Y.to(dev).contiguous()
         self._pos = sincos_table(14, 14, self.emb_size, dev)
+        self._pos7 = sincos_table(7, 7, self.emb_size, dev) if self.embed_kind == "concat" else None
+        self._zc = {}
         # names in the field order of BlockGrads / HeadGrads
         self._block_names, self._block_param_order, self._bparams_by_dtype = [], [], {}
         for i in range(self.depth):
@@ -408,6 +586,29 @@ class ViT(FlatParamModule):
                             "classhead.ch_linear1.bias", "classhead.ch_linear2.weight", "classhead.ch_linear2.bias"]
         self._head_param_order = [n for n in self._names() if n.startswith("classhead.")]
         self._arenas = {}
+
+    def _zero_chroma(self, n, dtype):
+        """(n, 2, 7, 7, 8, 8) zeros: the chroma argument of the sub-block kernel when the chroma planes themselves are
+        embedded as luma (ver=3); its 128 output features are not used."""
+        k = (n, dtype)
+        if k not in self._zc:
+            self._zc[k] = torch.zeros(n, 2, 7, 7, 8, 8, device=self._flat.device, dtype=dtype)
+        return self._zc[k]
+
+    def _sep_operands(self, cdtype):
+        """Block-diagonal [E, 384] operand of the six per-block Linears (+ concatenated bias) for this step."""
+        E, e6 = self.emb_size, self.emb_size // 6
+        key = cdtype
+        if key not in self._sep_cache:
+            self._sep_cache[key] = (torch.zeros(E, 384, device=self._flat.device, dtype=cdtype),
+                                    torch.zeros(E, device=self._flat.device, dtype=torch.float32))
+        wbd, bcat = self._sep_cache[key]
+        named = self._named
+        for i in range(6):
+            mod = f"patchembed.LinearY.{i}" if i < 4 else f"patchembed.LinearC.{i - 4}"
+            wbd[i * e6:(i + 1) * e6].index_copy_(1, self._sep_cols[i], named[mod + ".weight"].detach().to(cdtype))
+            bcat[i * e6:(i + 1) * e6].copy_(named[mod + ".bias"].detach())
+        return wbd, bcat
 
     def _pptr(self, name):
         return self._flat.data_ptr() + self._offs[name] * 4
@@ -490,11 +691,15 @@ class ViT(FlatParamModule):
         st = _FwdState(self, arena, self._grad_buffer() if need_grad else None)
         st.ln_chain = bool(L.lib().rgbnm_vit_ln_chain(C.byref(arena.cfg)))
         named = self._named
-        if self.ver == 1:
+        if self.embed_kind == "group":
             h = _PatchEmbedFn.apply(x, cbcr, st, named["patchembed.projection.0.weight"],
                                     named["patchembed.projection.0.bias"])
-        else:
+        elif self.embed_kind == "sep_sub":
             h = _PatchEmbed2Fn.apply(x, cbcr, st, *[named[n] for n in _PE2_NAMES])
+        elif self.embed_kind == "sep":
+            h = _PatchEmbedSepFn.apply(x, cbcr, st, *[named[n] for n in _PES_NAMES])
+        else:
+            h = _PatchEmbedConcatFn.apply(x, cbcr, st, *[named[n] for n in _PE3_NAMES])
         for i in range(self.depth):
             h = _BlockFn.apply(h, st, i, *[named[n] for n in self._block_param_order[i]])
         return _HeadFn.apply(h, st, *[named[n] for n in self._head_param_order])

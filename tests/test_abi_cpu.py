@@ -47,8 +47,19 @@ def test_state_dict_surface_matches_reference(golden):
     m2 = rg.ViT(3, 16, 192, depth=2, n_classes=1000, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=2)
     assert list(m2.state_dict().keys()) == [str(s) for s in g2["ti_d2_v2_names"]]
     assert [str(tuple(v.shape)) for v in m2.state_dict().values()] == [str(s) for s in g2["ti_d2_v2_shapes"]]
+    # ver=2 without sub-block conversion: PatchEmbedding_DCT_Separate keys, LinearMix registered twice like the reference
+    g3 = golden("g19_model_v2ns.npz")
+    m3 = rg.ViT(3, 16, 192, depth=2, n_classes=1000, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=2,
+                use_subblock=False)
+    assert list(m3.state_dict().keys()) == [str(s) for s in g3["ti_d2_v2ns_names"]]
+    assert [str(tuple(v.shape)) for v in m3.state_dict().values()] == [str(s) for s in g3["ti_d2_v2ns_shapes"]]
+    assert m3.state_dict()["patchembed.projection.1.weight"].data_ptr() == m3.state_dict()["patchembed.LinearMix.weight"].data_ptr()
+    # ver=3 (embed_type 3): PatchEmbedding_DCT_Concat keys; 294 tokens
+    g4 = golden("g18_model_v3.npz")
+    m4 = rg.ViT(3, 16, 192, depth=2, n_classes=1000, drop_p=0.0, num_heads=3, head_size=64, pixel_space="DCT", ver=3)
+    assert list(m4.state_dict().keys()) == [str(s) for s in g4["ti_d2_v3_names"]] and m4.n_tokens == 294
     with pytest.raises(NotImplementedError):
-        rg.ViT(3, 16, 192, depth=1, drop_p=0.0, num_heads=3, pixel_space="DCT", ver=3)
+        rg.ViT(3, 16, 192, depth=1, drop_p=0.0, num_heads=3, pixel_space="DCT", ver=4)
 
 
 def test_no_cpu_fallback():

@@ -176,7 +176,8 @@ def ref_attention(qkv, B, N, H, scale):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("B,N,H", [(3, 196, 3), (2, 196, 6), (2, 64, 3), (1, 100, 2)])
+@pytest.mark.parametrize("B,N,H", [(3, 196, 3), (2, 196, 6), (2, 64, 3), (1, 100, 2),
+                                   (2, 294, 3), (1, 294, 6), (1, 225, 2), (1, 320, 1)])   # > 224 tokens: embed_type 3 (10-tile kernels)
 def test_attention_fwd_bwd(dt, B, N, H):
     I = H * 64
     scale = 1.0 / math.sqrt(H * 64)

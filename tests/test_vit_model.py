@@ -284,6 +284,135 @@ def test_embed_type2_fp32_and_bf16_vs_reference_golden(golden, tag, emb, heads):
     assert np.median(rel) < 2e-2 and rel.max() < 0.15
 
 
+@pytest.mark.parametrize("tag,emb,heads", [("ti_d2_v2ns", 192, 3), ("s_d2_v2ns", 384, 6)])
+def test_embed_type2_without_subblock_vs_reference_golden(golden, tag, emb, heads):
+    """ver=2, use_subblock=False (PatchEmbedding_DCT_Separate, models/plainvit.py:220-278): six Linear(64, E/6) + GELU +
+    LinearMix.  Golden g19 from the reference (tests/golden/make_golden_r2.py): same state_dict keys (incl. the reference's
+    double registration of LinearMix as `projection.1`), fp32 logits within 1e-3, every gradient norm, bf16 tolerance."""
+    g = golden("g19_model_v2ns.npz")
+    m = rg.ViT(3, 16, emb, depth=2, n_classes=1000, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
+               pixel_space="DCT", ver=2, use_subblock=False)
+    assert [str(s) for s in g[tag + "_names"]] == list(m.state_dict().keys())
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert [str(v) for v in shapes.values()] == [str(s) for s in g[tag + "_shapes"]]
+    sd = detfill.fill_state_dict(shapes, base_seed=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    B = 2
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 73, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    m.train()
+    m.compute_dtype = torch.float32
+    logits = m(y, c)
+    x0 = logits.grad_fn.st.arena.x[0].view(B, 196, emb)[:, ::49, ::16].float().cpu().numpy()
+    np.testing.assert_allclose(x0, g[tag + "_x0_slice"], rtol=0, atol=2e-5)
+    err = np.abs(logits.detach().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] fp32 max |dlogit| = {err:.3e}")
+    assert err <= 1e-3 and err <= 5e-5
+    loss = rg.cls_transforms.cross_entropy(logits, tgt)
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-5
+    loss.backward()
+    gn = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=1e-3, atol=1e-7)
+    named = dict(m.named_parameters())
+    for nm in ("patchembed.LinearY.0.weight", "patchembed.LinearY.3.bias", "patchembed.LinearC.1.weight",
+               "patchembed.LinearMix.weight"):
+        got = named[nm].grad.reshape(-1)[::37].cpu().numpy()
+        np.testing.assert_allclose(got, g[tag + "_grad_" + nm], rtol=2e-3, atol=3e-7, err_msg=nm)
+    m.zero_grad(set_to_none=True)
+    m.compute_dtype = torch.bfloat16
+    lb = m(y, c)
+    errb = np.abs(lb.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] bf16 max |dlogit| = {errb:.3e}")
+    assert errb <= 2.5e-2
+    rg.cls_transforms.cross_entropy(lb, tgt, grad_dtype=torch.bfloat16).backward()
+    gnb = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    rel = np.abs(gnb - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+
+
+@pytest.mark.parametrize("tag,emb,heads,depth,B", [("ti_d2_v3", 192, 3, 2, 2), ("s_d2_v3", 384, 6, 2, 2), ("ti_d12_v3", 192, 3, 12, 3)])
+def test_embed_type3_concat_vs_reference_golden(golden, tag, emb, heads, depth, B):
+    """ver=3 (embed_type 3, PatchEmbedding_DCT_Concat, models/plainvit.py:353-410): 196 luma + 98 chroma tokens = 294, which
+    runs the 10-tile attention kernels.  Golden g18 from the reference: state_dict surface, patch-embedding output slice,
+    fp32 logits within 1e-3, every gradient norm, bf16 tolerance."""
+    g = golden("g18_model_v3.npz")
+    m = rg.ViT(3, 16, emb, depth=depth, n_classes=1000, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
+               pixel_space="DCT", ver=3, use_subblock=True)
+    assert [str(s) for s in g[tag + "_names"]] == list(m.state_dict().keys())
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert [str(v) for v in shapes.values()] == [str(s) for s in g[tag + "_shapes"]]
+    sd = detfill.fill_state_dict(shapes, base_seed=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 73, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    m.train()
+    m.compute_dtype = torch.float32
+    logits = m(y, c)
+    x0 = logits.grad_fn.st.arena.x[0].view(B, 294, emb)[:, ::49, ::16].float().cpu().numpy()
+    np.testing.assert_allclose(x0, g[tag + "_x0_slice"], rtol=0, atol=2e-5)
+    err = np.abs(logits.detach().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] fp32 max |dlogit| = {err:.3e}")
+    assert err <= 1e-3 and err <= 5e-5
+    loss = rg.cls_transforms.cross_entropy(logits, tgt)
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-5
+    loss.backward()
+    gn = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=1e-3, atol=1e-7)
+    named = dict(m.named_parameters())
+    for nm in ("patchembed.projectionY.1.weight", "patchembed.projectionC.1.weight", "patchembed.projectionC.1.bias"):
+        got = named[nm].grad.reshape(-1)[::37].cpu().numpy()
+        np.testing.assert_allclose(got, g[tag + "_grad_" + nm], rtol=2e-3, atol=3e-7, err_msg=nm)
+    m.zero_grad(set_to_none=True)
+    m.compute_dtype = torch.bfloat16
+    lb = m(y, c)
+    errb = np.abs(lb.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
+    print(f"[{tag}] bf16 max |dlogit| = {errb:.3e}")
+    assert errb <= 2.5e-2
+    rg.cls_transforms.cross_entropy(lb, tgt, grad_dtype=torch.bfloat16).backward()
+    gnb = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    rel = np.abs(gnb - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+
+
+def test_embed_type3_large_batch_fast_kernels_agree_with_generic():
+    """ver=3 at B = 32 (9408 tokens): the row-panel / fused-LayerNorm / fused-MLP kernels are eligible (M >= 8192); the
+    step must agree with the same step on the generic kernels to bf16 rounding."""
+    m = rg.ViT(3, 16, 192, depth=2, n_classes=1000, drop_p=0.0, device=DEV, num_heads=3, head_size=64,
+               pixel_space="DCT", ver=3, use_subblock=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in detfill.fill_state_dict(shapes, base_seed=1).items()})
+    m.compute_dtype = torch.bfloat16
+    B = 32
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    lab = torch.from_numpy(detfill.integers((B,), 74, 0, 998, np.int64)).to(DEV)
+    lib = rg.lib.lib()
+    opts = ("nt_wres", "nt_kpipe", "ln_fuse", "mlp_fuse", "tn_pipe")
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        lg = m(y, c)
+        rg.cls_transforms.cross_entropy(lg, lab, grad_dtype=torch.bfloat16).backward()
+        return lg.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    fast_l, fast_g = run()
+    try:
+        for o in opts:
+            rg.lib.check(lib.rgbnm_set_option(o.encode(), 0))
+        gen_l, gen_g = run()
+    finally:
+        for o in opts:
+            rg.lib.check(lib.rgbnm_set_option(o.encode(), 1))
+    assert (fast_l - gen_l).abs().max().item() <= 1e-2
+    for n in fast_g:
+        rel = ((fast_g[n] - gen_g[n]).norm() / (gen_g[n].norm() + 1e-20)).item()
+        assert rel < 4e-2, (n, rel)
+
+
 def test_bf16_training_memorises_a_fixed_batch():
     """Optimisation sanity for the whole fused bf16 path (grouped dW launches, fused LayerNorm epilogues, persistent
     attention, clip + AdamW + WeightDecay): 60 steps on one fixed batch of 64 images must drive the loss from ln(1000)
