@@ -25,6 +25,7 @@ extern "C" {
 #define RGBNM_ABI_VERSION 1
 #define RGBNM_DT_F32 0
 #define RGBNM_DT_BF16 1
+#define RGBNM_DT_I16 2   /* only as out_dtype of rgbnm_dct_augment[_ex] */
 
 /* epilogues of rgbnm_gemm_nt */
 #define RGBNM_EPI_NONE 0   /* C = A.W^T (+bias)                                         */
@@ -161,8 +162,11 @@ size_t rgbnm_dct_augment_workspace(int B);
  * read_coefficients.  crop_w must be 56, 28 or 14 (resize /2, identity, x2 -> 28x28 luma / 14x14 chroma blocks).
  * params are needed twice: on the device (kernels) and on the host (validated before launch).
  * conv16: A(8,2) 16x16 fp32; filters: [n][64] fp32 multipliers for MIDFREQAUG/SHARPNESS (may be NULL if unused).
- * outY [B,1,28,28,8,8], outC [B,2,14,14,8,8] in out_dtype, after ToRange(-1,1; -1024,1016).
- * entry_clamp: clamp before the first op (RandAugment_dct.forward, :1106-1108); nops in {0,1,2}. */
+ * outY [B,1,28,28,8,8], outC [B,2,14,14,8,8] in out_dtype, after ToRange(-1,1; -1024,1016); out_dtype 2 (RGBNM_DT_I16)
+ * stores the int16 coefficients themselves, WITHOUT ToRange (the per-transform classes of custom_transforms.py chain on it).
+ * entry_clamp bit 0: clamp before the first op (RandAugment_dct.forward, :1106-1108); bit 1: the input is already
+ * de-quantised (unit tables) and must NOT be clamped in front of the crop / resize / flip stage (the reference's per-transform
+ * classes pass out-of-range coefficients of a preceding resize through unchanged).  nops in {0,1,2}. */
 int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* quant, const rgbnm_aug_params* params_dev,
                       const rgbnm_aug_params* params_host, const float* conv16, const float* filters, void* outY,
                       void* outC, int out_dtype, int B, int Hy, int Wy, int Hc, int Wc, int entry_clamp, int nops,

@@ -53,14 +53,26 @@ def _choose_closest(val, choices, maxval):
     return closest
 
 
-class RandomResizedCrop_DCT:
-    """Parameter sampler with the reference's semantics (custom_transforms.py:527-629), ratio == (1, 1)."""
+class RandomResizedCrop_DCT(torch.nn.Module):
+    """Reference semantics (custom_transforms.py:527-663), ratio == (1, 1): `get_params` samples the crop box with the
+    reference's distribution; `forward(coeff)` crops and resizes device int16 coefficients (tensor or (Y, CbCr)) on the HIP
+    augment kernels and returns int16 coefficients on the `size` x `size` block grid."""
 
-    def __init__(self, size, scale=(0.05, 1.0), ratio=(1, 1), chroma_scale=2):
+    def __init__(self, size, scale=(0.05, 1.0), ratio=(1, 1), chroma_scale=2, dtype_resize=torch.float32):
+        super().__init__()
         if tuple(ratio) != (1, 1):
             raise NotImplementedError("the DCT pipelines use ratio=(1,1) (datasets.py:356,373)")
+        if dtype_resize != torch.float32:
+            raise NotImplementedError("resize runs in fp32 (the reference's default dtype_resize)")
         self.size, self.scale, self.chroma_scale = size, scale, chroma_scale
         self.even_size_choices = even_size_choices(size)
+
+    def forward(self, coeff, box=None):
+        """box: explicit (i, j, h, w) for every sample (parity tests); default: one get_params() draw per sample."""
+        Y, C, single, batched = _unpack(coeff)
+        B, H, W = Y.shape[0], Y.shape[2], Y.shape[3]
+        boxes = [box] * B if box is not None else [self.get_params(H, W) for _ in range(B)]
+        return _pack(*_run_chain(Y, C, self.size, boxes, None, None, 0, torch.int16), single, batched)
 
     def get_params(self, height, width, rng=torch):
         area = height * width
@@ -94,13 +106,20 @@ class RandomResizedCrop_DCT:
         return i, j, max(1, h), max(1, w)
 
 
-class ResizedCenterCrop_DCT:
-    """Eval crop box (custom_transforms.py:819-882): crop size_crop/size_resize of the grid, centred, even offsets."""
+class ResizedCenterCrop_DCT(torch.nn.Module):
+    """Eval transform (custom_transforms.py:819-911): crop size_crop/size_resize of the grid, centred, even offsets, then
+    resize to size_crop (= resize to size_resize + centre crop, in the cheaper order)."""
 
-    def __init__(self, size_resize, size_crop, chroma_scale=2):
+    def __init__(self, size_resize, size_crop, chroma_scale=2, dtype_resize=torch.float32):
+        super().__init__()
         self.size_resize, self.size_crop, self.chroma_scale = size_resize, size_crop, chroma_scale
         self.size = size_crop
         self.even_size_choices = even_size_choices(size_crop)
+
+    def forward(self, coeff):
+        Y, C, single, batched = _unpack(coeff)
+        box = self.get_params(Y.shape[2], Y.shape[3])
+        return _pack(*_run_chain(Y, C, self.size, [box] * Y.shape[0], None, None, 0, torch.int16), single, batched)
 
     def get_params(self, height, width):
         ratio = self.size_crop / self.size_resize
@@ -193,6 +212,233 @@ def encode_op(name, magnitude, aux, bank, grid=28):
     return op, f, a0, a1, a2
 
 
+def sample_ops(ops_list, num_ops, magnitude, meta, grid):
+    """RandAugment_dct.forward's draws for ONE sample (custom_transforms.py:1108-1123) -> [(name, magnitude, aux)].
+    The reference's `list(set(...))` reordering (:1117-1119) makes its op stream irreproducible from a seed; the
+    distribution is kept (uniform over the remaining list), the order of the list is not."""
+    ops, ops_list = [], list(ops_list)
+    for _k in range(num_ops if ops_list else 0):
+        name = ops_list[int(torch.randint(len(ops_list), (1,)).item())]
+        if name in CHROMA_OPS:
+            if name == "Grayscale":
+                ops_list = [o for o in ops_list if o not in CHROMA_OPS]
+            else:
+                ops_list = [o for o in ops_list if o != "Grayscale"]
+        mags, signed = meta[name]
+        mag = float(mags[magnitude].item()) if mags.ndim > 0 else float(mags.item())
+        if signed and int(torch.randint(2, (1,)).item()):
+            mag *= -1.0
+        aux = None
+        if name == "Cutout":
+            aux = ((torch.randint(0, grid, (1,)).item()) // 2 * 2, (torch.randint(0, grid, (1,)).item()) // 2 * 2)
+        elif name == "ChromaDrop":
+            aux = torch.rand(1).item() > 0.5
+        ops.append((name, mag, aux))
+    return ops
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The reference's per-transform classes (custom_transforms.py:406-1138) on DEVICE tensors, so that
+# `datasets.get_transform('imagenet_dct' | 'imagenet_dct_swin', ...)` composes them exactly like the reference does.
+# Each forward takes what the reference's takes -- one int16 coefficient tensor (C,H,W,8,8) or a (Y, CbCr) tuple, optionally
+# with a leading batch dimension -- and returns the same structure.  Every class runs the same two HIP kernels as the fused
+# TrainTransform_DCT with the other stages switched off (identity crop, no flip, no ops, raw int16 output), so a Compose
+# chain of them is bit-identical to the fused transform; the fused one does it in one launch pair per batch.
+# ----------------------------------------------------------------------------------------------------------------
+_RUNNERS = {}
+
+
+def _unpack(coeff):
+    single = not isinstance(coeff, (tuple, list))
+    items = [coeff] if single else list(coeff)
+    if len(items) > 2 or not all(torch.is_tensor(t) for t in items):
+        raise TypeError("expected a coefficient tensor or a (Y, CbCr) tuple")
+    Y = items[0]
+    C = items[1] if len(items) == 2 else None
+    batched = Y.dim() == 6
+    if Y.dim() not in (5, 6):
+        raise AssertionError("DCT coefficients should have 5 dimensions of (C, H, W, KH, KW) where KH, KW are typically 8")
+    if not batched:
+        Y, C = Y.unsqueeze(0), (C.unsqueeze(0) if C is not None else None)
+    if Y.shape[1] != 1 or (C is not None and C.shape[1] != 2):
+        raise NotImplementedError("the device transforms take a luma tensor (c = 1) optionally followed by CbCr (c = 2)")
+    L.require_cuda(Y.contiguous(), None if C is None else C.contiguous())
+    return Y.contiguous(), (None if C is None else C.contiguous()), single, batched
+
+
+def _pack(oy, oc, single, batched):
+    if not batched:
+        oy, oc = oy[0], (None if oc is None else oc[0])
+    return oy if single else (oy, oc)
+
+
+def _run_chain(Y, C, size, boxes, flips, ops, entry_clamp, out_dtype):
+    """One pass of the augment kernels with explicit per-sample parameters; stages that are None are switched off."""
+    if Y.dtype != torch.int16 or (C is not None and C.dtype != torch.int16):
+        raise TypeError("DCT transforms work on int16 coefficients (ToRange is the only transform that leaves int16)")
+    if size not in (28, 32):
+        raise NotImplementedError("HIP augment path covers 28 x 28 ('imagenet_dct') and 32 x 32 ('imagenet_dct_swin') grids")
+    key = (size, out_dtype)
+    if key not in _RUNNERS:
+        _RUNNERS[key] = TrainTransform_DCT(size=size, out_dtype=out_dtype)
+    t = _RUNNERS[key]
+    B = Y.shape[0]
+    params = [dict(box=boxes[b], flip=bool(flips[b]) if flips is not None else False, ops=list(ops[b]) if ops is not None else [])
+              for b in range(B)]
+    quant = t._unit_quant(B, Y.device)
+    oy, oc = t(Y, C, quant, params=params, entry_flags=(1 if entry_clamp else 0) | 2)   # | 2: input is de-quantised already
+    return oy, (oc if C is not None else None)
+
+
+class Compose(torch.nn.Module):
+    """torchvision.transforms.Compose for these modules (datasets.py:354-382 composes the reference's classes with it)."""
+
+    def __init__(self, transforms):
+        super().__init__()
+        self.transforms = torch.nn.ModuleList(transforms)
+
+    def forward(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+def _whole(Y):
+    return (0, 0, Y.shape[2], Y.shape[3])
+
+
+class Resize_DCT(torch.nn.Module):
+    """custom_transforms.py:468-525: resize the whole block grid to `size` (x2, identity or /2 on the HIP path)."""
+
+    def __init__(self, size, chroma_scale=2, dtype_resize=torch.float32, strict_even_size=False):
+        super().__init__()
+        if strict_even_size:
+            assert size % 2 == 0, f"ERROR: Resize_dct should have even numbered 'size' parameter. Current size: {size}"
+        self.size, self.chroma_scale = size, chroma_scale
+
+    def forward(self, coeff):
+        Y, C, single, batched = _unpack(coeff)
+        if Y.shape[2] != Y.shape[3]:
+            raise NotImplementedError("Resize_DCT on the HIP path resizes square block grids")
+        return _pack(*_run_chain(Y, C, self.size, [_whole(Y)] * Y.shape[0], None, None, 0, torch.int16), single, batched)
+
+
+class RandomCrop_DCT(torch.nn.Module):
+    """custom_transforms.py:671-745: crop a `size` x `size` block window at a random (even) offset, no resize."""
+
+    def __init__(self, size, chroma_scale=2):
+        super().__init__()
+        self.size, self.chroma_scale = size, chroma_scale
+
+    def get_params(self, height, width):
+        h = w = self.size
+        assert w <= width and h <= height, \
+            (f"Crop window should be smaller than original image's height and width. Current window size: {h},{w}, "
+             f"Original image size: {height},{width}")
+        i = int(torch.randint(0, height - h + 1, size=(1,)).item()) // self.chroma_scale * self.chroma_scale
+        j = int(torch.randint(0, width - w + 1, size=(1,)).item()) // self.chroma_scale * self.chroma_scale
+        return i, j, h, w
+
+    def forward(self, coeff, box=None):
+        Y, C, single, batched = _unpack(coeff)
+        B = Y.shape[0]
+        boxes = [box] * B if box is not None else [self.get_params(Y.shape[2], Y.shape[3]) for _ in range(B)]
+        return _pack(*_run_chain(Y, C, self.size, boxes, None, None, 0, torch.int16), single, batched)
+
+
+class CenterCrop_DCT(torch.nn.Module):
+    """custom_transforms.py:747-817: centre crop of `size` blocks (offsets floored to even), no resize."""
+
+    def __init__(self, size, chroma_scale=2):
+        super().__init__()
+        self.size, self.chroma_scale = size, chroma_scale
+
+    def get_params(self, height, width):
+        cs = self.chroma_scale
+        w = h = self.size
+        assert w <= width and h <= height, \
+            (f"Crop window should be smaller than original image's height and width. Current window size: {h},{w}, "
+             f"Original image size: {height},{width}")
+        i = int(height - self.size) // 2 // cs * cs
+        j = int(width - self.size) // 2 // cs * cs
+        return i, j, max(1, h // cs * cs), max(1, w // cs * cs)
+
+    def forward(self, coeff):
+        Y, C, single, batched = _unpack(coeff)
+        box = self.get_params(Y.shape[2], Y.shape[3])
+        return _pack(*_run_chain(Y, C, self.size, [box] * Y.shape[0], None, None, 0, torch.int16), single, batched)
+
+
+class RandomFlip_DCT(torch.nn.Module):
+    """custom_transforms.py:913-942: with probability p reverse the block order along W and negate the odd columns of
+    every 8x8 block.  (One draw per CALL in the reference, i.e. per sample in its per-sample pipeline: one draw per sample.)"""
+
+    def __init__(self, p=0.5, direction="horizontal"):
+        super().__init__()
+        if direction != "horizontal":
+            raise NotImplementedError("the DCT pipelines flip horizontally (datasets.py:357,374)")
+        self.p, self.direction = p, direction
+
+    def forward(self, coeff, flip=None):
+        Y, C, single, batched = _unpack(coeff)
+        B = Y.shape[0]
+        flips = [bool(flip)] * B if flip is not None else [not (torch.rand(1).item() > self.p) for _ in range(B)]
+        if Y.shape[2] != Y.shape[3]:
+            raise NotImplementedError("RandomFlip_DCT on the HIP path works on the square grids after the crop/resize stage")
+        return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * B, flips, None, 0, torch.int16), single, batched)
+
+
+class RandAugment_dct(torch.nn.Module):
+    """custom_transforms.py:1024-1138: clamp, then num_ops operations drawn from ops_list at magnitude bin `magnitude`
+    (random sign for the signed ones; chroma / grayscale mutual exclusion), clamp after every op."""
+
+    def __init__(self, num_ops: int = 2, magnitude: int = 10, num_magnitude_bins: int = 11, pad=2 ** 0.5, ops_list=None):
+        super().__init__()
+        if num_ops > 2:
+            raise NotImplementedError("the HIP kernel chains up to two operations per sample (cfg.TRAIN.NUMOPS default 2)")
+        self.num_ops, self.magnitude, self.num_magnitude_bins, self.pad = num_ops, magnitude, num_magnitude_bins, pad
+        if ops_list is None:   # the reference's default list holds the DFT-domain Rotate / ShearX / ShearY (not built)
+            ops_list = ["AutoContrast", "Equalize", "Invert", "Posterize", "Solarize", "SolarizeAdd", "Color", "Contrast",
+                        "Brightness", "Sharpness", "Cutout", "TranslateX", "TranslateY"]
+        bad = [o for o in ops_list if o not in OPS]
+        if bad:
+            raise NotImplementedError(f"operations {bad} are not implemented on the HIP path")
+        self.ops_list = list(ops_list)
+
+    def forward(self, coeff, ops=None):
+        """ops: explicit [(name, magnitude, aux), ...] applied to every sample (parity tests)."""
+        if len(self.ops_list) == 0:
+            return coeff
+        Y, C, single, batched = _unpack(coeff)
+        B, S = Y.shape[0], Y.shape[2]
+        if Y.shape[2] != Y.shape[3]:
+            raise NotImplementedError("RandAugment_dct on the HIP path works on the square grids after the crop/resize stage")
+        meta = magnitude_table(self.num_magnitude_bins, (S, S))
+        chosen = [list(ops)] * B if ops is not None else \
+            [sample_ops(self.ops_list, self.num_ops, self.magnitude, meta, S) for _ in range(B)]
+        return _pack(*_run_chain(Y, C, S, [_whole(Y)] * B, None, chosen, 1, torch.int16), single, batched)
+
+
+class ToRange(torch.nn.Module):
+    """custom_transforms.py:406-454: x -> (x - orig_min) / (orig_max - orig_min) * (val_max - val_min) + val_min, cast to
+    dtype.  The HIP kernel evaluates the pipelines' instance ToRange(-1, 1, -1024, 1016) (datasets.py:360,365,377,381)."""
+
+    def __init__(self, val_min: float = -1., val_max: float = 1., orig_min: float = -1024, orig_max: float = 1024,
+                 dtype=torch.float32):
+        super().__init__()
+        self.val_min, self.val_max, self.orig_min, self.orig_max, self.dtype = val_min, val_max, orig_min, orig_max, dtype
+        if (val_min, val_max, orig_min, orig_max) != (-1, 1, -1024, 1016):
+            raise NotImplementedError("the HIP kernel implements ToRange(val_min=-1, val_max=1, orig_min=-1024, orig_max=1016)")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError("ToRange output dtype: float32 or bfloat16")
+
+    def forward(self, coeff):
+        Y, C, single, batched = _unpack(coeff)
+        if Y.shape[2] != Y.shape[3]:
+            raise NotImplementedError("ToRange on the HIP path works on the square grids after the crop/resize stage")
+        return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * Y.shape[0], None, None, 0, self.dtype), single, batched)
+
+
 class TrainTransform_DCT(torch.nn.Module):
     """Batched device version of get_transform('imagenet_dct', 'train') (datasets.py:354-361)."""
 
@@ -229,26 +475,16 @@ class TrainTransform_DCT(torch.nn.Module):
                 continue
             box = self.rrc.get_params(height, width)
             flip = not (torch.rand(1).item() > self.flip_p)
-            ops, ops_list = [], list(self.ops_list)
-            for _k in range(self.num_ops if ops_list else 0):
-                name = ops_list[int(torch.randint(len(ops_list), (1,)).item())]
-                if name in CHROMA_OPS:
-                    if name == "Grayscale":
-                        ops_list = [o for o in ops_list if o not in CHROMA_OPS]
-                    else:
-                        ops_list = [o for o in ops_list if o != "Grayscale"]
-                mags, signed = meta[name]
-                mag = float(mags[self.magnitude].item()) if mags.ndim > 0 else float(mags.item())
-                if signed and int(torch.randint(2, (1,)).item()):
-                    mag *= -1.0
-                aux = None
-                if name == "Cutout":
-                    aux = ((torch.randint(0, self.size, (1,)).item()) // 2 * 2, (torch.randint(0, self.size, (1,)).item()) // 2 * 2)
-                elif name == "ChromaDrop":
-                    aux = torch.rand(1).item() > 0.5
-                ops.append((name, mag, aux))
+            ops = sample_ops(self.ops_list, self.num_ops, self.magnitude, meta, self.size)
             out.append(dict(box=box, flip=flip, ops=ops))
         return out
+
+    def _unit_quant(self, B, device):
+        """all-ones tables: the coefficients handed to the per-transform classes are already de-quantised (datasets.py:288)"""
+        q = getattr(self, "_uq", None)
+        if q is None or q.shape[0] < B or q.device != torch.device(device):
+            q = self._uq = torch.ones(max(B, 1), 3, 8, 8, device=device, dtype=torch.int16)
+        return q[:B]
 
     def pack(self, params):
         B = len(params)
@@ -266,8 +502,9 @@ class TrainTransform_DCT(torch.nn.Module):
                     a.op[s] = 0
         return arr, nops
 
-    def forward(self, Yq, CbCrq, quant, params=None):
-        """Yq (B,1,Hy,Wy,8,8) int16, CbCrq (B,2,Hc,Wc,8,8) int16 or None, quant (B,3,8,8) int16 -- device tensors."""
+    def forward(self, Yq, CbCrq, quant, params=None, entry_flags=None):
+        """Yq (B,1,Hy,Wy,8,8) int16, CbCrq (B,2,Hc,Wc,8,8) int16 or None, quant (B,3,8,8) int16 -- device tensors.
+        entry_flags: rgbnm_dct_augment_ex's `entry_clamp` argument (default: clamp before the ops unless eval_mode)."""
         L.require_cuda(Yq, CbCrq, quant)
         if Yq.dtype != torch.int16 or quant.dtype != torch.int16 or (CbCrq is not None and CbCrq.dtype != torch.int16):
             raise TypeError("coefficients and quantisation tables must be int16 (dct_manip.read_coefficients layout)")
@@ -287,11 +524,12 @@ class TrainTransform_DCT(torch.nn.Module):
             self._ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
         oy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=self.out_dtype)
         oc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=self.out_dtype)
+        odt = 2 if self.out_dtype == torch.int16 else L.dt_of(self.out_dtype)      # 2: raw int16, no ToRange (rgbnm.h)
         rc = L.lib().rgbnm_dct_augment_ex(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
                                           C.cast(arr, C.c_void_p), self._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),
-                                          oc.data_ptr(), L.dt_of(self.out_dtype), S, B, Hy, Wy, Hc, Wc,
-                                          0 if self.eval_mode else 1, nops, self._ws.data_ptr(), self._ws.numel(),
-                                          L.stream())
+                                          oc.data_ptr(), odt, S, B, Hy, Wy, Hc, Wc,
+                                          (0 if self.eval_mode else 1) if entry_flags is None else entry_flags, nops,
+                                          self._ws.data_ptr(), self._ws.numel(), L.stream())
         if rc == -1:
             raise L.RgbnmError("dct_augment: invalid parameters (crop side must be size/2, size or 2*size luma blocks "
                                "with even offsets inside the coefficient grid; see include/rgbnm.h)")
