@@ -15,3 +15,5 @@ from . import swinv2  # noqa: F401,E402
 from .swinv2 import SwinTransformerV2  # noqa: F401,E402
 from . import eval  # noqa: F401,E402,A004
 from . import datasets  # noqa: F401,E402
+from . import loader  # noqa: F401,E402
+from .loader import DCTBatchLoader  # noqa: F401,E402

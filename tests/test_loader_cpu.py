@@ -1,0 +1,91 @@
+"""DCTBatchLoader (rgb_no_more_amd/loader.py): the host side -- sharding identical to torch's
+DistributedSampler (datasets.py:533-535), batching, the decoder thread + buffer ring, short last batch, error reporting --
+runs without a GPU (device="cpu" yields the raw coefficient batches).  The H2D + HIP-transform half is in
+tests/test_loader_gpu.py."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data.distributed import DistributedSampler
+
+from rgb_no_more_amd import dct_manip as dm
+from rgb_no_more_amd.loader import DCTBatchLoader
+
+
+@pytest.fixture()
+def files(golden, tmp_path):
+    g = golden("g1_reader.npz")
+    paths = []
+    for i in range(11):
+        p = tmp_path / f"img{i:02d}.jpg"
+        p.write_bytes(g["c64x64_jpeg"].tobytes())
+        paths.append(str(p))
+    return paths, list(range(100, 111)), g
+
+
+def test_sharding_matches_torch_distributed_sampler(files):
+    paths, labels, _ = files
+    for world in (1, 2, 3):
+        for epoch in (0, 1, 5):
+            got = []
+            for rank in range(world):
+                ld = DCTBatchLoader(paths, labels, batch_size=4, device="cpu", grid=(8, 8), seed=7, rank=rank, world_size=world)
+                ld.set_epoch(epoch)
+                ds = DistributedSampler(list(range(len(paths))), num_replicas=world, rank=rank, shuffle=True, seed=7, drop_last=False)
+                ds.set_epoch(epoch)
+                assert ld.indices() == list(iter(ds)), (world, epoch, rank)
+                assert len(ld) == -(-len(ld.indices()) // 4)
+                got += ld.indices()
+            assert set(got) == set(range(len(paths)))            # padded by wrapping: every sample at least once
+    ns = DCTBatchLoader(paths, labels, batch_size=4, device="cpu", grid=(8, 8), shuffle=False, rank=1, world_size=2)
+    assert ns.indices() == list(iter(DistributedSampler(list(range(11)), num_replicas=2, rank=1, shuffle=False)))
+
+
+def test_batches_content_order_and_short_tail(files):
+    paths, labels, g = files
+    ld = DCTBatchLoader(paths, labels, batch_size=4, device="cpu", grid=(8, 8), threads=3, prefetch=2, seed=3)
+    ld.set_epoch(2)
+    want = ld.indices()
+    seen = []
+    sizes = []
+    for (Y, C, Q), lab in ld:
+        assert Y.dtype == torch.int16 and Y.shape[1:] == (1, 8, 8, 8, 8) and C.shape[1:] == (2, 4, 4, 8, 8) and Q.shape[1:] == (3, 8, 8)
+        assert np.array_equal(Y[0].numpy(), g["c64x64_Y"]) and np.array_equal(C[-1].numpy(), g["c64x64_CbCr"])
+        assert np.array_equal(Q[0].numpy(), g["c64x64_quant"])
+        sizes.append(Y.shape[0])
+        seen += [int(v) - 100 for v in lab]
+    assert sizes == [4, 4, 3] and seen == want
+    # a second pass re-uses the ring and gives the same epoch again; drop_last drops the short batch
+    assert [int(v) - 100 for _, lab in ld for v in lab] == want
+    dl = DCTBatchLoader(paths, labels, batch_size=4, device="cpu", grid=(8, 8), drop_last=True)
+    assert len(dl) == 2 and [b[0][0].shape[0] for b in dl] == [4, 4]
+    # yielded host batches are copies: they survive the ring being refilled
+    it = iter(DCTBatchLoader(paths * 3, labels * 3, batch_size=2, device="cpu", grid=(8, 8), prefetch=1, shuffle=False))
+    first = next(it)
+    keep = first[0][0].clone()
+    for _ in it:
+        pass
+    assert torch.equal(first[0][0], keep)
+
+
+def test_errors_name_the_file_and_stop_the_decoder(files, tmp_path):
+    paths, labels, g = files
+    bad = list(paths)
+    bad[5] = str(tmp_path / "missing.jpg")
+    ld = DCTBatchLoader(bad, labels, batch_size=4, device="cpu", grid=(8, 8), shuffle=False)
+    with pytest.raises(RuntimeError, match="missing.jpg"):
+        for _ in ld:
+            pass
+    gray = tmp_path / "gray.jpg"
+    gray.write_bytes(g["g40x56_jpeg"].tobytes())                       # another grid: refused, names the file
+    ld2 = DCTBatchLoader(paths[:3] + [str(gray)], labels[:4], batch_size=4, device="cpu", grid=(8, 8), shuffle=False)
+    with pytest.raises(dm.libjpeg_exception, match="gray.jpg"):
+        next(iter(ld2))
+    # abandoning an iterator mid-epoch must not leave the decoder thread blocked
+    import threading
+    before = threading.active_count()
+    it = iter(DCTBatchLoader(paths * 4, labels * 4, batch_size=2, device="cpu", grid=(8, 8), prefetch=1))
+    next(it)
+    it.close()
+    assert threading.active_count() <= before + 0
+    with pytest.raises(ValueError):
+        DCTBatchLoader(paths, labels[:-1], batch_size=2)
