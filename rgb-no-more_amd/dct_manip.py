@@ -94,6 +94,23 @@ def read_coefficients_bytes(data: bytes):
     return _read(data=bytes(data))
 
 
+def default_threads():
+    """Decoder threads worth starting: the CPUs this process may actually use (cgroup quota / affinity), not os.cpu_count()
+    (the GPU box shows 256 hardware threads and grants 16: 256 decoder threads ran 35 % slower than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def alloc_batch(n, grid=(64, 64), pin_memory=True):
     """Reusable (pinned) staging buffers for read_coefficients_batch(out=...): allocating pinned memory per batch costs
     more than decoding it."""

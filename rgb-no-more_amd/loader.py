@@ -34,14 +34,15 @@ from . import dct_manip as dm
 
 
 class DCTBatchLoader:
-    def __init__(self, paths, labels, batch_size, device="cuda", grid=(64, 64), threads=8, prefetch=2, shuffle=True,
+    def __init__(self, paths, labels, batch_size, device="cuda", grid=(64, 64), threads=None, prefetch=2, shuffle=True,
                  seed=0, rank=0, world_size=1, drop_last=False, transform=None):
         if len(paths) != len(labels):
             raise ValueError("paths and labels differ in length")
         if batch_size <= 0 or prefetch < 1:
             raise ValueError("batch_size and prefetch must be positive")
         self.paths, self.labels = list(paths), torch.as_tensor(labels, dtype=torch.int64)
-        self.batch_size, self.grid, self.threads, self.prefetch = batch_size, tuple(grid), int(threads), int(prefetch)
+        self.batch_size, self.grid, self.prefetch = batch_size, tuple(grid), int(prefetch)
+        self.threads = int(threads) if threads else dm.default_threads()
         self.shuffle, self.seed, self.rank, self.world_size, self.drop_last = shuffle, seed, rank, world_size, drop_last
         self.device = torch.device(device)
         self.transform = transform

@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--threads", type=int, default=os.cpu_count())
+    ap.add_argument("--threads", type=int, default=dm.default_threads())
     a = ap.parse_args()
     dev = "cuda:0"
     torch.cuda.set_device(0)
