@@ -572,19 +572,7 @@ class ViT(FlatParamModule):
         self._pos = sincos_table(14, 14, self.emb_size, dev)
         self._pos7 = sincos_table(7, 7, self.emb_size, dev) if self.embed_kind == "concat" else None
         self._zc = {}
-        # names in the field order of BlockGrads / HeadGrads
-        self._block_names, self._block_param_order, self._bparams_by_dtype = [], [], {}
-        for i in range(self.depth):
-            a, b = f"encoder.{i}.0.fn.", f"encoder.{i}.1.fn."
-            self._block_names.append([a + "eb_lrnorm1.weight", a + "eb_lrnorm1.bias", b + "eb_lrnorm2.weight",
-                                      b + "eb_lrnorm2.bias", a + "eb_mha.qkv.weight", a + "eb_mha.qkv.bias",
-                                      a + "eb_mha.projection.weight", a + "eb_mha.projection.bias",
-                                      b + "eb_ffb.0.weight", b + "eb_ffb.0.bias", b + "eb_ffb.3.weight",
-                                      b + "eb_ffb.3.bias"])
-            self._block_param_order.append([n for n in self._names() if n.startswith(f"encoder.{i}.")])
-        self._head_names = ["classhead.ch_lrnorm.weight", "classhead.ch_lrnorm.bias", "classhead.ch_linear1.weight",
-                            "classhead.ch_linear1.bias", "classhead.ch_linear2.weight", "classhead.ch_linear2.bias"]
-        self._head_param_order = [n for n in self._names() if n.startswith("classhead.")]
+        self._build_names()
         self._arenas = {}
 
     def _zero_chroma(self, n, dtype):
@@ -609,6 +597,31 @@ class ViT(FlatParamModule):
             wbd[i * e6:(i + 1) * e6].index_copy_(1, self._sep_cols[i], named[mod + ".weight"].detach().to(cdtype))
             bcat[i * e6:(i + 1) * e6].copy_(named[mod + ".bias"].detach())
         return wbd, bcat
+
+    def _build_names(self):
+        """Parameter names in the field order of BlockGrads / HeadGrads, and the groups the backward finishes in order (head,
+        blocks depth-1 .. 0, patch embedding) -- the order parallel.FlatGradSync sees them.  Pure naming: works on CPU."""
+        self._block_names, self._block_param_order, self._bparams_by_dtype = [], [], {}
+        for i in range(self.depth):
+            a, b = f"encoder.{i}.0.fn.", f"encoder.{i}.1.fn."
+            self._block_names.append([a + "eb_lrnorm1.weight", a + "eb_lrnorm1.bias", b + "eb_lrnorm2.weight",
+                                      b + "eb_lrnorm2.bias", a + "eb_mha.qkv.weight", a + "eb_mha.qkv.bias",
+                                      a + "eb_mha.projection.weight", a + "eb_mha.projection.bias",
+                                      b + "eb_ffb.0.weight", b + "eb_ffb.0.bias", b + "eb_ffb.3.weight",
+                                      b + "eb_ffb.3.bias"])
+            self._block_param_order.append([n for n in self._names() if n.startswith(f"encoder.{i}.")])
+        self._head_names = ["classhead.ch_lrnorm.weight", "classhead.ch_lrnorm.bias", "classhead.ch_linear1.weight",
+                            "classhead.ch_linear1.bias", "classhead.ch_linear2.weight", "classhead.ch_linear2.bias"]
+        self._head_param_order = [n for n in self._names() if n.startswith("classhead.")]
+        self._pe_names = {"group": ["patchembed.projection.0.weight", "patchembed.projection.0.bias"], "sep_sub": _PE2_NAMES,
+                          "sep": _PES_NAMES, "concat": _PE3_NAMES}[self.embed_kind]
+
+    def grad_ready_order(self):
+        """[(names, last)] in the order the autograd nodes report finished gradients to the gradient exchange."""
+        if not hasattr(self, "_head_names"):
+            self._build_names()
+        return ([(self._head_names, False)] + [(self._block_names[i], False) for i in reversed(range(self.depth))] +
+                [(self._pe_names, True)])
 
     def _pptr(self, name):
         return self._flat.data_ptr() + self._offs[name] * 4
