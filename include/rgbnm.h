@@ -46,6 +46,8 @@ int rgbnm_abi_version(void);
  *   "attn_persist" 1  persistent attention fwd / bwd with a DMA wave (>= 256 (image, head) pairs)
  *   "nt_dmawave" 0  row-panel GEMM with a dedicated DMA wave (measured: no gain there)
  *   "trace"     0   see rgbnm_trace_collect                      "tn_wgs" 512  workgroup budget of the generic dW GEMM
+ *   "kp_split"  0   row-panel NT GEMM as two 4-wave workgroups per CU (80 KB LDS each, 2-stage ring) instead of one 7-wave
+ *                   workgroup (measured 5.5 % slower on the whole step: kept as a parity-tested alternative)
  *   "mlp_fuse"  1   FeedForwardBlock forward (fc1 + GELU + fc2 + residual [+ next LayerNorm]) as one launch (bf16, E = 192) */
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
@@ -338,6 +340,10 @@ int rgbnm_calib_stream(const void* src, void* dst, size_t bytes, int mode, int w
  * out[(wg * waves + w) * 2 + {0, 1}] = cycles to issue them / cycles until they have all completed. */
 int rgbnm_calib_vmem_issue(int mode, int workgroups, int waves, void* buf, size_t wave_bytes, int ld,
                            unsigned long long* out, void* stream);
+/* Every workgroup (`waves` waves) re-reads its own L2-resident slice of `slice_bytes` (a multiple of waves * 8 KB) `iters`
+ * times: mode 0 plain 16-byte loads, mode 1 LDS-DMA.  Prices L2 -> CU traffic (weight re-streaming of the row-panel kernels). */
+int rgbnm_calib_l2(const void* buf, size_t slice_bytes, int iters, int mode, int workgroups, int waves, void* sink,
+                   void* stream);
 
 #ifdef __cplusplus
 }

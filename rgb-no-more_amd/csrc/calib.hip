@@ -99,3 +99,53 @@ extern "C" int rgbnm_calib_vmem_issue(int mode, int workgroups, int waves, void*
                        (unsigned char*)buf, wave_bytes, ld, out);
     return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
 }
+
+// ---- what can ONE CU pull through its vector-memory path when every line is an L2 hit?  Each workgroup re-reads its OWN
+// slice (slice_bytes, bigger than the 32 KB L1, all slices of an XCD together smaller than its 4 MB L2) `iters` times.
+// mode 0: global_load_dwordx4 into registers (8 in flight per lane); mode 1: LDS-DMA (global_load_lds_dwordx4, 8 pieces in
+// flight per wave).  This prices the weight re-streaming of the row-panel kernels.
+namespace rgbnm {
+typedef __attribute__((address_space(3))) void* clds_ptr;
+typedef const __attribute__((address_space(1))) void* cglb_ptr;
+__global__ __launch_bounds__(1024) void calib_l2_kernel(const unsigned char* __restrict__ buf, size_t slice_bytes, int iters,
+                                                        int mode, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const unsigned char* base = buf + (size_t)blockIdx.x * slice_bytes;
+    const size_t per_wave = slice_bytes / nw;                 // multiple of 8 KB
+    const unsigned char* wb = base + (size_t)w * per_wave;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    unsigned acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (size_t off = 0; off < per_wave; off += 8192) {
+            if (mode == 0) {
+                u4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const u4*>(wb + off + k * 1024 + lane * 16);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += v[k][0] ^ v[k][3];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    __builtin_amdgcn_global_load_lds((cglb_ptr)(wb + off + k * 1024 + lane * 16),
+                                                     (clds_ptr)(smem + (size_t)w * 8192 + k * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+    }
+    if (mode == 1) acc = *reinterpret_cast<unsigned*>(smem + (size_t)w * 8192 + lane * 4);
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+}  // namespace rgbnm
+
+extern "C" int rgbnm_calib_l2(const void* buf, size_t slice_bytes, int iters, int mode, int workgroups, int waves, void* sink,
+                              void* stream) {
+    if (!buf || !sink || waves < 1 || waves > 16 || workgroups <= 0 || iters <= 0 || mode < 0 || mode > 1) return RGBNM_EINVAL;
+    if (slice_bytes % ((size_t)waves * 8192)) return RGBNM_EINVAL;
+    const size_t smem = mode == 1 ? (size_t)waves * 8192 : 0;
+    if (hipFuncSetAttribute((const void*)rgbnm::calib_l2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192) != hipSuccess)
+        return RGBNM_ELAUNCH;
+    hipLaunchKernelGGL(rgbnm::calib_l2_kernel, dim3(workgroups), dim3(64 * waves), smem, (hipStream_t)stream,
+                       (const unsigned char*)buf, slice_bytes, iters, mode, (unsigned*)sink);
+    return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
+}

@@ -32,7 +32,7 @@ hipEvent_t take_event() {
 // process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
 // they select between parity-tested kernels and are meant to be set before work is enqueued
 struct Opt { const char* name; std::atomic<int> value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -108,7 +108,7 @@ static bool fused_dx_lnbwd(int dt, const void* A, int lda, const void* Wt, int l
                            const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
                            float* dbeta, int M, int E, int K, void* ws, size_t ws_bytes, hipStream_t st) {
   if (dt != RGBNM_DT_BF16 || E != 192 || !rgbnm_get_option("ln_fuse") || !rgbnm_get_option("nt_kpipe")) return false;
-  if (ws_bytes < (size_t)cdiv(M, cdiv(M, 256)) * 2 * E * sizeof(float)) return false;
+  if (ws_bytes < (size_t)cdiv(M, cdiv(M, 512)) * 2 * E * sizeof(float)) return false;    // up to 512 row panels (kp_split)
   int npanels = 0;
   const int rc = rgbnm_launch_nt_kpipe_lnbwd(A, lda, Wt, ldw, x, E, gamma, mean, rstd, dres, E, dx, E, (float*)ws,
                                              &npanels, M, E, K, st);

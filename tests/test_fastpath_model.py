@@ -183,3 +183,39 @@ def test_fused_mlp_forward_equals_the_two_gemm_path():
         nd = int((a != b).sum())
         print(f"{k:8s} max |d| {float((a - b).abs().max()):.3e}  differing elements {nd} / {a.numel()}")
         assert torch.equal(fused[k], plain[k]), k
+
+
+def test_row_panel_gemm_two_workgroups_per_cu_equals_one():
+    """gemm_nt_kpipe in its two geometries (option kp_split: 4-wave workgroups, two per CU, 2-stage ring / one 7-wave workgroup
+    per CU, 3-stage ring): per row the arithmetic is the same (k order, bf16 staging, LayerNorm butterflies), so logits, saved
+    activations and every gradient that does not depend on the panel count are bit-identical; the LayerNorm gamma / beta
+    gradients are sums over a different number of panel partials (fp32 rounding only)."""
+    lib = L.lib()
+    m, sd, y, c, tgt = build("ti_d2_b64", torch.bfloat16)
+    m.train()
+
+    def snapshot():
+        m.zero_grad()
+        logits = m(y, c)
+        ar = logits.grad_fn.st.arena
+        snap = {"x1": ar.x[1].clone(), "xn2_0": ar.blk[0]["xn2"].clone(), "xn1_1": ar.blk[1]["xn1"].clone(),
+                "rstd1_1": ar.blk[1]["rstd1"].clone(), "logits": logits.detach().clone()}
+        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
+        snap["grads"] = {n: p.grad.clone() for n, p in m.named_parameters()}
+        return snap
+
+    assert lib.rgbnm_get_option(b"kp_split") == 0       # default: one workgroup per CU (measured faster)
+    one = snapshot()
+    try:
+        L.check(lib.rgbnm_set_option(b"kp_split", 1))
+        two = snapshot()
+    finally:
+        L.check(lib.rgbnm_set_option(b"kp_split", 0))
+    for k in ("x1", "xn2_0", "xn1_1", "rstd1_1", "logits"):
+        assert torch.equal(two[k], one[k]), k
+    for n in two["grads"]:
+        a, b = two["grads"][n], one["grads"][n]
+        if "lrnorm" in n and "classhead" not in n:
+            assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), n
+        else:
+            assert torch.equal(a, b), n
