@@ -35,6 +35,7 @@
 // stretches to 3400 cycles); scalar instead of packed fp32 GELU arithmetic (88 us).
 #include "common.h"
 #include "internal.h"
+#include "../../include/rgbnm.h"
 
 namespace {
 
@@ -60,7 +61,7 @@ struct MlpArgs {
   const bf16* X; const bf16* W1; const float* b1; const bf16* W2; const float* b2; const bf16* R;
   bf16* G; bf16* GP; bf16* Y;
   int ldx, ldr, ldg, ldy;
-  int M, rows_per_wg, npanels;
+  int M, rows_per_wg, npanels, cold;       // cold: 1 = nt stores, 2 = sc1 (write-through) stores for the saved tensors
   const float* gamma; const float* beta; bf16* Y2; float* mean_o; float* rstd_o; float eps; int ldy2;   // gamma == null: no LN
 };
 
@@ -205,8 +206,15 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
       const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + STG_TILE + so);
       if (32 * w + row < rows) {
         const size_t go = (size_t)(m0 + 32 * w + row) * p.ldg + chunk * CH + vec * 8;
-        *reinterpret_cast<bf16x8*>(p.G + go) = v0;
-        *reinterpret_cast<bf16x8*>(p.GP + go) = v1;
+        // gelu(u) / gelu'(u) are read again only in the backward, seconds of traffic later: with the non-temporal hint they do
+        // not push the tensors the next kernels are about to read out of the Infinity Cache
+        if (p.cold == 1) {
+          __builtin_nontemporal_store(v0, reinterpret_cast<bf16x8*>(p.G + go));
+          __builtin_nontemporal_store(v1, reinterpret_cast<bf16x8*>(p.GP + go));
+        } else {
+          *reinterpret_cast<bf16x8*>(p.G + go) = v0;
+          *reinterpret_cast<bf16x8*>(p.GP + go) = v1;
+        }
       }
     }
   }
@@ -312,6 +320,7 @@ int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1
   p.X = (const bf16*)X; p.W1 = (const bf16*)W1; p.b1 = b1; p.W2 = (const bf16*)W2; p.b2 = b2; p.R = (const bf16*)R;
   p.G = (bf16*)G; p.GP = (bf16*)GP; p.Y = (bf16*)Y;
   p.ldx = ldx; p.ldr = ldr; p.ldg = ldg; p.ldy = ldy; p.M = M;
+  p.cold = rgbnm_get_option("nt_cold");
   p.gamma = gamma; p.beta = beta; p.Y2 = (bf16*)Y2; p.mean_o = mean; p.rstd_o = rstd; p.eps = eps; p.ldy2 = ldy2;
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;
