@@ -344,6 +344,11 @@ int rgbnm_calib_vmem_issue(int mode, int workgroups, int waves, void* buf, size_
  * times: mode 0 plain 16-byte loads, mode 1 LDS-DMA.  Prices L2 -> CU traffic (weight re-streaming of the row-panel kernels). */
 int rgbnm_calib_l2(const void* buf, size_t slice_bytes, int iters, int mode, int workgroups, int waves, void* sink,
                    void* stream);
+/* What two waves of one SIMD share: wave w of a `waves`-wave workgroup (w and w + 4 share a SIMD) runs role_dev[w] for `iters`
+ * rounds -- 0 idle, 1: 8 MFMAs (32x32x16 bf16, independent accumulators), 2: 64 v_fma_f32, 3: 32 v_pk_fma_f32, 4: 16 v_exp_f32 +
+ * 16 v_rcp_f32, 5: 32 v_cvt_pk_bf16_f32, 6: 8 MFMAs and 64 v_fma_f32 in ONE stream; out[wg * waves + w] = cycles of the loop. */
+int rgbnm_calib_pipes(const int* role_dev, int waves, int iters, int workgroups, unsigned long long* out, float* sink,
+                      void* stream);
 
 #ifdef __cplusplus
 }

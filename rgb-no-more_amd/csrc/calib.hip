@@ -149,3 +149,88 @@ extern "C" int rgbnm_calib_l2(const void* buf, size_t slice_bytes, int iters, in
                        (const unsigned char*)buf, slice_bytes, iters, mode, (unsigned*)sink);
     return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
 }
+
+// ---- pipe-overlap probe: what do two waves of one SIMD share?  Workgroup of `waves` waves (waves w and w + 4 sit on the same
+// SIMD).  role[w] decides what wave w runs for `iters` rounds:  0 idle, 1 = 8 independent-accumulator 32x32x16 bf16 MFMAs per
+// round, 2 = 64 dependent-free v_fma_f32 per round, 3 = 32 v_pk_fma_f32, 4 = 16 v_exp_f32 + 16 v_rcp_f32, 5 = 32
+// v_cvt_pk_bf16_f32, 6 = one wave doing both 8 MFMAs and 64 v_fma_f32 per round in one instruction stream.
+// out[(wg * waves + w)] = cycles the wave's loop took (s_memtime).
+namespace rgbnm {
+__global__ __launch_bounds__(512) void calib_pipes_kernel(const int* __restrict__ role, int iters, unsigned long long* out, float* sink) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int r = __builtin_amdgcn_readfirstlane(role[w]);
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)((lane + i) & 3); b[i] = (__bf16)(float)((lane >> 2) & 3); }
+    f32x16 c[8];
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 16; ++i) c[k][i] = 0.f;
+    float v[16];
+    for (int i = 0; i < 16; ++i) v[i] = 1.0f + 1e-3f * (float)(lane + i);
+    const float m = 1.0000001f, d = 1e-7f;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[16384];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 0.25f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (r == 1 || r == 6) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[k], 0, 0, 0);
+        }
+        if (r == 2 || r == 6) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(m), "v"(d));
+        }
+        if (r == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 x = {v[i], v[i + 1]};
+                    const f32x2 mm = {m, m}, dd = {d, d};
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(mm), "v"(dd));
+                    v[i] = x[0]; v[i + 1] = x[1];
+                }
+        }
+        if (r == 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { asm volatile("v_exp_f32 %0, %0" : "+v"(v[i])); asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i])); }
+        }
+        if (r == 7) {                                   // the real GELU / GELU' pair code of the GEMM epilogues, 8 pairs
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 x = {v[i], v[i + 1]}, ge, dg;
+                gelu_pair_fast(x, ge, dg);
+                v[i] = ge[0] + dg[1];
+                v[i + 1] = ge[1] + dg[0];
+            }
+        }
+        if (r == 8) {                                   // 8 MFMAs, each fed by a ds_read_b128 of its A fragment
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lds + ((k * 1024 + lane * 16 + it * 16) & 0x3fff));
+                c[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, c[k], 0, 0, 0);
+            }
+        }
+        if (r == 5) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { unsigned pk; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(pk) : "v"(v[i])); v[i] = __builtin_bit_cast(float, pk); }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 16; ++i) s += c[k][i];
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345.678f) sink[0] = s;
+    if (lane == 0) out[(size_t)blockIdx.x * nw + w] = t1 - t0;
+}
+}  // namespace rgbnm
+
+extern "C" int rgbnm_calib_pipes(const int* role_dev, int waves, int iters, int workgroups, unsigned long long* out, float* sink,
+                                 void* stream) {
+    if (!role_dev || !out || !sink || waves < 1 || waves > 8 || iters <= 0 || workgroups <= 0) return RGBNM_EINVAL;
+    hipLaunchKernelGGL(rgbnm::calib_pipes_kernel, dim3(workgroups), dim3(64 * waves), 0, (hipStream_t)stream, role_dev, iters, out, sink);
+    return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
+}

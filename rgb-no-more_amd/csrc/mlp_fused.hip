@@ -25,14 +25,24 @@
 // Results are bit-identical to the two-launch path (same operand rounding, same fp32 summation order):
 // tests/test_fastpath_model.py::test_fused_mlp_forward_equals_the_two_gemm_path.
 //
-// Measured (B = 256; per-phase cycle stamps): 78 us against 48 + 37 us for the two launches.  The
-// weight stream is free (a variant that fetches only two chunks: -1 us); the GELU arithmetic costs 17 us and the stores of
-// the two saved tensors 18 us, and they do not hide behind the matrix phases: a wave64 VALU instruction costs ~4 cycles
-// here, so gelu + gelu' (~27 instructions per element) takes 1650 cycles per 16 elements per wave against ~400 for the 12
-// MFMAs that produced them -- the fused block is VALU bound.  Variants tried and measured slower: 32-wide granules in a
-// 4-stage ring with the fc1 MFMAs of granule h + 1 issued next to the GELU of granule h (82 us); the two waves of a SIMD
-// running the phases in opposite order (86 us: the older wave wins the VALU arbitration and the younger one's GELU phase
-// stretches to 3400 cycles); scalar instead of packed fp32 GELU arithmetic (88 us).
+// Measured (B = 256): 78 us against 48 + 37 us for the two launches; the weight stream is free (a
+// variant that fetches only two chunks: -1 us).  Why 78 and not the ~35 us of its MFMAs or its VALU work alone -- per-wave
+// s_memtime stamps (build with RGBNM_HIPCC_FLAGS=-DMLP_TRACE, tools/mlp_trace.py), SQ counters (tools/gpu_stalls.sh) and a
+// two-wave micro-benchmark (tools/pipe_probe.py) agree:
+//   * one wave's GELU arithmetic already saturates its SIMD's VALU issue (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.35 cycles per
+//     instruction; two waves running the GELU code on one SIMD take exactly twice as long as one);
+//   * the packed-fp32 and bf16-convert instructions the GELU is made of run 1.8-1.9 x slower while the other wave of the SIMD
+//     issues MFMAs (v_fma_f32: 1.2 x), and an MFMA wave next to an older GELU wave is slowed 1.65 x: MFMA and VALU work on one
+//     SIMD overlap by only ~12 %, so a workgroup's time is close to the SUM of its MFMA, VALU and store phases however the waves
+//     are arranged;
+//   * the older wave of a SIMD wins every arbitration: per 64-unit chunk waves 0-3 run their two halves in 2 x 2850 ticks
+//     and then wait ~2800 at the barrier while waves 4-6, starved until then, finish (first half 6000 ticks, second 2650).
+// Variants built on the opposite assumption, all bit-identical and all measured slower, are not kept: 32-wide granules in a
+// 4-stage ring with fc1 of granule h + 1 issued next to the GELU of granule h (82 us); the same with the 24 MFMAs woven
+// into the GELU instruction stream by hand (82 us: the lone dependent GELU chain of a weave step issues at half rate);
+// a barrier-free version (LDS flags, waves drifting up to three granules apart: 85 us); the two waves of a SIMD in opposite
+// roles per barrier-separated slot, one on GELU while the other runs fc2 / fc1 / stores (84 us: the GELU slot stretches from
+// 1700 to 2600 ticks next to the MFMA wave); scalar instead of packed GELU arithmetic (88 us).
 #include "common.h"
 #include "internal.h"
 #include "../../include/rgbnm.h"
@@ -78,147 +88,11 @@ __device__ __forceinline__ float group8_pair_sum(float s0, float s1) {
   return s0 + s1;
 }
 
-__global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* B1s = reinterpret_cast<float*>(smem + B1_OFF);
-  float* B2s = reinterpret_cast<float*>(smem + B2_OFF);
-  const int panel = blockIdx.x;
-  if (panel >= p.npanels) return;
-  const int m0 = panel * p.rows_per_wg;
-  const int rows = min(p.rows_per_wg, p.M - m0);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, g = lane >> 5;
-
-  if (w == NCW) {
-    // ---------------- DMA wave: biases once, then one 48 KB weight chunk per barrier, one chunk ahead of the math
-#pragma unroll
-    for (int i = 0; i < H / 64; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(p.b1 + 64 * i + lane), (lds_ptr)(B1s + 64 * i), 4, 0, 0);
-#pragma unroll
-    for (int i = 0; i < E / 64; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(p.b2 + 64 * i + lane), (lds_ptr)(B2s + 64 * i), 4, 0, 0);
-    const int rl = lane >> 3, pc = lane & 7;
-    auto issue = [&](int chunk) {
-      unsigned char* st = smem + (chunk & 1) * STAGE;
-      const bf16* w1 = p.W1 + (size_t)chunk * CH * E;
-#pragma unroll
-      for (int i = 0; i < W1_STAGE / 1024; ++i) {
-        const int pidx = 64 * i + lane, row = pidx / 24, c24 = pidx % 24;
-        const int hrow = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);     // LDS row r holds hidden unit swap23(r)
-        __builtin_amdgcn_global_load_lds((glb_ptr)(w1 + hrow * E + pchunk(c24, row) * 8), (lds_ptr)(st + i * 1024), 16, 0, 0);
-      }
-      const bf16* w2 = p.W2 + chunk * CH;
-#pragma unroll
-      for (int i = 0; i < W2_STAGE / 1024; ++i) {
-        const int r8 = 8 * i + rl;
-        __builtin_amdgcn_global_load_lds((glb_ptr)(w2 + (size_t)r8 * H + ((pc ^ fswz(r8)) * 8)),
-                                         (lds_ptr)(st + W1_STAGE + i * 1024), 16, 0, 0);
-      }
-    };
-    issue(0);
-    for (int c = 0; c < NCHUNK; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c (and, the first time, the biases) landed
-      __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
-      if (c + 1 < NCHUNK) issue(c + 1);
-    }
-    return;                                               // ended waves drop out of the workgroup barrier
-  }
-
-  // ---------------- compute waves
+// x_out = acc2 + b2 + R [, LayerNorm of x_out]: the arithmetic of gemm_nt_kpipe's EPI_RES_LN (same bits as ln_fwd_kernel).
+// Called by the compute waves only (the DMA wave has ended); uses the weight ring as the staging tile.
+__device__ __forceinline__ void mlp_epilogue(const MlpArgs& p, unsigned char* smem, const float* B2s, f32x16 (&acc2)[6], int m0,
+                                             int rows, int tid, int w, int l31, int g) {
   const int rloc = 32 * w + l31;
-  const bf16* xrow = p.X + (size_t)(m0 + (rloc < rows ? rloc : rows - 1)) * p.ldx;
-  bf16x8 fa[E / 16];
-#pragma unroll
-  for (int c = 0; c < E / 16; ++c) fa[c] = *reinterpret_cast<const bf16x8*>(xrow + (2 * c + g) * 8);
-
-  f32x16 acc2[6];
-#pragma unroll
-  for (int b = 0; b < 6; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[b][r] = 0.f;
-
-  const int fl = fswz(l31);
-  const int woff0 = l31 * (E * 2) + ((g ^ fl) << 4);      // W1 fragment c of LDS row l31: (woff0 ^ ((c % 4) << 5)) + 128 (c / 4)
-  unsigned char* stg = smem + STG_OFF + w * STG_WAVE;
-
-  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-    __builtin_amdgcn_s_barrier();
-    const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
-    const unsigned char* sW2 = sW1 + W1_STAGE;
-#pragma unroll
-    for (int ht = 0; ht < 2; ++ht) {
-      f32x16 a1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
-      int wbase = woff0 + ht * 32 * (E * 2);
-      asm volatile("" : "+v"(wbase));
-#pragma unroll
-      for (int c = 0; c < E / 16; ++c) {
-        Frag<bf16> fb, fx;
-        fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
-        fx.v = fa[c];
-        mma(a1, fb, fx);                                   // D rows = hidden (LDS row order), D cols = tokens
-      }
-      Frag<bf16> pg[2];
-#pragma unroll
-      for (int hs = 0; hs < 2; ++hs) {
-        // registers 8 hs .. 8 hs + 7 of this lane = hidden units h0 .. h0 + 7 of the token l31 (rows were stored swap23-ed)
-        const int hl = 32 * ht + 16 * hs + 8 * g;
-        const float* bp = B1s + chunk * CH + hl;
-        const f32x4 bl = *reinterpret_cast<const f32x4*>(bp), bh = *reinterpret_cast<const f32x4*>(bp + 4);
-        bf16x8 gv, dv;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const float u0 = a1[8 * hs + j] + (j < 4 ? bl[j] : bh[j - 4]);
-          const float u1 = a1[8 * hs + j + 1] + (j < 4 ? bl[j + 1] : bh[j - 3]);
-          const f32x2 u = {(float)(bf16)u0, (float)(bf16)u1};          // the unfused path rounds u to bf16 before GELU
-          f32x2 ge, dg;
-          gelu_pair_fast(u, ge, dg);
-          gv[j] = (bf16)ge[0];
-          gv[j + 1] = (bf16)ge[1];
-          dv[j] = (bf16)dg[0];
-          dv[j + 1] = (bf16)dg[1];
-        }
-        pg[hs].v = gv;
-        const int pcx = ((2 * (2 * ht + hs) + g) ^ (l31 & 7)) << 4;
-        *reinterpret_cast<bf16x8*>(stg + l31 * (CH * 2) + pcx) = gv;
-        *reinterpret_cast<bf16x8*>(stg + STG_TILE + l31 * (CH * 2) + pcx) = dv;
-      }
-#pragma unroll
-      for (int hs = 0; hs < 2; ++hs) {
-        const int s = 2 * ht + hs;
-        Frag<bf16> fw[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b)
-          fw[b].v = *reinterpret_cast<const bf16x8*>(sW2 + (32 * b + l31) * (CH * 2) + (((2 * s + g) ^ fl) << 4));
-#pragma unroll
-        for (int b = 0; b < 6; ++b) mma(acc2[b], fw[b], pg[hs]);     // D rows = output features, D cols = tokens
-      }
-    }
-    // ---- the chunk's gelu / gelu' tiles: 32 rows x 128 B each, out as whole row pieces (LDS runs a wave in order)
-    const int ln = lane_id_here();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
-      const int so = row * (CH * 2) + ((vec ^ (row & 7)) << 4);
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + so);
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + STG_TILE + so);
-      if (32 * w + row < rows) {
-        const size_t go = (size_t)(m0 + 32 * w + row) * p.ldg + chunk * CH + vec * 8;
-        // gelu(u) / gelu'(u) are read again only in the backward, seconds of traffic later: with the non-temporal hint they do
-        // not push the tensors the next kernels are about to read out of the Infinity Cache
-        if (p.cold == 1) {
-          __builtin_nontemporal_store(v0, reinterpret_cast<bf16x8*>(p.G + go));
-          __builtin_nontemporal_store(v1, reinterpret_cast<bf16x8*>(p.GP + go));
-        } else {
-          *reinterpret_cast<bf16x8*>(p.G + go) = v0;
-          *reinterpret_cast<bf16x8*>(p.GP + go) = v1;
-        }
-      }
-    }
-  }
-
   // ---------------- epilogue: x_out = acc2 + b2 + R [, LayerNorm]: the arithmetic of gemm_nt_kpipe's EPI_RES_LN
   const int ctid = tid;                                   // compute threads are 0 .. 447
   const int l8 = ctid & 7, grp = ctid >> 3;
@@ -306,7 +180,195 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
   }
 }
 
+#ifdef MLP_TRACE
+// experiments only (RGBNM_HIPCC_FLAGS=-DMLP_TRACE): per-wave s_memtime stamps of the first workgroups, read by tools/mlp_trace.py
+__device__ unsigned long long g_mlp_trace[16 * 8 * 80];
+#define MLP_STAMP(i)                                                                                  \
+  do {                                                                                                \
+    if (blockIdx.x < 16) {                                                                            \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                     \
+      if ((threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 80 + (i)] = t_; \
+    }                                                                                                 \
+  } while (0)
+#else
+#define MLP_STAMP(i)
+#endif
+
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* B1s = reinterpret_cast<float*>(smem + B1_OFF);
+  float* B2s = reinterpret_cast<float*>(smem + B2_OFF);
+  const int panel = blockIdx.x;
+  if (panel >= p.npanels) return;
+  const int m0 = panel * p.rows_per_wg;
+  const int rows = min(p.rows_per_wg, p.M - m0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  MLP_STAMP(0);
+#ifdef MLP_TRACE
+  if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 79] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  if (w == NCW) {
+    // ---------------- DMA wave: biases once, then one 48 KB weight chunk per barrier, one chunk ahead of the math
+#pragma unroll
+    for (int i = 0; i < H / 64; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(p.b1 + 64 * i + lane), (lds_ptr)(B1s + 64 * i), 4, 0, 0);
+#pragma unroll
+    for (int i = 0; i < E / 64; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(p.b2 + 64 * i + lane), (lds_ptr)(B2s + 64 * i), 4, 0, 0);
+    const int rl = lane >> 3, pc = lane & 7;
+    auto issue = [&](int chunk) {
+      unsigned char* st = smem + (chunk & 1) * STAGE;
+      const bf16* w1 = p.W1 + (size_t)chunk * CH * E;
+#pragma unroll
+      for (int i = 0; i < W1_STAGE / 1024; ++i) {
+        const int pidx = 64 * i + lane, row = pidx / 24, c24 = pidx % 24;
+        const int hrow = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);     // LDS row r holds hidden unit swap23(r)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(w1 + hrow * E + pchunk(c24, row) * 8), (lds_ptr)(st + i * 1024), 16, 0, 0);
+      }
+      const bf16* w2 = p.W2 + chunk * CH;
+#pragma unroll
+      for (int i = 0; i < W2_STAGE / 1024; ++i) {
+        const int r8 = 8 * i + rl;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(w2 + (size_t)r8 * H + ((pc ^ fswz(r8)) * 8)),
+                                         (lds_ptr)(st + W1_STAGE + i * 1024), 16, 0, 0);
+      }
+    };
+    issue(0);
+    for (int c = 0; c < NCHUNK; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c (and, the first time, the biases) landed
+      MLP_STAMP(2 + 5 * c);
+      __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
+      MLP_STAMP(3 + 5 * c);
+      if (c + 1 < NCHUNK) issue(c + 1);
+      MLP_STAMP(4 + 5 * c);
+    }
+    MLP_STAMP(62);
+#ifdef MLP_TRACE
+    if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 78] = __builtin_amdgcn_s_memrealtime();
+#endif
+    return;                                               // ended waves drop out of the workgroup barrier
+  }
+
+  // ---------------- compute waves
+  const int rloc = 32 * w + l31;
+  const bf16* xrow = p.X + (size_t)(m0 + (rloc < rows ? rloc : rows - 1)) * p.ldx;
+  bf16x8 fa[E / 16];
+#pragma unroll
+  for (int c = 0; c < E / 16; ++c) fa[c] = *reinterpret_cast<const bf16x8*>(xrow + (2 * c + g) * 8);
+
+  f32x16 acc2[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[b][r] = 0.f;
+
+  const int fl = fswz(l31);
+  const int woff0 = l31 * (E * 2) + ((g ^ fl) << 4);      // W1 fragment c of LDS row l31: (woff0 ^ ((c % 4) << 5)) + 128 (c / 4)
+  unsigned char* stg = smem + STG_OFF + w * STG_WAVE;
+#ifdef MLP_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MLP_STAMP(1);
+
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+    MLP_STAMP(2 + 5 * chunk);
+    __builtin_amdgcn_s_barrier();
+    MLP_STAMP(3 + 5 * chunk);
+    const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
+    const unsigned char* sW2 = sW1 + W1_STAGE;
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht) {
+      f32x16 a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+      int wbase = woff0 + ht * 32 * (E * 2);
+      asm volatile("" : "+v"(wbase));
+#pragma unroll
+      for (int c = 0; c < E / 16; ++c) {
+        Frag<bf16> fb, fx;
+        fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+        fx.v = fa[c];
+        mma(a1, fb, fx);                                   // D rows = hidden (LDS row order), D cols = tokens
+      }
+      Frag<bf16> pg[2];
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+        // registers 8 hs .. 8 hs + 7 of this lane = hidden units h0 .. h0 + 7 of the token l31 (rows were stored swap23-ed)
+        const int hl = 32 * ht + 16 * hs + 8 * g;
+        const float* bp = B1s + chunk * CH + hl;
+        const f32x4 bl = *reinterpret_cast<const f32x4*>(bp), bh = *reinterpret_cast<const f32x4*>(bp + 4);
+        bf16x8 gv, dv;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float u0 = a1[8 * hs + j] + (j < 4 ? bl[j] : bh[j - 4]);
+          const float u1 = a1[8 * hs + j + 1] + (j < 4 ? bl[j + 1] : bh[j - 3]);
+          const f32x2 u = {(float)(bf16)u0, (float)(bf16)u1};          // the unfused path rounds u to bf16 before GELU
+          f32x2 ge, dg;
+          gelu_pair_fast(u, ge, dg);
+          gv[j] = (bf16)ge[0];
+          gv[j + 1] = (bf16)ge[1];
+          dv[j] = (bf16)dg[0];
+          dv[j + 1] = (bf16)dg[1];
+        }
+        pg[hs].v = gv;
+        const int pcx = ((2 * (2 * ht + hs) + g) ^ (l31 & 7)) << 4;
+        *reinterpret_cast<bf16x8*>(stg + l31 * (CH * 2) + pcx) = gv;
+        *reinterpret_cast<bf16x8*>(stg + STG_TILE + l31 * (CH * 2) + pcx) = dv;
+      }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+        const int s = 2 * ht + hs;
+        Frag<bf16> fw[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+          fw[b].v = *reinterpret_cast<const bf16x8*>(sW2 + (32 * b + l31) * (CH * 2) + (((2 * s + g) ^ fl) << 4));
+#pragma unroll
+        for (int b = 0; b < 6; ++b) mma(acc2[b], fw[b], pg[hs]);     // D rows = output features, D cols = tokens
+      }
+      if (ht == 0) MLP_STAMP(4 + 5 * chunk);
+      else MLP_STAMP(5 + 5 * chunk);
+    }
+    // ---- the chunk's gelu / gelu' tiles: 32 rows x 128 B each, out as whole row pieces (LDS runs a wave in order)
+    const int ln = lane_id_here();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+      const int so = row * (CH * 2) + ((vec ^ (row & 7)) << 4);
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + so);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + STG_TILE + so);
+      if (32 * w + row < rows) {
+        const size_t go = (size_t)(m0 + 32 * w + row) * p.ldg + chunk * CH + vec * 8;
+        // gelu(u) / gelu'(u) are read again only in the backward, seconds of traffic later: with the non-temporal hint they do
+        // not push the tensors the next kernels are about to read out of the Infinity Cache
+        if (p.cold == 1) {
+          __builtin_nontemporal_store(v0, reinterpret_cast<bf16x8*>(p.G + go));
+          __builtin_nontemporal_store(v1, reinterpret_cast<bf16x8*>(p.GP + go));
+        } else {
+          *reinterpret_cast<bf16x8*>(p.G + go) = v0;
+          *reinterpret_cast<bf16x8*>(p.GP + go) = v1;
+        }
+      }
+    }
+    MLP_STAMP(6 + 5 * chunk);
+  }
+  MLP_STAMP(62);
+  mlp_epilogue(p, smem, B2s, acc2, m0, rows, tid, w, l31, g);
+  MLP_STAMP(63);
+#ifdef MLP_TRACE
+  if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 78] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
 }  // namespace
+
+#ifdef MLP_TRACE
+extern "C" int rgbnm_mlp_trace_read(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mlp_trace), sizeof(unsigned long long) * 16 * 8 * 80) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // 1 = shape not eligible (the caller runs fc1 and fc2 as two GEMM launches).
 int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2,

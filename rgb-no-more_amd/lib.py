@@ -104,6 +104,7 @@ PROTOTYPES = {
     "rgbnm_calib_stream": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     "rgbnm_calib_vmem_issue": (_i, [_i, _i, _i, _vp, _sz, _i, _vp, _vp]),
     "rgbnm_calib_l2": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _vp]),
+    "rgbnm_calib_pipes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rgbnm_vit_block_fwd_chain": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _i, _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
                                  _vp, _vp]),
