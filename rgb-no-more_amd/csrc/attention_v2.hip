@@ -607,9 +607,9 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
   // rows per pair thrashed the 32 KB L1 and pulled up to 4x that from L2 while every store and DMA queued behind them.)
   u32x4 qraw[4], graw[4], oraw[4];
   float lq = 0.f;
-  auto load_own = [&](int bh) {              // 13 loads per lane
+  auto load_own_qg = [&](int bh) {           // 8 loads per lane: Q and dO rows
     const int b = bh / heads, h = bh % heads;
-    const int lane_ = lane_id_here();        // the 12 row addresses are recomputed here, not hoisted and spilled
+    const int lane_ = lane_id_here();        // the row addresses are recomputed here, not hoisted and spilled
     const int seg = lane_ & 7;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -617,11 +617,25 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
       r = r < N ? r : N - 1;
       qraw[i] = *reinterpret_cast<const u32x4*>(qkv + ((size_t)b * N + r) * ld + h * HD + seg * 8);
       graw[i] = *reinterpret_cast<const u32x4*>(dout + ((size_t)b * N + r) * inner + h * HD + seg * 8);
+    }
+  };
+  auto load_own_o = [&](int bh) {            // 5 loads per lane: O rows and the row's log-sum-exp
+    const int b = bh / heads, h = bh % heads;
+    const int lane_ = lane_id_here();
+    const int seg = lane_ & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int r = w * 32 + i * 8 + (lane_ >> 3);
+      r = r < N ? r : N - 1;
       oraw[i] = *reinterpret_cast<const u32x4*>(out + ((size_t)b * N + r) * inner + h * HD + seg * 8);
     }
     int rq_ = w * 32 + (lane_ & 31);
     rq_ = rq_ < N ? rq_ : N - 1;
     lq = lse[(size_t)bh * N + rq_];
+  };
+  auto load_own = [&](int bh) {
+    load_own_qg(bh);
+    load_own_o(bh);
   };
 
   int bh = blockIdx.x;
@@ -824,6 +838,10 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
         }
       });
       APROF3(4);
+      // the next pair's own Q / dO rows: issued as soon as the tile loop's temporaries are dead (only dk / dv are live), so that
+      // they fly during the two parks and the two barriers instead of after them; the O rows follow after the dV park (all 13
+      // loads here, or any of them earlier, and the 256-register budget spills)
+      if (nxt < nbh) load_own_qg(nxt);
       tile_park_private(stg, dk, scale, L);
       APROF3(5);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -831,9 +849,10 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
       APROF3(6);
       tile_park_rows(Gs, w, dv, 1.0f, L);
     } else {
+      if (nxt < nbh) load_own_qg(nxt);
       __builtin_amdgcn_s_barrier();          // end
     }
-    if (nxt < nbh) load_own(nxt);            // (any earlier and the 256-register budget spills)
+    if (nxt < nbh) load_own_o(nxt);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // end2: dV tiles parked
     APROF3(7);
