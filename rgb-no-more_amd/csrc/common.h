@@ -166,6 +166,27 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// The per-element steps of the LayerNorm backward with every FMA explicit and every product that must NOT be fused into a
+// following add made opaque (an empty asm "modifies" it; `#pragma clang fp contract(off)` in an inlined helper did not stop
+// -ffp-contract=fast from fusing across the inlining): the three kernels that run them (ln_bwd_kernel, gemm_nt_kpipe
+// EPI_LNBWD, mlp_bwd_kernel) then round identically.  acc: xhat and g*dy of one element, row sums s1 = sum(g dy),
+// s2 = sum(g dy xhat), column sums dgamma / dbeta.  dx = rs * (g dy - c1 - xhat * c2) + residual gradient (res = 0 if none).
+__device__ __forceinline__ void ln_bwd_acc(float dv, float x, float mu, float rs, float gm, float& xh, float& gv, float& s1,
+                                           float& s2, float& dg, float& db) {
+  xh = (x - mu) * rs;
+  gv = dv * gm;
+  asm volatile("" : "+v"(xh), "+v"(gv));
+  s1 += gv;
+  s2 = __builtin_fmaf(gv, xh, s2);
+  dg = __builtin_fmaf(dv, xh, dg);
+  db += dv;
+}
+__device__ __forceinline__ float ln_bwd_dx(float rs, float gv, float c1, float xh, float c2, float res) {
+  float t = gv - c1;
+  asm volatile("" : "+v"(t));
+  return __builtin_fmaf(rs, __builtin_fmaf(-xh, c2, t), res);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -42,6 +42,11 @@ int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1
                          const void* R, int ldr, void* G, void* GP, int ldg, void* Y, int ldy, const float* gamma,
                          const float* beta, void* Y2, int ldy2, float* mean, float* rstd, float eps, int M, int E, int H,
                          hipStream_t st);
+// The backward of the same block's data path in one launch (mlp_fused.hip): du = (dy . W2) * gelu'(u) -> DU (for the dW1 GEMM),
+// dx = dy + LayerNorm'(du . W1) -> DX, panel partial sums of dgamma / dbeta -> part [npanels][2][192]; 1 = not eligible.
+int rgbnm_launch_mlp_bwd(const void* DY, int lddy, const void* W2T, const void* W1T, const void* GP, int ldg, void* DU, int ldu,
+                         const void* X, int ldx, const float* gamma, const float* mean, const float* rstd, void* DX, int lddx,
+                         float* part, int* npanels_out, int M, int E, int H, hipStream_t st);
 // fc1 / qkv dX GEMM with the LayerNorm backward fused into the epilogue (gemm_nt_kpipe.hip); 1 = not eligible.
 int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, const void* X, int ldx,
                                 const float* gamma, const float* mean, const float* rstd, const void* dres, int ldr,

@@ -91,26 +91,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       const f32x4 dv = load4<T>(dy + off);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xh[v][i] = (xv[i] - mu) * rs;
-        gv[v][i] = dv[i] * gm[v][i];
-        s1 += gv[v][i];
-        s2 += gv[v][i] * xh[v][i];
-        dg[v][i] += dv[i] * xh[v][i];
-        db[v][i] += dv[i];
+        float xh_, gv_, dg_ = dg[v][i], db_ = db[v][i];
+        ln_bwd_acc(dv[i], xv[i], mu, rs, gm[v][i], xh_, gv_, s1, s2, dg_, db_);
+        xh[v][i] = xh_; gv[v][i] = gv_; dg[v][i] = dg_; db[v][i] = db_;
       }
     }
     const float c1 = group16_sum(s1) * (1.f / E), c2 = group16_sum(s2) * (1.f / E);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const size_t off = (size_t)row * E + (v * 16 + l16) * 4;
-      f32x4 o;
+      f32x4 o, rv = {0.f, 0.f, 0.f, 0.f};
+      if (dres) rv = load4<T>(dres + off);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2);
-      if (dres) {
-        const f32x4 rv = load4<T>(dres + off);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] += rv[i];
-      }
+      for (int i = 0; i < 4; ++i) o[i] = ln_bwd_dx(rs, gv[v][i], c1, xh[v][i], c2, rv[i]);
       store4<T>(dx + off, o);
     }
   }

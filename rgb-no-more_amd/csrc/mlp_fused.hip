@@ -362,6 +362,245 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The FeedForwardBlock BACKWARD data path in one launch: du = (dy . W2) * gelu'(u)  ->  dx = dy + LayerNorm'(du . W1)
+// (reference: models/plainvit.py:481-529 run backwards by autograd).  Until now that was gemm_nt_wres<DGELU> writing du
+// [M,768] and gemm_nt_kpipe<LNBWD> reading it back: here a wave's 32 x 64 du tile of every hidden chunk feeds the second
+// product's MFMAs straight from registers, exactly as gelu(u) does in mlp_fwd_kernel, and du goes to HBM once, for the dW1
+// GEMM only.  Same skeleton as the forward -- the dy rows of the wave live in registers as 12 operand fragments, a DMA wave
+// streams W2^T[64 x 192] / W1^T[192 x 64] chunks through the 2-stage ring with the same swizzles -- with these differences:
+//   * no biases; instead of evaluating GELU, the chunk's gelu'(u) tile (32 rows x 128 B per wave) arrives by 4 coalesced
+//     loads per lane issued one chunk ahead, is parked in the wave's first staging tile and read back as 16-byte fragments;
+//   * du = bf16(bf16(acc) * gelu') -- the rounding sequence of the DGELU epilogues -- leaves through the second staging tile;
+//   * epilogue = gemm_nt_kpipe's EPI_LNBWD (same arithmetic, 16 lanes per row, panel partial sums of dgamma / dbeta for
+//     reduce.hip), with its operand rows requested at the start of the epilogue (there is no register room in the loop).
+// Bit-identical to the two-launch path: tests/test_fastpath_model.py::test_fused_mlp_backward_equals_the_two_gemm_path.
+struct MlpBwdArgs {
+  const bf16* DY; const bf16* W2T; const bf16* W1T; const bf16* GP; bf16* DU;
+  int lddy, ldg, ldu;
+  int M, rows_per_wg, npanels;
+  const bf16* X; int ldx; const float* gamma; const float* mean; const float* rstd;     // LayerNorm input rows + saved statistics
+  bf16* DX; int lddx; float* part;                                                      // part: [npanels][2][192]
+};
+constexpr int LB_GROUPS = CTHREADS / 16, LB_ITERS = BM / LB_GROUPS;      // 28 row groups of 16 lanes, 8 rounds
+constexpr int RED_OFF = (BM * CP * 2 + 1023) / 1024 * 1024;              // column-reduction scratch behind the staging tile
+static_assert(RED_OFF + LB_GROUPS * (E + 4) * 4 <= SMEM, "LN-backward scratch: the ring and the (by then dead) staging tiles");
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int panel = blockIdx.x;
+  if (panel >= p.npanels) return;
+  const int m0 = panel * p.rows_per_wg;
+  const int rows = min(p.rows_per_wg, p.M - m0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+
+  if (w == NCW) {
+    // ---------------- DMA wave: one 48 KB weight chunk per barrier, one chunk ahead of the math (as in mlp_fwd_kernel)
+    const int rl = lane >> 3, pc = lane & 7;
+    auto issue = [&](int chunk) {
+      unsigned char* st = smem + (chunk & 1) * STAGE;
+      const bf16* w1 = p.W2T + (size_t)chunk * CH * E;
+#pragma unroll
+      for (int i = 0; i < W1_STAGE / 1024; ++i) {
+        const int pidx = 64 * i + lane, row = pidx / 24, c24 = pidx % 24;
+        const int hrow = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);     // LDS row r holds hidden unit swap23(r)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(w1 + hrow * E + pchunk(c24, row) * 8), (lds_ptr)(st + i * 1024), 16, 0, 0);
+      }
+      const bf16* w2 = p.W1T + chunk * CH;
+#pragma unroll
+      for (int i = 0; i < W2_STAGE / 1024; ++i) {
+        const int r8 = 8 * i + rl;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(w2 + (size_t)r8 * H + ((pc ^ fswz(r8)) * 8)),
+                                         (lds_ptr)(st + W1_STAGE + i * 1024), 16, 0, 0);
+      }
+    };
+    issue(0);
+    for (int c = 0; c < NCHUNK; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c landed
+      __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
+      if (c + 1 < NCHUNK) issue(c + 1);
+    }
+    return;                                               // ended waves drop out of the workgroup barrier
+  }
+
+  // ---------------- compute waves
+  const int rloc = 32 * w + l31;
+  const bf16* yrow = p.DY + (size_t)(m0 + (rloc < rows ? rloc : rows - 1)) * p.lddy;
+  bf16x8 fa[E / 16];
+#pragma unroll
+  for (int c = 0; c < E / 16; ++c) fa[c] = *reinterpret_cast<const bf16x8*>(yrow + (2 * c + g) * 8);
+
+  f32x16 acc2[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[b][r] = 0.f;
+
+  const int fl = fswz(l31);
+  const int woff0 = l31 * (E * 2) + ((g ^ fl) << 4);
+  unsigned char* stg = smem + STG_OFF + w * STG_WAVE;     // tile 0: gelu' in, tile 1: du out
+
+  // the chunk's gelu' tile of this wave, row-major pieces: lane = (row i*8 + lane/8, 16-byte segment lane%8)
+  const int ln = lane_id_here();
+  bf16x8 gpraw[4];
+  auto load_gp = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+      int rr = 32 * w + row;
+      rr = rr < rows ? rr : rows - 1;
+      gpraw[i] = *reinterpret_cast<const bf16x8*>(p.GP + (size_t)(m0 + rr) * p.ldg + chunk * CH + vec * 8);
+    }
+  };
+  load_gp(0);
+
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+      *reinterpret_cast<bf16x8*>(stg + row * (CH * 2) + ((vec ^ (row & 7)) << 4)) = gpraw[i];
+    }
+    if (chunk + 1 < NCHUNK) load_gp(chunk + 1);
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
+    const unsigned char* sW2 = sW1 + W1_STAGE;
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht) {
+      f32x16 a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+      int wbase = woff0 + ht * 32 * (E * 2);
+      asm volatile("" : "+v"(wbase));
+#pragma unroll
+      for (int c = 0; c < E / 16; ++c) {
+        Frag<bf16> fb, fx;
+        fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+        fx.v = fa[c];
+        mma(a1, fb, fx);                                   // D rows = hidden (LDS row order), D cols = tokens
+      }
+      Frag<bf16> pg[2];
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+        // registers 8 hs .. 8 hs + 7 of this lane = hidden units h0 .. h0 + 7 of the token l31 (rows were stored swap23-ed)
+        const int pcx = ((2 * (2 * ht + hs) + g) ^ (l31 & 7)) << 4;
+        const bf16x8 gpv = *reinterpret_cast<const bf16x8*>(stg + l31 * (CH * 2) + pcx);
+        bf16x8 dv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = (bf16)((float)(bf16)a1[8 * hs + j] * (float)gpv[j]);
+        pg[hs].v = dv;
+        *reinterpret_cast<bf16x8*>(stg + STG_TILE + l31 * (CH * 2) + pcx) = dv;
+      }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+        const int s = 2 * ht + hs;
+        Frag<bf16> fw[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+          fw[b].v = *reinterpret_cast<const bf16x8*>(sW2 + (32 * b + l31) * (CH * 2) + (((2 * s + g) ^ fl) << 4));
+#pragma unroll
+        for (int b = 0; b < 6; ++b) mma(acc2[b], fw[b], pg[hs]);     // D rows = input features, D cols = tokens
+      }
+    }
+    // ---- the chunk's du tile: 32 rows x 128 B, out as whole row pieces
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + STG_TILE + row * (CH * 2) + ((vec ^ (row & 7)) << 4));
+      if (32 * w + row < rows)
+        *reinterpret_cast<bf16x8*>(p.DU + (size_t)(m0 + 32 * w + row) * p.ldu + chunk * CH + vec * 8) = v0;
+    }
+  }
+
+  // ---------------- epilogue: dx = dy + LayerNorm'(acc2): the arithmetic of gemm_nt_kpipe's EPI_LNBWD
+  const int l16 = tid & 15, grp16 = tid >> 4;
+  bf16x4 lx[LB_ITERS][3], lrb[LB_ITERS][3];
+  float lmu[LB_ITERS], lrs[LB_ITERS];
+  f32x4 gmb[3];
+#pragma unroll
+  for (int v = 0; v < 3; ++v) gmb[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
+#pragma unroll
+  for (int it = 0; it < LB_ITERS; ++it) {
+    const int row = it * LB_GROUPS + grp16, rr = m0 + (row < rows ? row : rows - 1);
+    lmu[it] = p.mean[rr];
+    lrs[it] = p.rstd[rr];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      lx[it][v] = *reinterpret_cast<const bf16x4*>(p.X + (size_t)rr * p.ldx + (v * 16 + l16) * 4);
+      lrb[it][v] = *reinterpret_cast<const bf16x4*>(p.DY + (size_t)rr * p.lddy + (v * 16 + l16) * 4);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the staging tile
+  bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = 32 * b + 8 * q + 4 * g;
+      const f32x4 v = {acc2[b][4 * q + 0], acc2[b][4 * q + 1], acc2[b][4 * q + 2], acc2[b][4 * q + 3]};
+      store4<bf16>(Cs + rloc * CP + nl, v);
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f32x4 dg[3], db[3];
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int it = 0; it < LB_ITERS; ++it) {
+    const int row = it * LB_GROUPS + grp16;
+    if (row < rows) {
+      const float mu = lmu[it], rs = lrs[it];
+      f32x4 xh[3], gv[3];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const bf16x4 dvb = *reinterpret_cast<const bf16x4*>(Cs + row * CP + (v * 16 + l16) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float xh_, gv_, dg_ = dg[v][i], db_ = db[v][i];
+          ln_bwd_acc((float)dvb[i], (float)lx[it][v][i], mu, rs, gmb[v][i], xh_, gv_, s1, s2, dg_, db_);
+          xh[v][i] = xh_; gv[v][i] = gv_; dg[v][i] = dg_; db[v][i] = db_;
+        }
+      }
+      const float c1 = group16_sum(s1) * (1.f / E), c2 = group16_sum(s2) * (1.f / E);
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = ln_bwd_dx(rs, gv[v][i], c1, xh[v][i], c2, (float)lrb[it][v][i]);
+        store4<bf16>(p.DX + (size_t)(m0 + row) * p.lddx + (v * 16 + l16) * 4, o);
+      }
+    }
+  }
+  // panel-level column sums of dgamma / dbeta (fixed order => deterministic); reduced across panels by reduce.hip
+  float* red = reinterpret_cast<float*>(smem + RED_OFF);
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[grp16 * (E + 4) + (v * 16 + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
+    __syncthreads();
+    for (int e = tid; e < E; e += CTHREADS) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < LB_GROUPS; ++r) a += red[r * (E + 4) + e];
+      p.part[((size_t)panel * 2 + pass) * E + e] = a;
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef MLP_TRACE
@@ -403,3 +642,32 @@ int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1
   return RGBNM_OK;
 }
 
+// 1 = shape not eligible (the caller runs the DGELU GEMM and the LayerNorm-backward GEMM as two launches).
+int rgbnm_launch_mlp_bwd(const void* DY, int lddy, const void* W2T, const void* W1T, const void* GP, int ldg, void* DU, int ldu,
+                         const void* X, int ldx, const float* gamma, const float* mean, const float* rstd, void* DX, int lddx,
+                         float* part, int* npanels_out, int M, int Edim, int Hdim, hipStream_t st) {
+  if (Edim != E || Hdim != H || M < 8192 || lddy % 8 || ldg % 8 || ldu % 8 || ldx % 4 || lddx % 4) return 1;
+  if (!DY || !W2T || !W1T || !GP || !DU || !X || !gamma || !mean || !rstd || !DX || !part || !npanels_out) return RGBNM_EINVAL;
+  MlpBwdArgs p;
+  p.DY = (const bf16*)DY; p.W2T = (const bf16*)W2T; p.W1T = (const bf16*)W1T; p.GP = (const bf16*)GP; p.DU = (bf16*)DU;
+  p.lddy = lddy; p.ldg = ldg; p.ldu = ldu; p.M = M;
+  p.X = (const bf16*)X; p.ldx = ldx; p.gamma = gamma; p.mean = mean; p.rstd = rstd; p.DX = (bf16*)DX; p.lddx = lddx; p.part = part;
+  int rows = cdiv(M, 256);
+  if (rows > BM) rows = BM;
+  p.rows_per_wg = rows;
+  p.npanels = cdiv(M, rows);
+  *npanels_out = p.npanels;
+  static DevOnce attr;
+  if (attr.need()) {
+    if (hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr.done();
+  }
+  const double me = (double)M * E, mh = (double)M * H;
+  // algorithmic bytes: dy + x_mid in, gelu' in, du + dx out, both weight matrices once
+  const int slot = rgbnm_trace_begin(TR_NT, 4.0 * mh * E, (me * 3.0 + mh * 2.0) * 2.0 + 4.0 * E * H, st);
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(p.npanels), dim3(NTHREADS), SMEM, st, p);
+  rgbnm_trace_end(slot, st);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}

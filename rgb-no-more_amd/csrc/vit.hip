@@ -32,7 +32,7 @@ hipEvent_t take_event() {
 // process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
 // they select between parity-tested kernels and are meant to be set before work is enqueued
 struct Opt { const char* name; std::atomic<int> value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}, {"nt_cold", 0}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}, {"nt_cold", 0}, {"mlp_bwd", 1}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -112,6 +112,25 @@ static bool fused_dx_lnbwd(int dt, const void* A, int lda, const void* Wt, int l
   int npanels = 0;
   const int rc = rgbnm_launch_nt_kpipe_lnbwd(A, lda, Wt, ldw, x, E, gamma, mean, rstd, dres, E, dx, E, (float*)ws,
                                              &npanels, M, E, K, st);
+  if (rc != RGBNM_OK) return false;
+  RgbnmReduceJob j;
+  j.part = (const float*)ws; j.stride = 2LL * E; j.out = dgamma; j.n = E; j.S = npanels; j.cols = 1; j.perm_heads = 0;
+  j.accumulate = 0; j.epw = 8;
+  if (rgbnm_reduce_submit(j, st) != RGBNM_OK) return false;
+  j.part = (const float*)ws + E; j.out = dbeta;
+  return rgbnm_reduce_submit(j, st) == RGBNM_OK;
+}
+
+// du = (dy . W2) * gelu'(u), dx = dy + LayerNorm'(du . W1) in one launch (mlp_fused.hip) + two jobs for the batched reduction.
+// false: not eligible (fp32, E != 192, small M, option mlp_bwd / ln_fuse = 0) -> the caller runs the separate launches.
+static bool fused_mlp_bwd(int dt, const void* dy, const void* w2t, const void* w1t, const void* gp, void* du, const void* x,
+                          const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                          int M, int E, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (dt != RGBNM_DT_BF16 || E != 192 || !rgbnm_get_option("mlp_bwd") || !rgbnm_get_option("ln_fuse")) return false;
+  if (ws_bytes < (size_t)cdiv(M, cdiv(M, 256)) * 2 * E * sizeof(float)) return false;
+  int npanels = 0;
+  const int rc = rgbnm_launch_mlp_bwd(dy, E, w2t, w1t, gp, 4 * E, du, 4 * E, x, E, gamma, mean, rstd, dx, E, (float*)ws,
+                                      &npanels, M, E, 4 * E, st);
   if (rc != RGBNM_OK) return false;
   RgbnmReduceJob j;
   j.part = (const float*)ws; j.stride = 2LL * E; j.out = dgamma; j.n = E; j.S = npanels; j.cols = 1; j.perm_heads = 0;
@@ -218,12 +237,17 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   const int group = rgbnm_get_option("tn_group");
   if (group) rgbnm_tn_defer_begin();
   TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
-  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DGELU, dy, E, p->w2_t, E, s->du, 4 * E, 0, a->u, 4 * E, 0, 0, 0, 0, M, 4 * E, E, 0,
-                    st));
+  // du = (dy . W2) * gelu'(u) and dx_mid = dy + LN2'(du . W1) in ONE launch when eligible (mlp_fused.hip, option mlp_bwd)
+  const bool mlp_bwd_fused = fused_mlp_bwd(dt, dy, p->w2_t, p->w1_t, a->u, s->du, a->x_mid, p->ln2_g, a->mean2, a->rstd2,
+                                           s->dx_mid, g->dln2_g, g->dln2_b, M, E, WS(4), (hipStream_t)st);
+  if (!mlp_bwd_fused)
+    TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DGELU, dy, E, p->w2_t, E, s->du, 4 * E, 0, a->u, 4 * E, 0, 0, 0, 0, M, 4 * E, E, 0,
+                      st));
   TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, WS(1), st));
   if (group == 1) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
   // dx_mid = dy + LN2'(du . W1): LayerNorm backward fused into the GEMM epilogue when eligible
-  if (!fused_dx_lnbwd(dt, s->du, 4 * E, p->w1_t, 4 * E, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid,
+  if (mlp_bwd_fused) {
+  } else if (!fused_dx_lnbwd(dt, s->du, 4 * E, p->w1_t, 4 * E, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid,
                       g->dln2_g, g->dln2_b, M, E, 4 * E, WS(4), (hipStream_t)st)) {
     TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->du, 4 * E, p->w1_t, 4 * E, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E, 4 * E,
                       0, st));

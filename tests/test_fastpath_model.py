@@ -25,7 +25,7 @@ DEV = "cuda"
 
 CASES = {"ti_d2_b64": (192, 3, 2, 64, False), "ti_d12_b64": (192, 3, 12, 64, False), "s_d2_b64": (384, 6, 2, 64, False),
          "ti_d12_b256": (192, 3, 12, 256, True)}
-FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe", "mlp_fuse")
+FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe", "mlp_fuse", "mlp_bwd")
 
 
 def build(tag, compute):
@@ -183,6 +183,37 @@ def test_fused_mlp_forward_equals_the_two_gemm_path():
         nd = int((a != b).sum())
         print(f"{k:8s} max |d| {float((a - b).abs().max()):.3e}  differing elements {nd} / {a.numel()}")
         assert torch.equal(fused[k], plain[k]), k
+
+
+def test_fused_mlp_backward_equals_the_two_gemm_path():
+    """mlp_bwd_kernel (dGELU product + fc1 dX + LayerNorm backward in one launch, du kept in registers for the second product)
+    against gemm_nt_wres<DGELU> + gemm_nt_kpipe<LNBWD>: same roundings (du = bf16(bf16(acc) * gelu')), same k order, the same
+    LayerNorm-backward helpers (common.h ln_bwd_acc / ln_bwd_dx: explicit FMAs, opaque products) and panel partition, so every
+    gradient -- including the dW1 GEMM that reads the du this kernel writes, and LN2's dgamma / dbeta from its panel partial
+    sums -- must agree bit for bit."""
+    lib = L.lib()
+    m, sd, y, c, tgt = build("ti_d2_b64", torch.bfloat16)
+    m.train()
+
+    def grads():
+        m.zero_grad()
+        logits = m(y, c)
+        ar = logits.grad_fn.st.arena
+        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
+        torch.cuda.synchronize()
+        out = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        out["scratch.du"], out["scratch.dx_mid"] = ar.du.clone(), ar.dx_mid.clone()      # block 0's (processed last)
+        return out
+
+    assert lib.rgbnm_get_option(b"mlp_bwd") == 1
+    fused = grads()
+    try:
+        L.check(lib.rgbnm_set_option(b"mlp_bwd", 0))
+        plain = grads()
+    finally:
+        L.check(lib.rgbnm_set_option(b"mlp_bwd", 1))
+    for n in fused:
+        assert torch.equal(fused[n], plain[n]), n
 
 
 def test_row_panel_gemm_two_workgroups_per_cu_equals_one():
