@@ -706,9 +706,9 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) d += (float)gv[e] * (float)ov[e];
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
+        d += lane_xor1(d);
+        d += lane_xor2(d);
+        d += lane_xor4(d);
         if (seg == 0) D_s[w * 32 + i * 8 + rl] = d;
       }
       // Q, dO: row-major pieces -> private tile -> fragments (lane <-> row l31, 16-byte chunk 2c + g)

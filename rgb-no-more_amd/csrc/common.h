@@ -187,15 +187,59 @@ __device__ __forceinline__ float ln_bwd_dx(float rs, float gv, float c1, float x
   return __builtin_fmaf(rs, __builtin_fmaf(-xh, c2, t), res);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- lane exchanges inside a row of 16 lanes as DPP operand modifiers.  __shfl_xor compiles to ds_bpermute_b32 (an address
+// computation plus an LDS round trip of ~100 cycles); the row sums of the LayerNorm epilogues are chains of 3-4 of them per
+// row and made up most of those loops' time (mlp_bwd_kernel: 64 dependent exchanges, 9.3 k of its 26 k epilogue cycles).
+// A DPP exchange is one VALU instruction (usually folded into the add).  lane_xorN(v) returns v of lane (id ^ N).
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf,
+                                                               BANK, false));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_take<0xB1, 0xf>(v, v); }      // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_take<0x4E, 0xf>(v, v); }      // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_take<0x128, 0xf>(v, v); }     // row_ror:8
+// lanes 0-3 and 8-11 of a row take lane + 4 (row_shl:4 on banks 0, 2), lanes 4-7 and 12-15 lane - 4 (row_shr:4 on banks 1, 3)
+__device__ __forceinline__ float lane_xor4(float v) { return dpp_take<0x114, 0xa>(dpp_take<0x104, 0x5>(v, v), v); }
+// v of lane (id + 4) mod 16 of the row: equals lane_xor4 when v repeats with period 8 inside the row (after a lane_xor8 step)
+__device__ __forceinline__ float lane_ror4(float v) { return dpp_take<0x124, 0xf>(v, v); }
+
+// butterfly sums in the order 32, 16, 8, 4, 2, 1 (the order -- and therefore the bits -- of the __shfl_xor loops they replace)
+__device__ __forceinline__ float group16_sum(float v) {     // over the 16 lanes of a row
+  v += lane_xor8(v);
+  v += lane_ror4(v);
+  v += lane_xor2(v);
+  v += lane_xor1(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// sum over the 16 virtual lanes of a LayerNorm row held by 8 lanes: s0 / s1 = partial sums of virtual lanes 2 l8 / 2 l8 + 1
+__device__ __forceinline__ float group8_pair_sum(float s0, float s1) {
+  s0 += lane_xor4(s0);
+  s1 += lane_xor4(s1);
+  s0 += lane_xor2(s0);
+  s1 += lane_xor2(s1);
+  s0 += lane_xor1(s0);
+  s1 += lane_xor1(s1);
+  return s0 + s1;
+}
+__device__ __forceinline__ float group8_sum(float v) {      // over the 8 lanes of a half row
+  v += lane_xor4(v);
+  v += lane_xor2(v);
+  v += lane_xor1(v);
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  return group16_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, lane_xor8(v));
+  v = fmaxf(v, lane_ror4(v));
+  v = fmaxf(v, lane_xor2(v));
+  return fmaxf(v, lane_xor1(v));
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

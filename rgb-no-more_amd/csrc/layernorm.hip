@@ -8,11 +8,6 @@
 
 namespace {
 
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 // NV = E / 64 : each of the 16 lanes of a row group holds NV vectors of 4 consecutive elements,
 // element index e = (v*16 + l16)*4 + i.

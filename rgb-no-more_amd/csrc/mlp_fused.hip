@@ -79,14 +79,6 @@ __device__ __forceinline__ int fswz(int row) {
   return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
 }
 __device__ __forceinline__ int pchunk(int lc, int row) { return (lc & ~7) | ((lc & 7) ^ fswz(row)); }
-__device__ __forceinline__ float group8_pair_sum(float s0, float s1) {
-#pragma unroll
-  for (int o = 4; o > 0; o >>= 1) {
-    s0 += __shfl_xor(s0, o, 64);
-    s1 += __shfl_xor(s1, o, 64);
-  }
-  return s0 + s1;
-}
 
 // x_out = acc2 + b2 + R [, LayerNorm of x_out]: the arithmetic of gemm_nt_kpipe's EPI_RES_LN (same bits as ln_fwd_kernel).
 // Called by the compute waves only (the DMA wave has ended); uses the weight ring as the staging tile.
@@ -193,6 +185,14 @@ __device__ unsigned long long g_mlp_trace[16 * 8 * 80];
 #else
 #define MLP_STAMP(i)
 #endif
+// -DMLP_TRACE=2 stamps the backward kernel instead of the forward (same slots, same reader)
+#if defined(MLP_TRACE) && MLP_TRACE == 2
+#define MLP_FSTAMP(i)
+#define MLP_BSTAMP(i) MLP_STAMP(i)
+#else
+#define MLP_FSTAMP(i) MLP_STAMP(i)
+#define MLP_BSTAMP(i)
+#endif
 
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
-  MLP_STAMP(0);
-#ifdef MLP_TRACE
+  MLP_FSTAMP(0);
+#if defined(MLP_TRACE) && MLP_TRACE != 2
   if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 79] = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -239,14 +239,14 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
     issue(0);
     for (int c = 0; c < NCHUNK; ++c) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c (and, the first time, the biases) landed
-      MLP_STAMP(2 + 5 * c);
+      MLP_FSTAMP(2 + 5 * c);
       __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
-      MLP_STAMP(3 + 5 * c);
+      MLP_FSTAMP(3 + 5 * c);
       if (c + 1 < NCHUNK) issue(c + 1);
-      MLP_STAMP(4 + 5 * c);
+      MLP_FSTAMP(4 + 5 * c);
     }
-    MLP_STAMP(62);
-#ifdef MLP_TRACE
+    MLP_FSTAMP(62);
+#if defined(MLP_TRACE) && MLP_TRACE != 2
     if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 78] = __builtin_amdgcn_s_memrealtime();
 #endif
     return;                                               // ended waves drop out of the workgroup barrier
@@ -268,15 +268,15 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
   const int fl = fswz(l31);
   const int woff0 = l31 * (E * 2) + ((g ^ fl) << 4);      // W1 fragment c of LDS row l31: (woff0 ^ ((c % 4) << 5)) + 128 (c / 4)
   unsigned char* stg = smem + STG_OFF + w * STG_WAVE;
-#ifdef MLP_TRACE
+#if defined(MLP_TRACE) && MLP_TRACE != 2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-  MLP_STAMP(1);
+  MLP_FSTAMP(1);
 
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-    MLP_STAMP(2 + 5 * chunk);
+    MLP_FSTAMP(2 + 5 * chunk);
     __builtin_amdgcn_s_barrier();
-    MLP_STAMP(3 + 5 * chunk);
+    MLP_FSTAMP(3 + 5 * chunk);
     const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
     const unsigned char* sW2 = sW1 + W1_STAGE;
 #pragma unroll
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
 #pragma unroll
         for (int b = 0; b < 6; ++b) mma(acc2[b], fw[b], pg[hs]);     // D rows = output features, D cols = tokens
       }
-      if (ht == 0) MLP_STAMP(4 + 5 * chunk);
-      else MLP_STAMP(5 + 5 * chunk);
+      if (ht == 0) MLP_FSTAMP(4 + 5 * chunk);
+      else MLP_FSTAMP(5 + 5 * chunk);
     }
     // ---- the chunk's gelu / gelu' tiles: 32 rows x 128 B each, out as whole row pieces (LDS runs a wave in order)
     const int ln = lane_id_here();
@@ -352,12 +352,12 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
         }
       }
     }
-    MLP_STAMP(6 + 5 * chunk);
+    MLP_FSTAMP(6 + 5 * chunk);
   }
-  MLP_STAMP(62);
+  MLP_FSTAMP(62);
   mlp_epilogue(p, smem, B2s, acc2, m0, rows, tid, w, l31, g);
-  MLP_STAMP(63);
-#ifdef MLP_TRACE
+  MLP_FSTAMP(63);
+#if defined(MLP_TRACE) && MLP_TRACE != 2
   if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 78] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
@@ -386,11 +386,6 @@ constexpr int LB_GROUPS = CTHREADS / 16, LB_ITERS = BM / LB_GROUPS;      // 28 r
 constexpr int RED_OFF = (BM * CP * 2 + 1023) / 1024 * 1024;              // column-reduction scratch behind the staging tile
 static_assert(RED_OFF + LB_GROUPS * (E + 4) * 4 <= SMEM, "LN-backward scratch: the ring and the (by then dead) staging tiles");
 
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -461,6 +456,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
     }
   };
   load_gp(0);
+  MLP_BSTAMP(0);
+  MLP_BSTAMP(1);
 
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
 #pragma unroll
@@ -469,7 +466,9 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
       *reinterpret_cast<bf16x8*>(stg + row * (CH * 2) + ((vec ^ (row & 7)) << 4)) = gpraw[i];
     }
     if (chunk + 1 < NCHUNK) load_gp(chunk + 1);
+    MLP_BSTAMP(2 + 5 * chunk);
     __builtin_amdgcn_s_barrier();
+    MLP_BSTAMP(3 + 5 * chunk);
     const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
     const unsigned char* sW2 = sW1 + W1_STAGE;
 #pragma unroll
@@ -508,6 +507,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
 #pragma unroll
         for (int b = 0; b < 6; ++b) mma(acc2[b], fw[b], pg[hs]);     // D rows = input features, D cols = tokens
       }
+      if (ht == 0) MLP_BSTAMP(4 + 5 * chunk);
+      else MLP_BSTAMP(5 + 5 * chunk);
     }
     // ---- the chunk's du tile: 32 rows x 128 B, out as whole row pieces
 #pragma unroll
@@ -517,7 +518,9 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
       if (32 * w + row < rows)
         *reinterpret_cast<bf16x8*>(p.DU + (size_t)(m0 + 32 * w + row) * p.ldu + chunk * CH + vec * 8) = v0;
     }
+    MLP_BSTAMP(6 + 5 * chunk);
   }
+  MLP_BSTAMP(62);
 
   // ---------------- epilogue: dx = dy + LayerNorm'(acc2): the arithmetic of gemm_nt_kpipe's EPI_LNBWD
   const int l16 = tid & 15, grp16 = tid >> 4;
@@ -537,8 +540,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
       lrb[it][v] = *reinterpret_cast<const bf16x4*>(p.DY + (size_t)rr * p.lddy + (v * 16 + l16) * 4);
     }
   }
+  MLP_BSTAMP(64);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the staging tile
+  MLP_BSTAMP(65);
   bf16* Cs = reinterpret_cast<bf16*>(smem);
 #pragma unroll
   for (int b = 0; b < 6; ++b)
@@ -550,6 +555,11 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  MLP_BSTAMP(66);
+#if defined(MLP_TRACE) && MLP_TRACE == 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MLP_BSTAMP(67);
+#endif
   f32x4 dg[3], db[3];
 #pragma unroll
   for (int v = 0; v < 3; ++v) {
@@ -583,6 +593,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
       }
     }
   }
+  MLP_BSTAMP(68);
   // panel-level column sums of dgamma / dbeta (fixed order => deterministic); reduced across panels by reduce.hip
   float* red = reinterpret_cast<float*>(smem + RED_OFF);
   for (int pass = 0; pass < 2; ++pass) {
@@ -599,6 +610,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
       p.part[((size_t)panel * 2 + pass) * E + e] = a;
     }
   }
+  MLP_BSTAMP(63);
 }
 
 }  // namespace

@@ -28,7 +28,7 @@ if __name__ == "__main__":
         print(f"wg {wg}: wave 0 lifetime {ticks} ticks = {real:.0f} ns  ({ticks / max(real, 1):.3f} ticks/ns)")
         for w in (0, 3, 4, 6, 7):
             r = t[wg, w] - base
-            print(f"  wave {w}: start {r[0]}  X-loaded {r[1]}  loop-end {r[62]}  end {r[63] if w < 7 else 0}")
+            print(f"  wave {w}: start {r[0]}  X-loaded {r[1]}  loop-end {r[62]}  end {r[63] if w < 7 else 0}   epilogue stamps 64.. {[int(v) for v in (r[64:69] - r[62])]}")
             rows = []
             for c in range(12):
                 s = r[2 + 5 * c:7 + 5 * c]
