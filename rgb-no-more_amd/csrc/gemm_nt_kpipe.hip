@@ -10,6 +10,7 @@
 // memory -> coalesced 16-byte row pieces, bias and the residual (prefetched into registers before the loop) fused.
 #include "common.h"
 #include "internal.h"
+#include "ln_bwd_rows.h"
 #include "../../include/rgbnm.h"
 
 #define KP_NS kp7

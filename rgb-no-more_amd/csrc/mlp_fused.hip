@@ -45,6 +45,7 @@
 // 1700 to 2600 ticks next to the MFMA wave); scalar instead of packed GELU arithmetic (88 us).
 #include "common.h"
 #include "internal.h"
+#include "ln_bwd_rows.h"
 #include "../../include/rgbnm.h"
 
 namespace {
@@ -382,9 +383,9 @@ struct MlpBwdArgs {
   const bf16* X; int ldx; const float* gamma; const float* mean; const float* rstd;     // LayerNorm input rows + saved statistics
   bf16* DX; int lddx; float* part;                                                      // part: [npanels][2][192]
 };
-constexpr int LB_GROUPS = CTHREADS / 16, LB_ITERS = BM / LB_GROUPS;      // 28 row groups of 16 lanes, 8 rounds
 constexpr int RED_OFF = (BM * CP * 2 + 1023) / 1024 * 1024;              // column-reduction scratch behind the staging tile
-static_assert(RED_OFF + LB_GROUPS * (E + 4) * 4 <= SMEM, "LN-backward scratch: the ring and the (by then dead) staging tiles");
+typedef rgbnm::LnBwdRows<CTHREADS, BM> LnBwd;
+static_assert(RED_OFF + LnBwd::RED_BYTES <= SMEM, "LN-backward scratch: the ring and the (by then dead) staging tiles");
 
 
 __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
@@ -522,24 +523,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
   }
   MLP_BSTAMP(62);
 
-  // ---------------- epilogue: dx = dy + LayerNorm'(acc2): the arithmetic of gemm_nt_kpipe's EPI_LNBWD
-  const int l16 = tid & 15, grp16 = tid >> 4;
-  bf16x4 lx[LB_ITERS][3], lrb[LB_ITERS][3];
-  float lmu[LB_ITERS], lrs[LB_ITERS];
-  f32x4 gmb[3];
-#pragma unroll
-  for (int v = 0; v < 3; ++v) gmb[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * 16 + l16) * 4);
-#pragma unroll
-  for (int it = 0; it < LB_ITERS; ++it) {
-    const int row = it * LB_GROUPS + grp16, rr = m0 + (row < rows ? row : rows - 1);
-    lmu[it] = p.mean[rr];
-    lrs[it] = p.rstd[rr];
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      lx[it][v] = *reinterpret_cast<const bf16x4*>(p.X + (size_t)rr * p.ldx + (v * 16 + l16) * 4);
-      lrb[it][v] = *reinterpret_cast<const bf16x4*>(p.DY + (size_t)rr * p.lddy + (v * 16 + l16) * 4);
-    }
-  }
+  // ---------------- epilogue: dx = dy + LayerNorm'(acc2): gemm_nt_kpipe's EPI_LNBWD (ln_bwd_rows.h, 8 lanes per row)
+  LnBwd lnb;
+  lnb.request_x(p.X, p.ldx, p.mean, p.rstd, m0, rows, tid);
+  lnb.request_res(p.DY, p.lddy, m0, rows, tid);
   MLP_BSTAMP(64);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the staging tile
@@ -556,60 +543,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   MLP_BSTAMP(66);
-#if defined(MLP_TRACE) && MLP_TRACE == 2
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  MLP_BSTAMP(67);
-#endif
-  f32x4 dg[3], db[3];
-#pragma unroll
-  for (int v = 0; v < 3; ++v) {
-    dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int it = 0; it < LB_ITERS; ++it) {
-    const int row = it * LB_GROUPS + grp16;
-    if (row < rows) {
-      const float mu = lmu[it], rs = lrs[it];
-      f32x4 xh[3], gv[3];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        const bf16x4 dvb = *reinterpret_cast<const bf16x4*>(Cs + row * CP + (v * 16 + l16) * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float xh_, gv_, dg_ = dg[v][i], db_ = db[v][i];
-          ln_bwd_acc((float)dvb[i], (float)lx[it][v][i], mu, rs, gmb[v][i], xh_, gv_, s1, s2, dg_, db_);
-          xh[v][i] = xh_; gv[v][i] = gv_; dg[v][i] = dg_; db[v][i] = db_;
-        }
-      }
-      const float c1 = group16_sum(s1) * (1.f / E), c2 = group16_sum(s2) * (1.f / E);
-#pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        f32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = ln_bwd_dx(rs, gv[v][i], c1, xh[v][i], c2, (float)lrb[it][v][i]);
-        store4<bf16>(p.DX + (size_t)(m0 + row) * p.lddx + (v * 16 + l16) * 4, o);
-      }
-    }
-  }
-  MLP_BSTAMP(68);
-  // panel-level column sums of dgamma / dbeta (fixed order => deterministic); reduced across panels by reduce.hip
-  float* red = reinterpret_cast<float*>(smem + RED_OFF);
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) red[grp16 * (E + 4) + (v * 16 + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
-    __syncthreads();
-    for (int e = tid; e < E; e += CTHREADS) {
-      float a = 0.f;
-#pragma unroll
-      for (int r = 0; r < LB_GROUPS; ++r) a += red[r * (E + 4) + e];
-      p.part[((size_t)panel * 2 + pass) * E + e] = a;
-    }
-  }
+  lnb.run(Cs, CP, p.DX, p.lddx, p.gamma, true, p.part, panel, reinterpret_cast<float*>(smem + RED_OFF), m0, rows, tid);
   MLP_BSTAMP(63);
 }
 
@@ -658,7 +592,7 @@ int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1
 int rgbnm_launch_mlp_bwd(const void* DY, int lddy, const void* W2T, const void* W1T, const void* GP, int ldg, void* DU, int ldu,
                          const void* X, int ldx, const float* gamma, const float* mean, const float* rstd, void* DX, int lddx,
                          float* part, int* npanels_out, int M, int Edim, int Hdim, hipStream_t st) {
-  if (Edim != E || Hdim != H || M < 8192 || lddy % 8 || ldg % 8 || ldu % 8 || ldx % 4 || lddx % 4) return 1;
+  if (Edim != E || Hdim != H || M < 8192 || lddy % 8 || ldg % 8 || ldu % 8 || ldx % 8 || lddx % 8) return 1;
   if (!DY || !W2T || !W1T || !GP || !DU || !X || !gamma || !mean || !rstd || !DX || !part || !npanels_out) return RGBNM_EINVAL;
   MlpBwdArgs p;
   p.DY = (const bf16*)DY; p.W2T = (const bf16*)W2T; p.W1T = (const bf16*)W1T; p.GP = (const bf16*)GP; p.DU = (bf16*)DU;
