@@ -10,7 +10,10 @@ from . import lib as L
 
 class RandomMixup_DCT(torch.nn.Module):
     """Roll-by-one batch mixup of (Y, CbCr) and labels; lambda ~ Dirichlet(alpha, alpha) sorted descending
-    (cls_transforms.py:135-182).  lambda stays on the device: no host sync in the step."""
+    (cls_transforms.py:135-182).  As in the reference (:168) lambda is drawn on the HOST from torch's CPU generator -- the same
+    random stream for the same seed -- and reaches the kernels through a small ring of pinned slots with one asynchronous copy:
+    no host sync in the step, and none of the half-dozen tiny device kernels a device-side Dirichlet + sort costs."""
+    _SLOTS = 16
 
     def __init__(self, num_classes: int, alpha: float = 1.0, inplace: bool = False) -> None:
         super().__init__()
@@ -22,8 +25,27 @@ class RandomMixup_DCT(torch.nn.Module):
         self.out_dtype = None   # None: keep the input dtype
 
     def sample_lambda(self, device):
-        lam, _ = torch._sample_dirichlet(torch.tensor([self.alpha, self.alpha], device=device)).sort(descending=True)
-        return lam.to(torch.float32).contiguous()
+        lam, _ = torch._sample_dirichlet(torch.tensor([self.alpha, self.alpha])).sort(descending=True)
+        lam = lam.to(torch.float32)
+        device = torch.device(device)
+        if device.type != "cuda":
+            return lam.contiguous()
+        ring = self.__dict__.setdefault("_ring", {})
+        st = ring.get(device)
+        if st is None:
+            st = ring[device] = {"host": torch.empty(self._SLOTS, 2, dtype=torch.float32).pin_memory(),
+                                 "dev": torch.empty(self._SLOTS, 2, dtype=torch.float32, device=device),
+                                 "ev": [None] * self._SLOTS, "i": 0}
+        i = st["i"]
+        st["i"] = (i + 1) % self._SLOTS
+        if st["ev"][i] is not None:
+            st["ev"][i].synchronize()          # the copy that last used this pinned slot (16 steps ago) has long completed
+        st["host"][i].copy_(lam)
+        st["dev"][i].copy_(st["host"][i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        st["ev"][i] = ev
+        return st["dev"][i]
 
     def forward(self, batch, target: Tensor, lam: Tensor = None) -> Tuple[Tensor, Tensor]:
         if target.ndim != 1:

@@ -267,6 +267,15 @@ def test_mixup_golden(golden):
     np.testing.assert_allclose(mt.cpu().numpy(), g["mt"], atol=1e-6)
     lam2 = mix.sample_lambda(DEV)
     assert lam2[0] >= lam2[1] and abs(lam2.sum().item() - 1) < 1e-5
+    # the draw is the reference's own expression on the CPU generator (cls_transforms.py:168): same seed, same lambda --
+    # also across more draws than the pinned staging ring has slots
+    torch.manual_seed(77)
+    want = [torch._sample_dirichlet(torch.tensor([0.2, 0.2])).sort(descending=True)[0].float() for _ in range(40)]
+    torch.manual_seed(77)
+    got = [mix.sample_lambda(DEV).clone() for _ in range(40)]
+    torch.cuda.synchronize()
+    for w, g_ in zip(want, got):
+        assert torch.equal(w, g_.cpu())
 
 
 def test_clip_adamw_wd_golden(golden):
