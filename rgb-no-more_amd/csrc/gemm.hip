@@ -273,6 +273,13 @@ int launch_nt_epi(const GemmNT& p, int epi, hipStream_t st) {
 template <typename T, int NB>
 int launch_nt_sel(const GemmNT& p, int epi, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
+    if (p.M <= 512 && !p.pos && !p.C2 && rgbnm_get_option("nt_small")) {
+      // few rows (the classification head: M = batch): 32 x 32 tiles, the reduction split over a workgroup's four waves
+      // (gemm_nt_small.hip); 1 = shape / epilogue not eligible
+      const int rc = rgbnm_launch_nt_small(epi, p.A, p.lda, p.W, p.ldw, p.C, p.ldc, p.bias, p.R, p.ldr, p.c_f32, p.M, p.N,
+                                           p.K, st);
+      if (rc != 1) return rc;
+    }
     const bool ok = !p.c_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!p.R || p.ldr % 8 == 0) &&
                     (!p.C2 || p.ldc2 % 8 == 0) && rgbnm_get_option("nt_staged");
     if (ok && !p.pos && rgbnm_get_option("nt_kpipe")) {

@@ -42,6 +42,10 @@ int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1
                          const void* R, int ldr, void* G, void* GP, int ldg, void* Y, int ldy, const float* gamma,
                          const float* beta, void* Y2, int ldy2, float* mean, float* rstd, float eps, int M, int E, int H,
                          hipStream_t st);
+// NT GEMM for few rows (M <= 512: the classification head), bf16 operands, bf16 or fp32 output, epilogues none / tanh /
+// (1 - h^2) product (gemm_nt_small.hip); 1 = not eligible.
+int rgbnm_launch_nt_small(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
+                          const void* R, int ldr, int c_f32, int M, int N, int K, hipStream_t st);
 // The backward of the same block's data path in one launch (mlp_fused.hip): du = (dy . W2) * gelu'(u) -> DU (for the dW1 GEMM),
 // dx = dy + LayerNorm'(du . W1) -> DX, panel partial sums of dgamma / dbeta -> part [npanels][2][192]; 1 = not eligible.
 int rgbnm_launch_mlp_bwd(const void* DY, int lddy, const void* W2T, const void* W1T, const void* GP, int ldg, void* DU, int ldu,

@@ -332,6 +332,36 @@ def test_gemm_nt_bf16_epilogue_paths(option, staged):
         test_gemm_nt_bias(torch.bfloat16, *shp)
 
 
+@pytest.mark.parametrize("small", [0, 1])
+def test_gemm_nt_bf16_few_rows_path(option, small):
+    """gemm_nt_small.hip (M <= 512: the head's GEMMs) and the tile-per-workgroup kernel on the head's shapes and on ragged
+    ones, against torch fp32: bias, tanh, the (1 - h^2) product, bf16 and fp32 outputs, K with a half MFMA step (1000)."""
+    option("nt_small", small)
+    dt = torch.bfloat16
+    for M, N, K in [(256, 192, 192), (256, 1000, 192), (256, 192, 1000), (77, 1000, 192), (33, 36, 72), (512, 192, 1000)]:
+        A = dev(detfill.normalish((M, K), 31), dt)
+        W = dev(detfill.uniform((N, K), 32, -0.1, 0.1), dt)
+        b = dev(detfill.uniform((N,), 33))
+        base = A.float() @ W.float().T
+        out, _ = gemm_nt(dt, L.EPI_NONE, A, W, b)
+        assert relerr(out, base + b) < 4e-3, (M, N, K)
+        out32, _ = gemm_nt(dt, L.EPI_NONE, A, W, b, c_f32=True)
+        assert out32.dtype == torch.float32 and relerr(out32, base + b) < 1e-5, (M, N, K)
+        out, _ = gemm_nt(dt, L.EPI_TANH, A, W, b)
+        assert relerr(out, torch.tanh((base + b).to(dt).float())) < 4e-3, (M, N, K)
+        h = torch.tanh(dev(detfill.normalish((M, N), 34))).to(dt)
+        out, _ = gemm_nt(dt, L.EPI_DTANH, A, W, None, R=h)
+        assert relerr(out, base * (1 - h.float() ** 2)) < 6e-3, (M, N, K)
+    # a selector operand catches row / column swaps of the accumulator layout
+    M, N, K = 64, 96, 64
+    A = torch.zeros(M, K, device=DEV)
+    for i in range(M):
+        A[i, (i * 7) % K] = 1.0
+    W = dev(detfill.uniform((N, K), 35), dt)
+    out, _ = gemm_nt(dt, L.EPI_NONE, A.to(dt), W)
+    assert torch.equal(out.float(), (A @ W.float().T))
+
+
 @pytest.mark.parametrize("tr", [0, 1])
 def test_gemm_tn_bf16_fragment_paths(option, tr):
     option("tn_tr", tr)
