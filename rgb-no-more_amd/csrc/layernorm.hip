@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dpo
   }
 }
 
-constexpr int LN_BWD_BLOCKS = 512;   // 2 workgroups per CU
+constexpr int LN_BWD_BLOCKS = 2048;  // 8 workgroups per CU: the row loop has no prefetch, so the loads in flight come from the number of resident workgroups
 
 template <typename T>
 int ln_fwd_t(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int E, float eps,
