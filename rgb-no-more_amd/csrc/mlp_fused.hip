@@ -62,7 +62,8 @@ constexpr int STG_OFF = NSTAGE * STAGE;             // per-wave staging: gelu ti
 constexpr int STG_TILE = 32 * CH * 2, STG_WAVE = 2 * STG_TILE;
 constexpr int B1_OFF = STG_OFF + NCW * STG_WAVE;    // 768 floats
 constexpr int B2_OFF = B1_OFF + H * 4;              // 192 floats
-constexpr int SMEM = B2_OFF + E * 4;                // 159,488 B
+constexpr int FLAG_OFF = B2_OFF + E * 4;            // one int: the last chunk whose tiles of waves 4-6 the DMA wave has taken
+constexpr int SMEM = FLAG_OFF + 16;                 // 159,504 B
 constexpr int CP = E + 4;                           // final staging pitch (elements)
 constexpr int LN_GROUPS = CTHREADS / 8, LN_ITERS = BM / LN_GROUPS;      // 56 row groups of 8 lanes, 4 rounds
 static_assert(SMEM <= 160 * 1024, "LDS");
@@ -73,6 +74,7 @@ struct MlpArgs {
   bf16* G; bf16* GP; bf16* Y;
   int ldx, ldr, ldg, ldy;
   int M, rows_per_wg, npanels, cold;       // cold: 1 = nt stores, 2 = sc1 (write-through) stores for the saved tensors
+  int offload;                             // 1: the DMA wave stores the gelu / gelu' tiles of waves 4-6 (option mlp_dmast)
   const float* gamma; const float* beta; bf16* Y2; float* mean_o; float* rstd_o; float eps; int ldy2;   // gamma == null: no LN
 };
 
@@ -237,12 +239,53 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
                                          (lds_ptr)(st + W1_STAGE + i * 1024), 16, 0, 0);
       }
     };
+    // offload: the younger wave of each SIMD pair (4, 5, 6) is the critical path of a chunk (stamps: it is starved while the
+    // older one runs, then finishes alone and stores); its tile stores are taken over by this wave, which is idle between two
+    // weight chunks.  After barrier c + 1 the tiles of chunk c are complete: read them into registers, raise the flag (the
+    // owners poll it before they overwrite the tiles), issue the stores, then the next weight chunk (it has a whole chunk to land).
+    volatile int* flag = reinterpret_cast<volatile int*>(smem + FLAG_OFF);
+    bf16x8 tv[3][2][4];
+    const int trow = lane >> 3, tvec = lane & 7;
+    auto take_tiles = [&]() {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = trow + 8 * i;
+            tv[q][t][i] = *reinterpret_cast<const bf16x8*>(smem + STG_OFF + (4 + q) * STG_WAVE + t * STG_TILE + row * (CH * 2) +
+                                                           ((tvec ^ (row & 7)) << 4));
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto store_tiles = [&](int chunk) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 32 * (4 + q) + trow + 8 * i;
+          if (row < rows) {
+            const size_t go = (size_t)(m0 + row) * p.ldg + chunk * CH + tvec * 8;
+            *reinterpret_cast<bf16x8*>(p.G + go) = tv[q][0][i];
+            *reinterpret_cast<bf16x8*>(p.GP + go) = tv[q][1][i];
+          }
+        }
+    };
+    if (p.offload && lane == 0) *flag = 0;
     issue(0);
     for (int c = 0; c < NCHUNK; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c (and, the first time, the biases) landed
+      // chunk c (and, the first time, the biases) landed -- and the tile stores issued before it (vmcnt retires in order; the
+      // number of store instructions depends on the valid rows, so no counted wait)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       MLP_FSTAMP(2 + 5 * c);
       __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
       MLP_FSTAMP(3 + 5 * c);
+      if (p.offload && c >= 1) {
+        take_tiles();
+        if (lane == 0) *flag = c;
+        store_tiles(c - 1);
+      }
       if (c + 1 < NCHUNK) issue(c + 1);
       MLP_FSTAMP(4 + 5 * c);
     }
@@ -250,6 +293,12 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
 #if defined(MLP_TRACE) && MLP_TRACE != 2
     if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 78] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (p.offload) {                                      // the last chunk's tiles: after the epilogue's first barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      take_tiles();
+      store_tiles(NCHUNK - 1);
+    }
     return;                                               // ended waves drop out of the workgroup barrier
   }
 
@@ -274,8 +323,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
 #endif
   MLP_FSTAMP(1);
 
+  const bool handed = p.offload && w >= 4;                // this wave's tiles leave through the DMA wave
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
     MLP_FSTAMP(2 + 5 * chunk);
+    if (p.offload) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile writes of the previous chunk are in LDS
     __builtin_amdgcn_s_barrier();
     MLP_FSTAMP(3 + 5 * chunk);
     const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
@@ -295,6 +346,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
         mma(a1, fb, fx);                                   // D rows = hidden (LDS row order), D cols = tokens
       }
       Frag<bf16> pg[2];
+      if (handed && ht == 0 && chunk > 0) {               // the DMA wave has taken the previous chunk's tiles (normally long ago)
+        const volatile int* flag = reinterpret_cast<const volatile int*>(smem + FLAG_OFF);
+        while (__builtin_amdgcn_readfirstlane(*flag) < chunk) __builtin_amdgcn_s_sleep(1);
+      }
 #pragma unroll
       for (int hs = 0; hs < 2; ++hs) {
         // registers 8 hs .. 8 hs + 7 of this lane = hidden units h0 .. h0 + 7 of the token l31 (rows were stored swap23-ed)
@@ -334,6 +389,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
     }
     // ---- the chunk's gelu / gelu' tiles: 32 rows x 128 B each, out as whole row pieces (LDS runs a wave in order)
     const int ln = lane_id_here();
+    if (!handed)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
@@ -382,6 +438,7 @@ struct MlpBwdArgs {
   int M, rows_per_wg, npanels;
   const bf16* X; int ldx; const float* gamma; const float* mean; const float* rstd;     // LayerNorm input rows + saved statistics
   bf16* DX; int lddx; float* part;                                                      // part: [npanels][2][192]
+  int offload;                                                                          // option mlp_dmast, see MlpArgs
 };
 constexpr int RED_OFF = (BM * CP * 2 + 1023) / 1024 * 1024;              // column-reduction scratch behind the staging tile
 typedef rgbnm::LnBwdRows<CTHREADS, BM> LnBwd;
@@ -418,11 +475,48 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
                                          (lds_ptr)(st + W1_STAGE + i * 1024), 16, 0, 0);
       }
     };
+    // offload (as in mlp_fwd_kernel): the du tiles of waves 4-6, the younger and therefore critical wave of each SIMD pair,
+    // leave through this wave: registers after barrier c + 1, flag, 12 stores, next weight chunk
+    volatile int* flag = reinterpret_cast<volatile int*>(smem + FLAG_OFF);
+    bf16x8 tv[3][4];
+    const int trow = lane >> 3, tvec = lane & 7;
+    auto take_tiles = [&]() {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = trow + 8 * i;
+          tv[q][i] = *reinterpret_cast<const bf16x8*>(smem + STG_OFF + (4 + q) * STG_WAVE + STG_TILE + row * (CH * 2) +
+                                                      ((tvec ^ (row & 7)) << 4));
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto store_tiles = [&](int chunk) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 32 * (4 + q) + trow + 8 * i;
+          if (row < rows) *reinterpret_cast<bf16x8*>(p.DU + (size_t)(m0 + row) * p.ldu + chunk * CH + tvec * 8) = tv[q][i];
+        }
+    };
+    if (p.offload && lane == 0) *flag = 0;
     issue(0);
     for (int c = 0; c < NCHUNK; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c landed
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // chunk c landed (and the tile stores issued before it)
       __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
+      if (p.offload && c >= 1) {
+        take_tiles();
+        if (lane == 0) *flag = c;
+        store_tiles(c - 1);
+      }
       if (c + 1 < NCHUNK) issue(c + 1);
+    }
+    if (p.offload) {                                      // the last chunk's tiles: after the epilogue's first barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      take_tiles();
+      store_tiles(NCHUNK - 1);
     }
     return;                                               // ended waves drop out of the workgroup barrier
   }
@@ -460,6 +554,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
   MLP_BSTAMP(0);
   MLP_BSTAMP(1);
 
+  const bool handed = p.offload && w >= 4;                // this wave's du tiles leave through the DMA wave
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -467,6 +562,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
       *reinterpret_cast<bf16x8*>(stg + row * (CH * 2) + ((vec ^ (row & 7)) << 4)) = gpraw[i];
     }
     if (chunk + 1 < NCHUNK) load_gp(chunk + 1);
+    if (p.offload) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // du tile writes of the previous chunk are in LDS
     MLP_BSTAMP(2 + 5 * chunk);
     __builtin_amdgcn_s_barrier();
     MLP_BSTAMP(3 + 5 * chunk);
@@ -487,6 +583,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
         mma(a1, fb, fx);                                   // D rows = hidden (LDS row order), D cols = tokens
       }
       Frag<bf16> pg[2];
+      if (handed && ht == 0 && chunk > 0) {               // the DMA wave has taken the previous chunk's du tile
+        const volatile int* flag = reinterpret_cast<const volatile int*>(smem + FLAG_OFF);
+        while (__builtin_amdgcn_readfirstlane(*flag) < chunk) __builtin_amdgcn_s_sleep(1);
+      }
 #pragma unroll
       for (int hs = 0; hs < 2; ++hs) {
         // registers 8 hs .. 8 hs + 7 of this lane = hidden units h0 .. h0 + 7 of the token l31 (rows were stored swap23-ed)
@@ -512,6 +612,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
       else MLP_BSTAMP(5 + 5 * chunk);
     }
     // ---- the chunk's du tile: 32 rows x 128 B, out as whole row pieces
+    if (!handed)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
@@ -568,6 +669,7 @@ int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1
   p.G = (bf16*)G; p.GP = (bf16*)GP; p.Y = (bf16*)Y;
   p.ldx = ldx; p.ldr = ldr; p.ldg = ldg; p.ldy = ldy; p.M = M;
   p.cold = rgbnm_get_option("nt_cold");
+  p.offload = rgbnm_get_option("mlp_dmast");
   p.gamma = gamma; p.beta = beta; p.Y2 = (bf16*)Y2; p.mean_o = mean; p.rstd_o = rstd; p.eps = eps; p.ldy2 = ldy2;
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;
@@ -598,6 +700,7 @@ int rgbnm_launch_mlp_bwd(const void* DY, int lddy, const void* W2T, const void* 
   p.DY = (const bf16*)DY; p.W2T = (const bf16*)W2T; p.W1T = (const bf16*)W1T; p.GP = (const bf16*)GP; p.DU = (bf16*)DU;
   p.lddy = lddy; p.ldg = ldg; p.ldu = ldu; p.M = M;
   p.X = (const bf16*)X; p.ldx = ldx; p.gamma = gamma; p.mean = mean; p.rstd = rstd; p.DX = (bf16*)DX; p.lddx = lddx; p.part = part;
+  p.offload = rgbnm_get_option("mlp_dmast");
   int rows = cdiv(M, 256);
   if (rows > BM) rows = BM;
   p.rows_per_wg = rows;

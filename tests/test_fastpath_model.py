@@ -183,6 +183,16 @@ def test_fused_mlp_forward_equals_the_two_gemm_path():
         nd = int((a != b).sum())
         print(f"{k:8s} max |d| {float((a - b).abs().max()):.3e}  differing elements {nd} / {a.numel()}")
         assert torch.equal(fused[k], plain[k]), k
+    # option mlp_dmast: the DMA wave stores the saved tensors of waves 4-6 (LDS flag hand-over) -- same bits, every time
+    old = lib.rgbnm_get_option(b"mlp_dmast")
+    try:
+        L.check(lib.rgbnm_set_option(b"mlp_dmast", 1 - old))
+        for rep in range(3):
+            other = snapshot()
+            for k in other:
+                assert torch.equal(other[k], plain[k]), (k, rep)
+    finally:
+        L.check(lib.rgbnm_set_option(b"mlp_dmast", old))
 
 
 def test_fused_mlp_backward_equals_the_two_gemm_path():
@@ -214,6 +224,15 @@ def test_fused_mlp_backward_equals_the_two_gemm_path():
         L.check(lib.rgbnm_set_option(b"mlp_bwd", 1))
     for n in fused:
         assert torch.equal(fused[n], plain[n]), n
+    old = lib.rgbnm_get_option(b"mlp_dmast")               # du tiles of waves 4-6 through the DMA wave: same bits, every time
+    try:
+        L.check(lib.rgbnm_set_option(b"mlp_dmast", 1 - old))
+        for rep in range(3):
+            other = grads()
+            for n in other:
+                assert torch.equal(other[n], plain[n]), (n, rep)
+    finally:
+        L.check(lib.rgbnm_set_option(b"mlp_dmast", old))
 
 
 def test_row_panel_gemm_two_workgroups_per_cu_equals_one():
