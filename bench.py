@@ -397,6 +397,31 @@ def main():
     while time.perf_counter() - t_pre < a.prewarm_sec:     # DVFS ramp: cold clocks cost up to 40 % on the first runs
         step()
         torch.cuda.synchronize()
+    sync_schedule = None
+    if world > 1 and grad_sync == "flat":
+        # How to place the collectives is decided by measurement, on every rank alike, before the timed region: slices
+        # all-reduced from inside the backward (overlapped) or ONE all-reduce of the flat buffer after it.  The compute
+        # kernels of this library run one workgroup per CU with nearly all of its LDS, so an RCCL kernel that holds a few CUs
+        # while a backward kernel launches can push that kernel into a second round -- which schedule wins depends on the
+        # RCCL channel count and the link speed, i.e. on the node.
+        fs = model._grad_sync
+        best = None
+        for name, elems in (("overlapped 4 MB slices", (4 << 20) // 4), ("overlapped 16 MB slices", (16 << 20) // 4),
+                            ("one all-reduce after the backward", 1 << 60)):
+            fs.bucket_elems = elems
+            for _ in range(2):
+                step()
+            barrier()
+            tc = time.perf_counter()
+            for _ in range(6):
+                step()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - tc], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if best is None or tt.item() < best[0]:
+                best = (tt.item(), name, elems)
+        fs.bucket_elems = best[2]
+        sync_schedule = best[1]
     TAG_NT = 1
     trace_on = (not a.no_trace) and rank == 0
     for i in range(a.warmup):
@@ -466,7 +491,7 @@ def main():
                                    (NAMES[a.arch], a.dtype, B, CONFIG_OF[a.arch],
                                     "model-only on S-randn inputs" if a.no_augment else
                                     "HIP DCT-augment of S-coef 512x512 coefficient batches resident in HBM"),
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "grad_sync": grad_sync,
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "grad_sync": grad_sync if sync_schedule is None else f"{grad_sync}: {sync_schedule}",
                        "loss": round(float(loss.item()), 5)},
             "parity_mode": ("bf16 operands, fp32 accumulate: logits within 2.5e-2 of the fp32 reference (torch's own bf16 autocast of "
                             "the reference deviates 6e-3); the fp32 strict mode (--dtype fp32) carries the 1e-3 north-star "

@@ -138,6 +138,15 @@ def _worker(rank, world, port, out):
     assert not sync._handles
     g4 = torch.cat([p.grad.reshape(-1) for p in m3.parameters()])
     assert torch.allclose(g4, g, atol=1e-6)
+    # bench.py re-times the step under different slice sizes before the timed region (overlapped slices vs one all-reduce
+    # after the backward) by changing bucket_elems between steps: same gradients, and the huge bucket collapses the step to
+    # at most a few collectives (ranges separated by more than alignment padding are not merged)
+    before = sync.collectives
+    sync.bucket_elems = 1 << 60
+    m3.zero_grad(set_to_none=True)
+    m3(x).square().mean().backward()
+    assert not sync._handles and sync._pending is None and 1 <= sync.collectives - before <= 3
+    assert torch.allclose(torch.cat([p.grad.reshape(-1) for p in m3.parameters()]), g, atol=1e-6)
     sync.detach()
     # bench.py's timing reduction: MAX over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
