@@ -6,7 +6,7 @@
 K=${1:-fused_mlp}   # BENCH_ARGS="--arch vits" STEPS=30 select another config
 run() { for i in 1 2; do python bench.py --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline --no-parity-check $BENCH_ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'])"; done; }
 cp rgb-no-more_amd/librgbnm.so /tmp/new.so
-python -m pytest tests/test_fastpath_model.py tests/test_vit_model.py tests/test_hip_kernels.py -m gpu -x -q -k "$K" 2>&1 | tail -2
+python -m pytest ${TESTS:-tests/test_fastpath_model.py tests/test_vit_model.py tests/test_hip_kernels.py} -m gpu -x -q -k "$K" 2>&1 | tail -2
 run new
 cp tools/librgbnm_base.so rgb-no-more_amd/librgbnm.so; run base
 cp /tmp/new.so rgb-no-more_amd/librgbnm.so; run new
