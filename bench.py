@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-baseline-images", type=int, default=64)
     ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel HIP-event trace of the timed region")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B experiments)")
+    ap.add_argument("--no-defer-reduce", action="store_true",
+                    help="run every block's gradient reductions inside its backward instead of one launch per step")
     ap.add_argument("--grad-sync", default="flat", choices=["flat", "ddp"],
                     help="N > 1: zero-copy slice-wise all-reduce of the flat gradient buffer (self-checked, falls back "
                          "to ddp) or torch DistributedDataParallel")
@@ -318,6 +320,11 @@ def main():
         model = rg.ViT(3, 16, emb, depth=12, n_classes=1000, drop_p=0.0, device=dev, num_heads=heads, head_size=64,
                        pixel_space="DCT", ver=1, use_subblock=True)
     model.compute_dtype = cdt
+    # one GPU, or one all-reduce after the backward: no gradient is read before the backward pass is over, so the encoder
+    # blocks' split-sum reductions are held and run as one launch (ViT.defer_grad_reduction; with overlapped slices or torch
+    # DDP the model ignores / must not get the flag)
+    if not swin and not a.no_defer_reduce:
+        model.defer_grad_reduction = True
     net = model
     grad_sync = "none"
     if world > 1:
@@ -338,6 +345,7 @@ def main():
                 model._grad_sync = None
                 grad_sync = "ddp"
         if grad_sync == "ddp":
+            model.defer_grad_reduction = False          # DDP's reducer reads .grad from hooks during the backward
             from torch.nn.parallel import DistributedDataParallel as DDP
             # several ~4 MB buckets so the all-reduce of late layers overlaps the backward of early ones
             net = DDP(model, device_ids=[local], output_device=local, bucket_cap_mb=4, gradient_as_bucket_view=False)

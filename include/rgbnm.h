@@ -268,6 +268,21 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, c
                         const rgbnm_block_grads* g, const rgbnm_block_scratch* s, const void* dy, void* dx,
                         void* stream);
 
+/* Held gradient reductions.  Every backward entry point of this header (rgbnm_vit_block_bwd, rgbnm_head_bwd,
+ * rgbnm_patch_embed_bwd, rgbnm_gemm_tn, rgbnm_layernorm_bwd, ...) finishes with a small reduction of its split partial
+ * sums (reference: autograd accumulates straight into .grad, models/plainvit.py runs under torch.autograd).  A caller that
+ * reads no gradient before the END of the backward pass -- one GPU, or one all-reduce after the pass -- may bracket the pass:
+ *   rgbnm_reduce_hold_begin();  ... backward calls, each with ITS OWN workspace region ...
+ *   rgbnm_reduce_hold_end(table, rgbnm_reduce_hold_table_bytes(), stream);
+ * and all reductions issued in between (on this host thread) run as ONE launch at _end, with the same summation order (same
+ * bits).  `table` is a device buffer of the caller that must stay untouched between steps (the job table is re-uploaded only
+ * when it changed).  The partial sums live in the workspaces until _end: regions must not be shared between the calls of one
+ * bracket.  rgbnm_reduce_hold_cancel() leaves the mode without running anything (error paths). */
+int rgbnm_reduce_hold_begin(void);
+int rgbnm_reduce_hold_end(void* table, size_t table_bytes, void* stream);
+void rgbnm_reduce_hold_cancel(void);
+size_t rgbnm_reduce_hold_table_bytes(void);
+
 /* PatchEmbedding_DCT_Group (plainvit.py:157-218): feat = subblock(y,cbcr); x0 = feat.Wpe^T + b + sincos */
 int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* cfg, int in_dtype, const void* y, const void* cbcr,
                           const float* conv16, const void* wpe, const float* bpe, const float* pos, void* feat,

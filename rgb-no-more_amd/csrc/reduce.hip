@@ -3,6 +3,8 @@
 // composite (rgbnm_vit_block_bwd) brackets its producers with defer_begin / defer_flush so that the twelve small
 // reductions of one transformer block run as ONE launch instead of six latency-bound kernels (measured: 6 launches,
 // 41 us per block -> 1 launch).  Outside a bracket a submit launches immediately: same kernel, same summation order.
+#include <cstddef>
+#include <cstring>
 #include "common.h"
 #include "internal.h"
 
@@ -60,6 +62,88 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(Jobs J) {
   }
 }
 
+// ---- held reductions: a caller that needs no gradient before the END of a backward pass (one GPU, or one all-reduce after
+// the backward) brackets the pass with rgbnm_reduce_hold_begin / _end; every reduction submitted in between -- the twelve of
+// each encoder block, the head's, the patch embedding's -- is collected and run as ONE launch at the end (12 + launches of
+// ~8.5 us, each latency bound, become one bandwidth-bound pass over the partials).  The job table lives in a device buffer of
+// the caller and is uploaded only when it changed (the same pointers come back every step).  Same workgroup-to-element
+// scheme and summation order as reduce_multi_kernel: the same bits.
+constexpr int MAXHELD = 384;
+struct HeldTable {
+  int njobs, total;
+  int first[MAXHELD + 1];      // job k owns workgroups first[k] .. first[k + 1] - 1
+  unsigned char vec[MAXHELD];  // 1: element count, slice stride and base pointer of job k allow 16-byte moves
+  RgbnmReduceJob j[MAXHELD];
+};
+thread_local bool g_hold = false;
+thread_local HeldTable g_held;                 // being collected
+thread_local HeldTable g_uploaded;             // what the device buffer holds
+thread_local const void* g_uploaded_to = nullptr;
+
+// VEC = 4: an element slot is four consecutive elements moved as one 16-byte load per partial slice (the held pass reads
+// partials that have long left the caches: wide loads are what an HBM-bound pass wants); same partial -> group assignment and
+// the same summation order per element as VEC = 1 and as reduce_multi_kernel: the same bits.
+template <int VEC>
+__device__ __forceinline__ void reduce_job(const RgbnmReduceJob& jb, int bx, int nbx, float* red) {
+  const int epw = jb.epw, nsg = 256 / epw;
+  const int el = threadIdx.x % epw, sg = threadIdx.x / epw;
+  for (int base = bx * epw * VEC; base < jb.n; base += nbx * epw * VEC) {
+    const int i = base + el * VEC;
+    float a[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[v] = 0.f;
+    if (i < jb.n) {
+      const float* src = jb.part + i;
+#pragma unroll 8
+      for (int s = sg; s < jb.S; s += nsg) {
+        if (VEC == 4) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(src + (size_t)s * jb.stride);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) a[v] += q[v];
+        } else {
+          a[0] += src[(size_t)s * jb.stride];
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) red[(sg * epw + el) * VEC + v] = a[v];
+    __syncthreads();
+    if (sg == 0 && i < jb.n) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float t;
+        if (nsg == 4) {
+          t = (red[el * VEC + v] + red[(epw + el) * VEC + v]) + (red[(2 * epw + el) * VEC + v] + red[(3 * epw + el) * VEC + v]);
+        } else {
+          t = 0.f;
+          for (int g = 0; g < nsg; ++g) t += red[(g * epw + el) * VEC + v];
+        }
+        int o = i + v;
+        if (jb.perm_heads > 0) {
+          const int r = o / jb.cols, c = o % jb.cols;
+          o = qkv_row_r(r, jb.perm_heads) * jb.cols + c;
+        }
+        jb.out[o] = jb.accumulate ? (jb.out[o] + t) : t;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_table_kernel(const HeldTable* __restrict__ T) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 4];
+  int lo = 0, hi = T->njobs - 1;               // largest k with first[k] <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (T->first[mid] <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const RgbnmReduceJob jb = T->j[lo];
+  const int bx = blockIdx.x - T->first[lo], nbx = T->first[lo + 1] - T->first[lo];
+  if (T->vec[lo]) reduce_job<4>(jb, bx, nbx, red);
+  else reduce_job<1>(jb, bx, nbx, red);
+}
+
 int launch(const Jobs& J, int njobs, hipStream_t st) {
   int gx = 1;
   for (int k = 0; k < njobs; ++k) {
@@ -88,6 +172,10 @@ int rgbnm_reduce_defer_flush(hipStream_t st) {
 
 int rgbnm_reduce_submit(const RgbnmReduceJob& job, hipStream_t st) {
   if (job.n <= 0 || job.S <= 0 || (job.epw != 64 && job.epw != 8)) return RGBNM_EINVAL;
+  if (g_hold && g_held.njobs < MAXHELD) {                  // (a full table: the job runs the ordinary way, in order)
+    g_held.j[g_held.njobs++] = job;
+    return RGBNM_OK;
+  }
   if (g_defer) {
     if (g_njobs == MAXJOBS) {          // queue full: run what is there, keep queueing
       const int rc = launch(g_jobs, g_njobs, st);
@@ -101,3 +189,51 @@ int rgbnm_reduce_submit(const RgbnmReduceJob& job, hipStream_t st) {
   one.j[0] = job;
   return launch(one, 1, st);
 }
+
+extern "C" {
+
+int rgbnm_reduce_hold_begin(void) {
+  g_hold = true;
+  g_held.njobs = 0;
+  return RGBNM_OK;
+}
+
+void rgbnm_reduce_hold_cancel(void) {
+  g_hold = false;
+  g_held.njobs = 0;
+}
+
+int rgbnm_reduce_hold_end(void* table_dev, size_t table_bytes, void* stream) {
+  if (!g_hold) return RGBNM_OK;
+  g_hold = false;
+  const int n = g_held.njobs;
+  if (n == 0) return RGBNM_OK;
+  if (!table_dev || table_bytes < sizeof(HeldTable)) return RGBNM_EWORKSPACE;
+  int total = 0;
+  for (int k = 0; k < n; ++k) {
+    const RgbnmReduceJob& j = g_held.j[k];
+    const bool vec = j.n % 4 == 0 && j.stride % 4 == 0 && ((size_t)j.part & 15) == 0 && (j.perm_heads <= 0 || j.cols % 4 == 0);
+    g_held.vec[k] = vec ? 1 : 0;
+    g_held.first[k] = total;
+    const int need = cdiv(j.n, j.epw * (vec ? 4 : 1));
+    total += need > 1024 ? 1024 : need;
+  }
+  for (int k = n; k <= MAXHELD; ++k) g_held.first[k] = total;
+  g_held.total = total;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t used = offsetof(HeldTable, j) + sizeof(RgbnmReduceJob) * (size_t)n;
+  if (g_uploaded_to != table_dev || memcmp(&g_uploaded, &g_held, used) != 0) {
+    // pageable source: the runtime stages it before returning, so g_held may be reused at once; stream-ordered on st
+    if (hipMemcpyAsync(table_dev, &g_held, used, hipMemcpyHostToDevice, st) != hipSuccess) return RGBNM_ELAUNCH;
+    memcpy(&g_uploaded, &g_held, used);
+    g_uploaded_to = table_dev;
+  }
+  g_held.njobs = 0;
+  hipLaunchKernelGGL(reduce_table_kernel, dim3(total), dim3(256), 0, st, (const HeldTable*)table_dev);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+size_t rgbnm_reduce_hold_table_bytes(void) { return sizeof(HeldTable); }
+
+}  // extern "C"

@@ -89,6 +89,10 @@ PROTOTYPES = {
     "rgbnm_clip_adamw_wd_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _sz, _vp]),
     "rgbnm_vit_workspace": (_sz, [_P(VitCfg)]),
     "rgbnm_vit_workspace_ex": (_sz, [_P(VitCfg), _i]),
+    "rgbnm_reduce_hold_begin": (_i, []),
+    "rgbnm_reduce_hold_end": (_i, [_vp, _sz, _vp]),
+    "rgbnm_reduce_hold_cancel": (None, []),
+    "rgbnm_reduce_hold_table_bytes": (_sz, []),
     "rgbnm_vit_block_fwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_ln_chain": (_i, [_P(VitCfg)]),
     "rgbnm_swin_embed": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

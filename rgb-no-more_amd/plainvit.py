@@ -171,6 +171,7 @@ class _Arena:
             self.scratch = L.BlockScratch(self.du.data_ptr(), self.dxn.data_ptr(), self.dx_mid.data_ptr(),
                                           self.dattn.data_ptr(), self.dqkv.data_ptr(), self.ws.data_ptr(), ws_bytes)
         self.ws_bytes = ws_bytes
+        self.ws_blk = self.hold_table = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
         self.acts = []
         for i in range(D):
             b = self.blk[i if need_grad else 0]
@@ -190,6 +191,37 @@ class _FwdState:
 
     def __init__(self, model, arena, gbuf):
         self.model, self.arena, self.gbuf = model, arena, gbuf
+        self.holding = False
+
+    # ---- held gradient reductions (rgbnm.h rgbnm_reduce_hold_*; ViT.defer_grad_reduction): opened after the head's backward,
+    # closed in front of the patch embedding's, whose own reductions run at once (both nodes run on the same autograd thread:
+    # the library's queues are thread-local)
+    def begin_hold(self):
+        m, a = self.model, self.arena
+        gs = m._grad_sync
+        if not m.defer_grad_reduction or (gs is not None and gs.bucket_elems < m._gflat.numel()):
+            return                                     # somebody reads block gradients before the backward pass is over
+        if not all(p.requires_grad for n, p in m.named_parameters() if n.startswith("patchembed.")):
+            return                                     # a frozen patch embedding has no backward node to close the bracket
+        if a.ws_blk is None:                           # the partial sums of every block now live until the end of the pass
+            a.ws_blk = torch.empty(m.depth * a.ws_bytes, device=a.ws.device, dtype=torch.uint8)
+            a.hold_table = torch.zeros(L.lib().rgbnm_reduce_hold_table_bytes(), device=a.ws.device, dtype=torch.uint8)
+            a.scratch_blk = [L.BlockScratch(a.du.data_ptr(), a.dxn.data_ptr(), a.dx_mid.data_ptr(), a.dattn.data_ptr(),
+                                            a.dqkv.data_ptr(), a.ws_blk.data_ptr() + i * a.ws_bytes, a.ws_bytes)
+                             for i in range(m.depth)]
+        L.check(L.lib().rgbnm_reduce_hold_begin(), "reduce_hold_begin")
+        self.holding = True
+
+    def end_hold(self):
+        if self.holding:
+            self.holding = False
+            a = self.arena
+            L.check(L.lib().rgbnm_reduce_hold_end(a.hold_table.data_ptr(), a.hold_table.numel(), L.stream()), "reduce_hold_end")
+
+    def cancel_hold(self):
+        if self.holding:
+            self.holding = False
+            L.lib().rgbnm_reduce_hold_cancel()
 
     def __del__(self):
         try:
@@ -214,6 +246,7 @@ class _PatchEmbedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx0):
         st = ctx.st
+        st.end_hold()          # held reductions of the encoder blocks run now (before this node's own, and before the exchange)
         m, a = st.model, st.arena
         dx0 = dx0.contiguous()
         gw, gb = m._gview(st.gbuf, "patchembed.projection.0.weight"), m._gview(st.gbuf, "patchembed.projection.0.bias")
@@ -260,6 +293,7 @@ class _PatchEmbed2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx0):
         st = ctx.st
+        st.end_hold()          # held reductions of the encoder blocks run now (before this node's own, and before the exchange)
         m, a = st.model, st.arena
         lib, dt, M, E = L.lib(), a.cfg.dtype, a.cfg.B * a.cfg.N, a.cfg.E
         Ey = E // 6 * 4
@@ -318,6 +352,7 @@ class _PatchEmbedSepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx0):
         st = ctx.st
+        st.end_hold()          # held reductions of the encoder blocks run now (before this node's own, and before the exchange)
         m, a = st.model, st.arena
         lib, dt, M, E = L.lib(), a.cfg.dtype, a.cfg.B * a.cfg.N, a.cfg.E
         dx0 = dx0.contiguous()
@@ -378,6 +413,7 @@ class _PatchEmbedConcatFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx0):
         st = ctx.st
+        st.end_hold()          # held reductions of the encoder blocks run now (before this node's own, and before the exchange)
         m, a = st.model, st.arena
         lib, dt, E, B = L.lib(), a.cfg.dtype, a.cfg.E, a.cfg.B
         dxv = dx0.contiguous().view(B, 294, E)
@@ -420,9 +456,14 @@ class _BlockFn(torch.autograd.Function):
             dx = a.dx[(idx + 1) & 1]
         grads = [m._gview(st.gbuf, n) for n in m._block_names[idx]]
         g = L.BlockGrads(*[t.data_ptr() for t in grads])
-        L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
-                                            C.byref(g), C.byref(a.scratch), dy.data_ptr(), dx.data_ptr(),
-                                            L.stream()), "vit_block_bwd")
+        scratch = a.scratch_blk[idx] if st.holding else a.scratch
+        try:
+            L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
+                                                C.byref(g), C.byref(scratch), dy.data_ptr(), dx.data_ptr(),
+                                                L.stream()), "vit_block_bwd")
+        except BaseException:
+            st.cancel_hold()
+            raise
         if m._grad_sync is not None:            # this block's gradients are final: start their all-reduce now
             m._grad_sync.ready(st.gbuf, m._block_names[idx])
         # grads come back in BlockGrads field order; reorder to the order the params were passed in
@@ -455,13 +496,21 @@ class _HeadFn(torch.autograd.Function):
                                        a.ws.data_ptr(), a.ws_bytes, L.stream()), "head_bwd")
         if m._grad_sync is not None:
             m._grad_sync.ready(st.gbuf, names)
+        st.begin_hold()
         by_name = dict(zip(names, grads))
         return (dx, None) + tuple(by_name[n] for n in m._head_param_order)
 
 
 # ------------------------------------------------------------------ the model
 class ViT(FlatParamModule):
-    """Vision Transformer on DCT coefficients -- same ctor as the reference `ViT` (plainvit.py:559-599)."""
+    """Vision Transformer on DCT coefficients -- same ctor as the reference `ViT` (plainvit.py:559-599).
+
+    defer_grad_reduction (default False): when True the split-sum reductions of the encoder blocks' weight / LayerNorm
+    gradients are held during the backward pass and run as one launch in front of the patch embedding's backward (rgbnm.h,
+    rgbnm_reduce_hold_*): parameter gradients of the blocks are then final only when `backward()` returns.  Safe with no
+    gradient exchange or with FlatGradSync's single all-reduce after the backward; NOT with torch DDP or any hook that reads
+    `.grad` during the backward (leave it False there)."""
+    defer_grad_reduction = False
 
     def __init__(self, in_channels: int = 3, patch_size: int = 16, emb_size: int = 768, input_embed: int = -1,
                  depth: int = 12, n_classes: int = 1000, drop_p=0.1, pixel_space="RGB", ver=1, use_subblock=True,
