@@ -72,7 +72,7 @@ class FlatParamModule(nn.Module):
         """flat fp32 buffer the backward writes into; a fresh one if live .grad tensors still alias it (gradient
         accumulation across several backward passes must not be clobbered)."""
         base, end = self._gflat.data_ptr(), self._gflat.data_ptr() + self._gflat.numel() * 4
-        for p in self.parameters():
+        for p in self._named.values():                 # (the cached name -> parameter map: no module-tree walk per step)
             if p.grad is not None and base <= p.grad.data_ptr() < end:
                 return torch.zeros_like(self._gflat)
         return self._gflat

@@ -201,7 +201,10 @@ class _FwdState:
         gs = m._grad_sync
         if not m.defer_grad_reduction or (gs is not None and gs.bucket_elems < m._gflat.numel()):
             return                                     # somebody reads block gradients before the backward pass is over
-        if not all(p.requires_grad for n, p in m.named_parameters() if n.startswith("patchembed.")):
+        pe = m.__dict__.get("_pe_params")
+        if pe is None:
+            pe = m.__dict__["_pe_params"] = [p for n, p in m._named.items() if n.startswith("patchembed.")]
+        if not all(p.requires_grad for p in pe):
             return                                     # a frozen patch embedding has no backward node to close the bracket
         if a.ws_blk is None:                           # the partial sums of every block now live until the end of the pass
             a.ws_blk = torch.empty(m.depth * a.ws_bytes, device=a.ws.device, dtype=torch.uint8)
