@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-baseline-images", type=int, default=64)
     ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel HIP-event trace of the timed region")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B experiments)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step from the host (no HIP graph replay)")
     ap.add_argument("--no-defer-reduce", action="store_true",
                     help="run every block's gradient reductions inside its backward instead of one launch per step")
     ap.add_argument("--grad-sync", default="flat", choices=["flat", "ddp"],
@@ -294,6 +295,13 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    # Graph mode (one GPU, ViT): the whole run uses ONE non-default stream -- a HIP graph cannot be captured on the legacy
+    # default stream, and autograd ties every parameter's AccumulateGrad node to the stream of its first use: capturing on a
+    # side stream while the eager steps run on the default one costs ~150 cross-stream event waits per eager backward
+    work_stream = None
+    if world == 1 and a.arch != "swinv2t" and not a.no_graph:
+        work_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(work_stream)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" IS RCCL on ROCm; RGBNM_BENCH_BACKEND=gloo only for the 1-GPU smoke test above
@@ -381,17 +389,63 @@ def main():
         aug = CT.TrainTransform_DCT(size=S, out_dtype=cdt)
         sampler = CT.FastParamSampler(aug, seed=1234 + rank)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    def data_part(out=None):
         if a.no_augment:
             y, c = y_in, c_in
         else:
             packed, nops = sampler.sample(B, 64, 64)
             y, c = CT.apply_packed(aug, Yq, Cq, quant, packed, nops)
-        (my, mc), mt = mix((y, c), lab)
+        return mix((y, c), lab, out=out)
+
+    def model_part(my, mc, mt):
         logits = net(my, mc)
         loss = rg.cls_transforms.cross_entropy(logits, mt, grad_dtype=cdt)
         loss.backward()
+        return loss
+
+    # One GPU: mixup output -> model forward -> loss -> backward (~110 of the step's ~150 launches, ~2.5 ms of host time next to
+    # 5 ms of GPU time) is captured ONCE into a HIP graph and replayed; sampling, augment, mixup and the optimizer stay eager
+    # (their arguments change every step).  Same kernels, same order, same bits (checked below against an eager pass); what it
+    # buys is that a busy host cannot make the step launch-bound.  Steps whose kernels are bracketed with HIP events for the
+    # roofline figure run eagerly.  N > 1 (collectives, calibration) and SwinV2 stay eager.
+    graph = None
+    if work_stream is not None:
+        try:
+            sy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=cdt)
+            sc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=cdt)
+            smt = torch.empty(B, 1000, device=dev, dtype=torch.float32)
+            static = (sy, sc, smt)
+            data_part(out=static)
+            opt.zero_grad(set_to_none=True)
+            ref_loss = model_part(sy, sc, smt).detach().clone()
+            ref_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                model_part(sy, sc, smt)
+            opt.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=work_stream):      # the stream everything here runs on (see work_stream above)
+                gloss = model_part(sy, sc, smt)
+            g.replay()
+            torch.cuda.synchronize()
+            got_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+            if model.flat_grad_base() is None or not torch.equal(gloss.detach(), ref_loss) or not torch.equal(got_grad, ref_grad):
+                raise RuntimeError("graph replay does not reproduce the eager pass")
+            graph = (g, gloss, static)
+        except Exception as e:          # noqa: BLE001
+            print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step(eager=False):
+        if graph is not None and not eager:
+            data_part(out=graph[2])
+            graph[0].replay()
+            opt.step()
+            return graph[1]
+        opt.zero_grad(set_to_none=True)
+        (my, mc), mt = data_part()
+        loss = model_part(my, mc, mt)
         opt.step()
         return loss
 
@@ -435,7 +489,7 @@ def main():
     for i in range(a.warmup):
         if trace_on and i == 0:            # fill the library's event pool outside the timed region
             lib.rgbnm_set_option(b"trace", 1 << TAG_NT)
-        step()
+        step(eager=trace_on and i == 0)
         if trace_on and i == 0:
             lib.rgbnm_set_option(b"trace", 0)
             lib.rgbnm_trace_collect(TAG_NT, None, None, None, None)
@@ -449,7 +503,7 @@ def main():
         if tr:
             lib.rgbnm_set_option(b"trace", 1 << TAG_NT)
             traced_steps += 1
-        loss = step()
+        loss = step(eager=tr)
         if tr:
             lib.rgbnm_set_option(b"trace", 0)
     barrier()
@@ -499,7 +553,7 @@ def main():
                                    (NAMES[a.arch], a.dtype, B, CONFIG_OF[a.arch],
                                     "model-only on S-randn inputs" if a.no_augment else
                                     "HIP DCT-augment of S-coef 512x512 coefficient batches resident in HBM"),
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "grad_sync": grad_sync if sync_schedule is None else f"{grad_sync}: {sync_schedule}",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "HIP graph replay of mixup-out -> forward -> loss -> backward; data stage and optimizer eager" if graph is not None else "eager", "grad_sync": grad_sync if sync_schedule is None else f"{grad_sync}: {sync_schedule}",
                        "loss": round(float(loss.item()), 5)},
             "parity_mode": ("bf16 operands, fp32 accumulate: logits within 2.5e-2 of the fp32 reference (torch's own bf16 autocast of "
                             "the reference deviates 6e-3); the fp32 strict mode (--dtype fp32) carries the 1e-3 north-star "

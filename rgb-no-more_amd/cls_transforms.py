@@ -47,7 +47,9 @@ class RandomMixup_DCT(torch.nn.Module):
         st["ev"][i] = ev
         return st["dev"][i]
 
-    def forward(self, batch, target: Tensor, lam: Tensor = None) -> Tuple[Tensor, Tensor]:
+    def forward(self, batch, target: Tensor, lam: Tensor = None, out=None) -> Tuple[Tensor, Tensor]:
+        """out: optional (tensors for the mixed batch items ..., tensor for the mixed target) to write into (static buffers of a
+        captured HIP graph); default: fresh tensors."""
         if target.ndim != 1:
             raise ValueError(f"Target ndim should be 1. Got {target.ndim}")
         if target.dtype != torch.int64:
@@ -58,14 +60,18 @@ class RandomMixup_DCT(torch.nn.Module):
         if lam is None:
             lam = self.sample_lambda(target.device)
         outs = []
-        for t in items:
+        for k, t in enumerate(items):
             od = self.out_dtype or t.dtype
-            o = torch.empty(t.shape, device=t.device, dtype=od)
+            o = torch.empty(t.shape, device=t.device, dtype=od) if out is None else out[k]
+            if o.shape != t.shape or o.dtype != od or not o.is_contiguous():
+                raise ValueError("out tensors must match the batch items in shape and output dtype")
             B = t.shape[0]
             L.check(L.lib().rgbnm_mixup(L.dt_of(t.dtype), L.dt_of(od), t.data_ptr(), o.data_ptr(), lam.data_ptr(), B,
                                         t.numel() // B, L.stream()), "mixup")
             outs.append(o)
-        tgt = torch.empty(target.shape[0], self.num_classes, device=target.device, dtype=torch.float32)
+        tgt = torch.empty(target.shape[0], self.num_classes, device=target.device, dtype=torch.float32) if out is None else out[-1]
+        if tgt.shape != (target.shape[0], self.num_classes) or tgt.dtype != torch.float32 or not tgt.is_contiguous():
+            raise ValueError("the out tensor of the target must be float32 [B, num_classes]")
         L.check(L.lib().rgbnm_mixup_target(target.data_ptr(), tgt.data_ptr(), lam.data_ptr(), target.shape[0],
                                            self.num_classes, L.stream()), "mixup_target")
         return (outs[0] if single else tuple(outs)), tgt

@@ -748,7 +748,7 @@ class ViT(FlatParamModule):
             raise NotImplementedError(f"compute dtype {cdtype}: the MI355X path implements fp32 and bf16")
         self._ensure_flat()
         B = x.shape[0]
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._named.values())
         if need_grad and self._grad_sync is not None:
             self._grad_sync.begin_step()
         self._prep(cdtype)

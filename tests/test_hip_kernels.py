@@ -265,6 +265,13 @@ def test_mixup_golden(golden):
     np.testing.assert_allclose(my.cpu().numpy(), g["my"], atol=1e-6)
     np.testing.assert_allclose(mc.cpu().numpy(), g["mc"], atol=1e-6)
     np.testing.assert_allclose(mt.cpu().numpy(), g["mt"], atol=1e-6)
+    # out=: the same results written into caller-owned (static) buffers, as bench.py's HIP-graph mode needs them
+    oy, oc, ot = torch.empty_like(my), torch.empty_like(mc), torch.empty_like(mt)
+    (my2, mc2), mt2 = mix((dev(g["y"]), dev(g["c"])), torch.from_numpy(g["lab"]).to(DEV), lam=lam, out=(oy, oc, ot))
+    assert my2.data_ptr() == oy.data_ptr() and mt2.data_ptr() == ot.data_ptr()
+    assert torch.equal(oy, my) and torch.equal(oc, mc) and torch.equal(ot, mt)
+    with pytest.raises(ValueError):
+        mix((dev(g["y"]), dev(g["c"])), torch.from_numpy(g["lab"]).to(DEV), lam=lam, out=(oy, oc, ot[:, :5]))
     lam2 = mix.sample_lambda(DEV)
     assert lam2[0] >= lam2[1] and abs(lam2.sum().item() - 1) < 1e-5
     # the draw is the reference's own expression on the CPU generator (cls_transforms.py:168): same seed, same lambda --
