@@ -15,7 +15,7 @@ cat $OUT/bench_line.json
 BENCH="python bench.py --steps 24 --warmup 4 --prewarm-sec 1 --no-cpu-baseline --no-trace"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $BENCH > $OUT/kt.log 2>&1
 f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -25 $OUT/kernel_stats.csv
-PMCB="python bench.py --steps 3 --warmup 1 --prewarm-sec 0 --no-cpu-baseline --no-trace"
+PMCB="python bench.py --steps 3 --warmup 1 --prewarm-sec 0 --no-cpu-baseline --no-trace --no-graph"   # eager: the capture passes of graph mode would add model-only dispatches to the counters
 timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p --output-format csv -- $PMCB > $OUT/pmc_mfma.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- $PMCB > $OUT/pmc_write.log 2>&1
