@@ -299,7 +299,7 @@ def main():
     # default stream, and autograd ties every parameter's AccumulateGrad node to the stream of its first use: capturing on a
     # side stream while the eager steps run on the default one costs ~150 cross-stream event waits per eager backward
     work_stream = None
-    if world == 1 and a.arch != "swinv2t" and not a.no_graph:
+    if a.arch != "swinv2t" and not a.no_graph:
         work_stream = torch.cuda.Stream()
         torch.cuda.set_stream(work_stream)
     if world > 1:
@@ -409,7 +409,10 @@ def main():
     # buys is that a busy host cannot make the step launch-bound.  Steps whose kernels are bracketed with HIP events for the
     # roofline figure run eagerly.  N > 1 (collectives, calibration) and SwinV2 stay eager.
     graph = None
-    if work_stream is not None:
+    use_graph = world == 1          # N > 1: decided by the schedule calibration below (replay + ONE all-reduce after it)
+    fs_saved = model._grad_sync
+    if work_stream is not None and grad_sync in ("none", "flat"):
+        model._grad_sync = None     # the captured backward contains no collective: at N > 1 the exchange follows the replay
         try:
             sy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=cdt)
             sc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=cdt)
@@ -436,11 +439,27 @@ def main():
             print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+        model._grad_sync = fs_saved
+    if world > 1:                   # every rank must take the same path
+        gflag = torch.tensor([1 if graph is not None else 0], device=dev)
+        dist.all_reduce(gflag, op=dist.ReduceOp.MIN)
+        if gflag.item() == 0:
+            graph = None
+
+    def exchange_after_replay():
+        """N > 1 in graph mode: ONE all-reduce (average) of the flat gradient buffer the replayed backward has just written."""
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(model._gflat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(model._gflat, op=dist.ReduceOp.SUM)
+            model._gflat.mul_(1.0 / world)
 
     def step(eager=False):
-        if graph is not None and not eager:
+        if graph is not None and use_graph and not eager:
             data_part(out=graph[2])
             graph[0].replay()
+            if world > 1:
+                exchange_after_replay()
             opt.step()
             return graph[1]
         opt.zero_grad(set_to_none=True)
@@ -460,6 +479,7 @@ def main():
         step()
         torch.cuda.synchronize()
     sync_schedule = None
+    calib = None
     if world > 1 and grad_sync == "flat":
         # How to place the collectives is decided by measurement, on every rank alike, before the timed region: slices
         # all-reduced from inside the backward (overlapped) or ONE all-reduce of the flat buffer after it.  The compute
@@ -468,9 +488,28 @@ def main():
         # RCCL channel count and the link speed, i.e. on the node.
         fs = model._grad_sync
         best = None
-        for name, elems in (("overlapped 4 MB slices", (4 << 20) // 4), ("overlapped 16 MB slices", (16 << 20) // 4),
-                            ("one all-reduce after the backward", 1 << 60)):
+        calib = {}
+        cands = [("overlapped 4 MB slices", (4 << 20) // 4, False), ("overlapped 16 MB slices", (16 << 20) // 4, False),
+                 ("one all-reduce after the backward", 1 << 60, False)]
+        if graph is not None:
+            # the replayed backward + one explicit all-reduce must give the gradients of the eager step with the same inputs
+            fs.bucket_elems = 1 << 60
+            opt.zero_grad(set_to_none=True)
+            model_part(*graph[2])
+            torch.cuda.synchronize()
+            g_eager = model._gflat.clone()
+            graph[0].replay()
+            exchange_after_replay()
+            torch.cuda.synchronize()
+            err = (model._gflat - g_eager).abs().max().item()
+            okf = torch.tensor([1 if (model.flat_grad_base() is not None and err <= 1e-4 * g_eager.abs().max().item() + 1e-8) else 0],
+                               device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if okf.item() == 1:
+                cands.append(("HIP graph replay, then one all-reduce", 1 << 60, True))
+        for name, elems, ug in cands:
             fs.bucket_elems = elems
+            use_graph = ug
             for _ in range(2):
                 step()
             barrier()
@@ -480,9 +519,11 @@ def main():
             barrier()
             tt = torch.tensor([time.perf_counter() - tc], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            calib[name] = round(tt.item() / 6 * 1e3, 3)
             if best is None or tt.item() < best[0]:
-                best = (tt.item(), name, elems)
+                best = (tt.item(), name, elems, ug)
         fs.bucket_elems = best[2]
+        use_graph = best[3]
         sync_schedule = best[1]
     TAG_NT = 1
     trace_on = (not a.no_trace) and rank == 0
@@ -553,7 +594,7 @@ def main():
                                    (NAMES[a.arch], a.dtype, B, CONFIG_OF[a.arch],
                                     "model-only on S-randn inputs" if a.no_augment else
                                     "HIP DCT-augment of S-coef 512x512 coefficient batches resident in HBM"),
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "HIP graph replay of mixup-out -> forward -> loss -> backward; data stage and optimizer eager" if graph is not None else "eager", "grad_sync": grad_sync if sync_schedule is None else f"{grad_sync}: {sync_schedule}",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "HIP graph replay of mixup-out -> forward -> loss -> backward; data stage and optimizer eager" if (graph is not None and use_graph) else "eager", "grad_sync": grad_sync if sync_schedule is None else f"{grad_sync}: {sync_schedule}", "grad_sync_calibration_ms_per_step": calib,
                        "loss": round(float(loss.item()), 5)},
             "parity_mode": ("bf16 operands, fp32 accumulate: logits within 2.5e-2 of the fp32 reference (torch's own bf16 autocast of "
                             "the reference deviates 6e-3); the fp32 strict mode (--dtype fp32) carries the 1e-3 north-star "
