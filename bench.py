@@ -204,42 +204,68 @@ def cpu_baseline(arch, n_images, batch=8):
                       f"(inputs are coefficients, as on the GPU side)"}
 
 
+BF16_LOGIT_TOL = 1e-2      # bf16 operands / fp32 accumulate vs the fp32 reference (tests/test_fastpath_model.py uses the same bar)
+
+
 def parity_check(arch, cdt, dev):
     """The exact kernel mix of the timed step against the reference: a second model instance with the deterministic detfill
     weights on detfill inputs at the fast-path batch sizes, compared with golden vectors captured from the reference model
-    itself (tests/golden/g17_fastpath.npz, make_golden_r2.py).  Data only -- nothing of oracle/ is imported here."""
+    itself -- EVERY logit (tests/golden/g20_fullsize.npz, make_golden_r3.py: JPEG-Ti B = 256 depth 12 = the bench
+    configuration, JPEG-S B = 64 depth 12, SwinV2-T B = 64).  Data only -- nothing of oracle/ is imported here."""
     import numpy as np
     import torch
     import rgb_no_more_amd as rg
     from rgb_no_more_amd import detfill
-    case = {("vitti", torch.bfloat16): ("ti_d12_b256", 192, 3, 12, 256, True), ("vitti", torch.float32): ("ti_d12_b64", 192, 3, 12, 64, False),
-            ("vits", torch.bfloat16): ("s_d2_b64", 384, 6, 2, 64, False), ("vits", torch.float32): ("s_d2_b64", 384, 6, 2, 64, False)}.get((arch, cdt))
-    path = os.path.join(ROOT, "tests", "golden", "g17_fastpath.npz")
-    if case is None or not os.path.exists(path):
+    path = os.path.join(ROOT, "tests", "golden", "g20_fullsize.npz")
+    if not os.path.exists(path):
         return None
-    tag, emb, heads, depth, B, hard = case
     g = np.load(path)
-    m = rg.ViT(3, 16, emb, depth=depth, n_classes=1000, drop_p=0.0, device=dev, num_heads=heads, head_size=64,
-               pixel_space="DCT", ver=1, use_subblock=True)
-    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in detfill.fill_state_dict(shapes, base_seed=1).items()})
-    m.compute_dtype = cdt
-    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(dev)
-    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(dev)
+    bf16 = cdt == torch.bfloat16
+    if arch == "swinv2t":
+        tag, B, hard = "swt_b64", 64, False
+        depths, sheads = [2, 2, 6, 2], [3, 6, 12, 24]
+        m = rg.SwinTransformerV2(img_size=256, patch_size=4, embed_dim=96, depths=depths, num_heads=sheads, window_size=8,
+                                 mlp_ratio=4.0, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, qkv_bias=True, ape=False,
+                                 patch_norm=True, pretrained_window_sizes=[0] * 4, device=dev, pixel_space="dct")
+        # the reference test vectors' parameter fill (a data generator shared with the golden script, not oracle code)
+        names = [str(n) for n in g[tag + "_names"]]
+        shapes = {n: tuple(p.shape) for n, p in m.named_parameters()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in detfill.fill_swin_params({n: shapes[n] for n in names}).items()},
+                          strict=False)
+        y = torch.from_numpy(detfill.normalish((B, 1, 32, 32, 8, 8), 171)).to(dev)
+        c = torch.from_numpy(detfill.normalish((B, 2, 16, 16, 8, 8), 172)).to(dev)
+        t = detfill.uniform((B, 1000), 173, 0.0, 1.0)
+        tol = 6e-2 if bf16 else 1e-3                     # cosine attention with logit scales up to 30 (tests/test_swin.py)
+        desc = f"reference SwinV2-T DCT, detfill weights, B={B}, drop_path 0"
+    else:
+        tag, emb, heads, depth, B, hard = {"vitti": ("ti_d12_b256", 192, 3, 12, 256, True),
+                                           "vits": ("s_d12_b64", 384, 6, 12, 64, False)}[arch]
+        m = rg.ViT(3, 16, emb, depth=depth, n_classes=1000, drop_p=0.0, device=dev, num_heads=heads, head_size=64,
+                   pixel_space="DCT", ver=1, use_subblock=True)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in detfill.fill_state_dict(shapes, base_seed=1).items()})
+        y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(dev)
+        c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(dev)
+        t = detfill.uniform((B, 1000), 73, 0.0, 1.0)
+        tol = BF16_LOGIT_TOL if bf16 else 1e-3
+        desc = f"reference ViT, detfill weights, B={B}, depth {depth}"
+    if tag + "_logits" not in g.files:
+        return None
     if hard:
         tgt = torch.from_numpy(detfill.integers((B,), 74, 0, 998, np.int64)).to(dev)
     else:
-        t = detfill.uniform((B, 1000), 73, 0.0, 1.0)
         tgt = torch.from_numpy(t / t.sum(1, keepdims=True)).to(dev)
+    m.compute_dtype = cdt
     m.train()
     logits = m(y, c)
     loss = rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=cdt)
     loss.backward()
     gn = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
     rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
-    err = float(np.abs(logits.detach().float().cpu().numpy()[:, ::8] - g[tag + "_logits"]).max())
-    tol = 2.5e-2 if cdt == torch.bfloat16 else 1e-3
-    out = {"golden": f"tests/golden/g17_fastpath.npz:{tag} (reference ViT, detfill weights, B={B}, depth {depth})",
+    ref = g[tag + "_logits"]
+    got = logits.detach().float().cpu().numpy()
+    err = float(np.abs(got - ref).max()) if got.shape == ref.shape else float("inf")
+    out = {"golden": f"tests/golden/g20_fullsize.npz:{tag} ({desc}; all {ref.shape[0]} x {ref.shape[1]} logits)",
            "max_abs_dlogit": round(err, 6), "tol": tol, "loss": round(float(loss.item()), 6),
            "loss_reference": round(float(g[tag + "_loss"]), 6), "gradnorm_rel_err_median": round(float(np.median(rel)), 6),
            "ok": bool(err <= tol and abs(float(loss.item()) - float(g[tag + "_loss"])) < 5e-3 and np.median(rel) < 2e-2)}
@@ -596,7 +622,7 @@ def main():
                                     "HIP DCT-augment of S-coef 512x512 coefficient batches resident in HBM"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "HIP graph replay of mixup-out -> forward -> loss -> backward; data stage and optimizer eager" if (graph is not None and use_graph) else "eager", "grad_sync": grad_sync if sync_schedule is None else f"{grad_sync}: {sync_schedule}", "grad_sync_calibration_ms_per_step": calib,
                        "loss": round(float(loss.item()), 5)},
-            "parity_mode": ("bf16 operands, fp32 accumulate: logits within 2.5e-2 of the fp32 reference (torch's own bf16 autocast of "
+            "parity_mode": ("bf16 operands, fp32 accumulate: every logit within 1e-2 of the fp32 reference (torch's own bf16 autocast of "
                             "the reference deviates 6e-3); the fp32 strict mode (--dtype fp32) carries the 1e-3 north-star "
                             "tolerance (tests/test_fastpath_model.py)") if a.dtype == "bf16" else "fp32 strict mode: logits within 1e-3 of the reference",
             "parity_check": pcheck,

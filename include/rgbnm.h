@@ -273,13 +273,17 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, c
  * sums (reference: autograd accumulates straight into .grad, models/plainvit.py runs under torch.autograd).  A caller that
  * reads no gradient before the END of the backward pass -- one GPU, or one all-reduce after the pass -- may bracket the pass:
  *   rgbnm_reduce_hold_begin();  ... backward calls, each with ITS OWN workspace region ...
- *   rgbnm_reduce_hold_end(table, rgbnm_reduce_hold_table_bytes(), stream);
+ *   rgbnm_reduce_hold_end(table, table_host, rgbnm_reduce_hold_table_bytes(), stream);
  * and all reductions issued in between (on this host thread) run as ONE launch at _end, with the same summation order (same
- * bits).  `table` is a device buffer of the caller that must stay untouched between steps (the job table is re-uploaded only
- * when it changed).  The partial sums live in the workspaces until _end: regions must not be shared between the calls of one
- * bracket.  rgbnm_reduce_hold_cancel() leaves the mode without running anything (error paths). */
+ * bits).  `table` is a device buffer and `table_host` a HOST buffer of the same size, both owned by the caller, allocated
+ * together (table_host zero-filled) and freed together, untouched between steps: table_host records what the device table
+ * holds, and the job table is uploaded only when it differs from that record (so a graph capture of a steady-state pass
+ * contains no copy; a pass whose table changed returns RGBNM_EINVAL when the stream is capturing).  The partial sums live in
+ * the workspaces until _end: regions must not be shared between the calls of one bracket.  One bracket per host thread:
+ * _begin inside an open bracket returns RGBNM_EINVAL.  rgbnm_reduce_hold_cancel() leaves the mode without running anything
+ * (error paths). */
 int rgbnm_reduce_hold_begin(void);
-int rgbnm_reduce_hold_end(void* table, size_t table_bytes, void* stream);
+int rgbnm_reduce_hold_end(void* table, void* table_host, size_t table_bytes, void* stream);
 void rgbnm_reduce_hold_cancel(void);
 size_t rgbnm_reduce_hold_table_bytes(void);
 

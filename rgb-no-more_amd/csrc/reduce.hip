@@ -77,8 +77,6 @@ struct HeldTable {
 };
 thread_local bool g_hold = false;
 thread_local HeldTable g_held;                 // being collected
-thread_local HeldTable g_uploaded;             // what the device buffer holds
-thread_local const void* g_uploaded_to = nullptr;
 
 // VEC = 4: an element slot is four consecutive elements moved as one 16-byte load per partial slice (the held pass reads
 // partials that have long left the caches: wide loads are what an HBM-bound pass wants); same partial -> group assignment and
@@ -193,6 +191,7 @@ int rgbnm_reduce_submit(const RgbnmReduceJob& job, hipStream_t st) {
 extern "C" {
 
 int rgbnm_reduce_hold_begin(void) {
+  if (g_hold) return RGBNM_EINVAL;              // one bracket per host thread: a second begin would drop the jobs collected so far
   g_hold = true;
   g_held.njobs = 0;
   return RGBNM_OK;
@@ -203,12 +202,12 @@ void rgbnm_reduce_hold_cancel(void) {
   g_held.njobs = 0;
 }
 
-int rgbnm_reduce_hold_end(void* table_dev, size_t table_bytes, void* stream) {
+int rgbnm_reduce_hold_end(void* table_dev, void* table_host, size_t table_bytes, void* stream) {
   if (!g_hold) return RGBNM_OK;
   g_hold = false;
   const int n = g_held.njobs;
   if (n == 0) return RGBNM_OK;
-  if (!table_dev || table_bytes < sizeof(HeldTable)) return RGBNM_EWORKSPACE;
+  if (!table_dev || !table_host || table_bytes < sizeof(HeldTable)) return RGBNM_EWORKSPACE;
   int total = 0;
   for (int k = 0; k < n; ++k) {
     const RgbnmReduceJob& j = g_held.j[k];
@@ -222,11 +221,21 @@ int rgbnm_reduce_hold_end(void* table_dev, size_t table_bytes, void* stream) {
   g_held.total = total;
   hipStream_t st = (hipStream_t)stream;
   const size_t used = offsetof(HeldTable, j) + sizeof(RgbnmReduceJob) * (size_t)n;
-  if (g_uploaded_to != table_dev || memcmp(&g_uploaded, &g_held, used) != 0) {
+  // What the device table holds is recorded in `table_host`, a host buffer the caller allocates (zeroed) TOGETHER with the
+  // device table and frees with it: a device address handed out again by the allocator after its owner died comes with a fresh,
+  // zeroed record and is uploaded again, whichever host thread gets here.
+  if (memcmp(table_host, &g_held, used) != 0) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      g_held.njobs = 0;
+      return RGBNM_EINVAL;                       // a changed table cannot be uploaded from inside a graph capture: run one eager pass first
+    }
     // pageable source: the runtime stages it before returning, so g_held may be reused at once; stream-ordered on st
-    if (hipMemcpyAsync(table_dev, &g_held, used, hipMemcpyHostToDevice, st) != hipSuccess) return RGBNM_ELAUNCH;
-    memcpy(&g_uploaded, &g_held, used);
-    g_uploaded_to = table_dev;
+    if (hipMemcpyAsync(table_dev, &g_held, used, hipMemcpyHostToDevice, st) != hipSuccess) {
+      g_held.njobs = 0;
+      return RGBNM_ELAUNCH;
+    }
+    memcpy(table_host, &g_held, used);
   }
   g_held.njobs = 0;
   hipLaunchKernelGGL(reduce_table_kernel, dim3(total), dim3(256), 0, st, (const HeldTable*)table_dev);

@@ -388,6 +388,12 @@ class RandomFlip_DCT(torch.nn.Module):
         return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * B, flips, None, 0, torch.int16), single, batched)
 
 
+# ops_list=None: the reference's own default (custom_transforms.py:1060-1062) minus the DFT-domain Rotate / ShearX / ShearY, which
+# are not built; the fused transform and datasets.get_transform(fused=...) use the same list
+DEFAULT_OPS = ("AutoContrast", "Equalize", "Invert", "Posterize", "Solarize", "SolarizeAdd", "Color", "Contrast",
+               "Brightness", "Sharpness", "Cutout", "TranslateX", "TranslateY")
+
+
 class RandAugment_dct(torch.nn.Module):
     """custom_transforms.py:1024-1138: clamp, then num_ops operations drawn from ops_list at magnitude bin `magnitude`
     (random sign for the signed ones; chroma / grayscale mutual exclusion), clamp after every op."""
@@ -397,9 +403,8 @@ class RandAugment_dct(torch.nn.Module):
         if num_ops > 2:
             raise NotImplementedError("the HIP kernel chains up to two operations per sample (cfg.TRAIN.NUMOPS default 2)")
         self.num_ops, self.magnitude, self.num_magnitude_bins, self.pad = num_ops, magnitude, num_magnitude_bins, pad
-        if ops_list is None:   # the reference's default list holds the DFT-domain Rotate / ShearX / ShearY (not built)
-            ops_list = ["AutoContrast", "Equalize", "Invert", "Posterize", "Solarize", "SolarizeAdd", "Color", "Contrast",
-                        "Brightness", "Sharpness", "Cutout", "TranslateX", "TranslateY"]
+        if ops_list is None:
+            ops_list = DEFAULT_OPS
         bad = [o for o in ops_list if o not in OPS]
         if bad:
             raise NotImplementedError(f"operations {bad} are not implemented on the HIP path")

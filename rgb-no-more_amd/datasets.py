@@ -20,6 +20,8 @@ def get_transform(dataset="imagenet_dct", type="train", ops_list=None, num_ops=2
         raise NotImplementedError("rgb-no-more_amd implements the --domain DCT datasets ('imagenet_dct', 'imagenet_dct_swin')")
     size = 28 if dataset == "imagenet_dct" else 32
     if type == "train":
+        if ops_list is None:          # one default for both forms (the fused class alone defaults to the JPEG-Ti config's list)
+            ops_list = ctrans.DEFAULT_OPS
         if fused:
             return ctrans.TrainTransform_DCT(size=size, num_ops=num_ops, magnitude=ops_magnitude, num_magnitude_bins=11,
                                              ops_list=ops_list, out_dtype=dtype)

@@ -67,3 +67,16 @@ def fill_state_dict(shapes: dict, base_seed=0):
             a = 1.0 / np.sqrt(float(fan))
             out[name] = uniform(shp, sd, -a, a)
     return out
+
+
+def fill_swin_params(shapes: dict, base_seed=3):
+    """Deterministic SwinV2 test weights for goldens, parity tests and bench.py's parity check: the Linear-like fill above,
+    LayerNorm scales 1 + U(-a, a) (so the post-norm branches are O(1), not O(0.1)), logit_scale = ln 10 + U(-.5a, .5a)
+    (the trained range)."""
+    sd = fill_state_dict(shapes, base_seed=base_seed)
+    for n in shapes:
+        if n.endswith("logit_scale"):
+            sd[n] = (np.log(10.0) + 0.5 * sd[n]).astype(np.float32)
+        elif "norm" in n and n.endswith(".weight"):
+            sd[n] = (1.0 + sd[n]).astype(np.float32)
+    return sd

@@ -90,7 +90,7 @@ PROTOTYPES = {
     "rgbnm_vit_workspace": (_sz, [_P(VitCfg)]),
     "rgbnm_vit_workspace_ex": (_sz, [_P(VitCfg), _i]),
     "rgbnm_reduce_hold_begin": (_i, []),
-    "rgbnm_reduce_hold_end": (_i, [_vp, _sz, _vp]),
+    "rgbnm_reduce_hold_end": (_i, [_vp, _vp, _sz, _vp]),
     "rgbnm_reduce_hold_cancel": (None, []),
     "rgbnm_reduce_hold_table_bytes": (_sz, []),
     "rgbnm_vit_block_fwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _vp]),

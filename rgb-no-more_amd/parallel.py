@@ -18,7 +18,8 @@ stream wait for every outstanding collective, so once `backward()` has returned 
 The overlap is untouched (nothing but the optimizer runs after the last node).  Not supported, and refused loudly:
 gradient accumulation over several backward passes (the second pass writes a fresh buffer that autograd accumulates
 into .grad while a collective would still own it) -- use torch DDP for that.  A backward that died half-way leaves
-collectives in flight; they are drained at the next forward (`begin_step`).
+collectives in flight; they are drained at the next forward (`begin_step`).  A frozen patch embedding (no last node) is
+refused at the forward.
 """
 import torch
 import torch.distributed as dist
@@ -44,6 +45,12 @@ class FlatGradSync:
     def begin_step(self):
         """Called by the model at the start of a forward that will be differentiated: nothing of an earlier backward
         may still be in flight when its kernels start rewriting the flat gradient buffer."""
+        m = self.module
+        if not all(m._named[n].requires_grad for n in getattr(m, "_pe_names", ())):
+            # the patch embedding's backward node is the one that flushes the last slice and orders the collectives before
+            # backward() returns; with frozen patch-embedding parameters that node does not exist
+            raise RuntimeError("FlatGradSync needs trainable patch-embedding parameters (its backward node closes the "
+                               "exchange); for a frozen patch embedding use torch DDP")
         if self._handles or self._pending is not None:
             self._pending = None
             for h, _seg in self._handles:

@@ -13,6 +13,7 @@ There is no fallback path: without librgbnm.so / a HIP device `forward` raises.
 """
 import ctypes as C
 import math
+import threading
 import warnings
 from collections import OrderedDict
 
@@ -171,7 +172,7 @@ class _Arena:
             self.scratch = L.BlockScratch(self.du.data_ptr(), self.dxn.data_ptr(), self.dx_mid.data_ptr(),
                                           self.dattn.data_ptr(), self.dqkv.data_ptr(), self.ws.data_ptr(), ws_bytes)
         self.ws_bytes = ws_bytes
-        self.ws_blk = self.hold_table = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
+        self.ws_blk = self.hold_table = self.hold_table_host = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
         self.acts = []
         for i in range(D):
             b = self.blk[i if need_grad else 0]
@@ -184,6 +185,9 @@ class _Arena:
 
     def xbuf(self, i):
         return self.x[i] if self.need_grad else self.x[i & 1]
+
+
+_HOLDER = threading.local()     # .st = the _FwdState whose held-reduction bracket is open on this (autograd) thread
 
 
 class _FwdState:
@@ -209,21 +213,36 @@ class _FwdState:
         if a.ws_blk is None:                           # the partial sums of every block now live until the end of the pass
             a.ws_blk = torch.empty(m.depth * a.ws_bytes, device=a.ws.device, dtype=torch.uint8)
             a.hold_table = torch.zeros(L.lib().rgbnm_reduce_hold_table_bytes(), device=a.ws.device, dtype=torch.uint8)
+            # host record of what hold_table holds: allocated and freed WITH it (rgbnm.h), so a recycled device address
+            # never inherits somebody else's "already uploaded"
+            a.hold_table_host = torch.zeros(a.hold_table.numel(), dtype=torch.uint8)
             a.scratch_blk = [L.BlockScratch(a.du.data_ptr(), a.dxn.data_ptr(), a.dx_mid.data_ptr(), a.dattn.data_ptr(),
                                             a.dqkv.data_ptr(), a.ws_blk.data_ptr() + i * a.ws_bytes, a.ws_bytes)
                              for i in range(m.depth)]
-        L.check(L.lib().rgbnm_reduce_hold_begin(), "reduce_hold_begin")
+        # one bracket per host thread (the library's queue is thread-local): a second forward state in the same backward pass
+        # (two models, or one model applied twice) closes the bracket that is open -- its held reductions run now, its remaining
+        # blocks reduce the ordinary way -- before it opens its own
+        other = getattr(_HOLDER, "st", None)
+        if other is not None and other is not self:
+            other.end_hold()
+        if L.lib().rgbnm_reduce_hold_begin() != 0:     # a bracket left open by a backward pass that died on this thread
+            L.lib().rgbnm_reduce_hold_cancel()
+            L.check(L.lib().rgbnm_reduce_hold_begin(), "reduce_hold_begin")
         self.holding = True
+        _HOLDER.st = self
 
     def end_hold(self):
         if self.holding:
             self.holding = False
+            _HOLDER.st = None
             a = self.arena
-            L.check(L.lib().rgbnm_reduce_hold_end(a.hold_table.data_ptr(), a.hold_table.numel(), L.stream()), "reduce_hold_end")
+            L.check(L.lib().rgbnm_reduce_hold_end(a.hold_table.data_ptr(), a.hold_table_host.data_ptr(), a.hold_table.numel(),
+                                                  L.stream()), "reduce_hold_end")
 
     def cancel_hold(self):
         if self.holding:
             self.holding = False
+            _HOLDER.st = None
             L.lib().rgbnm_reduce_hold_cancel()
 
     def __del__(self):
@@ -464,11 +483,11 @@ class _BlockFn(torch.autograd.Function):
             L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
                                                 C.byref(g), C.byref(scratch), dy.data_ptr(), dx.data_ptr(),
                                                 L.stream()), "vit_block_bwd")
+            if m._grad_sync is not None:        # this block's gradients are final: start their all-reduce now
+                m._grad_sync.ready(st.gbuf, m._block_names[idx])
         except BaseException:
-            st.cancel_hold()
+            st.cancel_hold()                    # never leave the autograd thread's bracket open behind an exception
             raise
-        if m._grad_sync is not None:            # this block's gradients are final: start their all-reduce now
-            m._grad_sync.ready(st.gbuf, m._block_names[idx])
         # grads come back in BlockGrads field order; reorder to the order the params were passed in
         by_name = dict(zip(m._block_names[idx], grads))
         return (dx, None, None) + tuple(by_name[n] for n in m._block_param_order[idx])

@@ -1,0 +1,61 @@
+"""The N > 1 code path of bench.py -- the one the driver's 2/4/8-GPU scaling run executes -- run for real with two ranks.
+
+A GPU lease has ONE MI355X, so both ranks share it (RGBNM_BENCH_SAME_DEVICE=1) and talk over gloo
+(RGBNM_BENCH_BACKEND=gloo); on the 8-GPU node the same code runs one rank per GPU over RCCL.  No scaling number is
+asked of this test: the point is that process-group set-up, the FlatGradSync self-check, the HIP-graph capture with the
+exchange after the replay, the schedule calibration (four candidates), the max-over-ranks timing and the JSON line all
+execute.  Reference loop: train.py:137 (DDP wrap), :145-176 (step)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(extra, timeout=900):
+    env = dict(os.environ, RGBNM_BENCH_SAME_DEVICE="1", RGBNM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--prewarm-sec", "0.2", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])       # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_flat_exchange_with_calibration():
+    d = _run([])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
+    cfg = d["config"]
+    assert cfg["global_batch"] == 2 * cfg["per_gpu_batch"] == 512 and cfg["parallelism"] == "dp2"
+    assert cfg["grad_sync"].startswith("flat"), cfg["grad_sync"]        # the self-check passed: no fallback to torch DDP
+    cal = cfg["grad_sync_calibration_ms_per_step"]
+    assert len(cal) == 4 and all(v > 0 for v in cal.values()), cal     # incl. "HIP graph replay, then one all-reduce"
+    assert cfg["grad_sync"].split(": ", 1)[1] in cal
+    assert d["parity_check"]["ok"] is True
+    assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] / 1e3)) < 0.01 * d["value"]
+    loss = cfg["loss"]
+    assert loss == loss and 0 < loss < 20
+
+
+def test_bench_two_ranks_torch_ddp_path():
+    d = _run(["--grad-sync", "ddp", "--no-parity-check", "--no-trace"])
+    assert d["n_gpus"] == 2 and d["config"]["grad_sync"] == "ddp"
+    assert d["config"]["launch"] == "eager"
+    loss = d["config"]["loss"]
+    assert loss == loss and 0 < loss < 20

@@ -6,8 +6,10 @@ GEMM with fused residual+LayerNorm forward and LayerNorm-backward epilogues (`ge
 persistent DMA-wave attention and the grouped weight-gradient launch.  Reference values: golden g17 (the reference ViT
 itself on detfill weights, tests/golden/make_golden_r2.py) and, for full tensors, the torch fp32 oracle run live.
 
-Tolerances: fp32 mode <= 1e-3 on logits (north_star), gradient norms rtol 1e-3; bf16 mode <= 2.5e-2 on logits and
-<= 2x the error of torch's own bf16 autocast of the oracle, gradient norms median 2e-2 (see tests/test_vit_model.py).
+Tolerances: fp32 mode <= 1e-3 on logits (north_star), gradient norms rtol 1e-3; bf16 mode <= 1e-2 on logits (measured
+4.4e-3 at B = 256 depth 12; torch's own bf16 autocast of the reference: 5.7e-3) and <= 2x the error of torch's own bf16
+autocast of the oracle, gradient norms median 2e-2 (see tests/test_vit_model.py).  Golden g20 (make_golden_r3.py) holds
+EVERY logit of the bench configuration (B = 256, depth 12) and of JPEG-S at depth 12.
 """
 import ctypes as C
 
@@ -24,7 +26,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 CASES = {"ti_d2_b64": (192, 3, 2, 64, False), "ti_d12_b64": (192, 3, 12, 64, False), "s_d2_b64": (384, 6, 2, 64, False),
-         "ti_d12_b256": (192, 3, 12, 256, True)}
+         "ti_d12_b256": (192, 3, 12, 256, True), "s_d12_b64": (384, 6, 12, 64, False)}
+BF16_LOGIT_TOL = 1e-2        # bf16 operands, fp32 accumulate, vs the fp32 reference (bench.py's parity_check uses the same bar)
 FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe", "mlp_fuse", "mlp_bwd")
 
 
@@ -97,7 +100,7 @@ def test_bf16_fast_path_vs_reference_golden(golden, tag):
     rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
     print(f"[{tag}] bf16 fast path: max |dlogit| = {err:.3e}, loss {loss:.5f} vs {float(g[tag + '_loss']):.5f}, "
           f"grad-norm rel err median {np.median(rel):.3e} max {rel.max():.3e}")
-    assert err <= 2.5e-2
+    assert err <= BF16_LOGIT_TOL
     assert abs(loss - float(g[tag + "_loss"])) < 5e-3
     assert np.median(rel) < 2e-2 and rel.max() < 0.15
     named = dict(m.named_parameters())
@@ -106,6 +109,40 @@ def test_bf16_fast_path_vs_reference_golden(golden, tag):
         want = g[tag + "_grad_" + nm].astype(np.float64)
         cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
         assert cos > 0.995, (nm, cos)
+
+
+@pytest.mark.parametrize("tag,compute", [("ti_d12_b256", torch.bfloat16), ("ti_d12_b256", torch.float32),
+                                         ("s_d12_b64", torch.bfloat16), ("s_d12_b64", torch.float32)])
+def test_every_logit_at_full_size_vs_reference_golden(golden, tag, compute):
+    """g20 (make_golden_r3.py): ALL [B, 1000] logits of the reference at the bench configuration (JPEG-Ti, B = 256, depth 12)
+    and of JPEG-S at full depth, in both compute modes; gradient norms of every parameter and strided gradient slices."""
+    g = golden("g20_fullsize.npz")
+    m, sd, y, c, tgt = build(tag, compute)
+    logits, loss, gn = run(m, y, c, tgt, compute)
+    ref = g[tag + "_logits"]
+    assert ref.shape == logits.shape == (CASES[tag][3], 1000)
+    err = np.abs(logits - ref).max()
+    rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    print(f"[{tag} {compute}] all logits: max |dlogit| = {err:.3e} (mean {np.abs(logits - ref).mean():.3e}), loss {loss:.6f} "
+          f"vs {float(g[tag + '_loss']):.6f}, grad-norm rel err median {np.median(rel):.3e} max {rel.max():.3e}")
+    depth = CASES[tag][2]
+    named = dict(m.named_parameters())
+    slices = ("encoder.0.0.fn.eb_mha.qkv.weight", f"encoder.{depth - 1}.1.fn.eb_ffb.0.weight", "patchembed.projection.0.weight")
+    if compute == torch.float32:
+        assert err <= 1e-4                                   # north_star bar: 1e-3
+        assert abs(loss - float(g[tag + "_loss"])) < 2e-5
+        np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=1e-3, atol=1e-7)
+        for nm in slices:
+            np.testing.assert_allclose(named[nm].grad.reshape(-1)[::37].cpu().numpy(), g[tag + "_grad_" + nm], rtol=2e-3,
+                                       atol=3e-7, err_msg=nm)
+    else:
+        assert err <= BF16_LOGIT_TOL
+        assert abs(loss - float(g[tag + "_loss"])) < 5e-3
+        assert np.median(rel) < 2e-2 and rel.max() < 0.15
+        for nm in slices:
+            got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
+            want = g[tag + "_grad_" + nm].astype(np.float64)
+            assert float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30)) > 0.995, nm
 
 
 def test_bf16_fast_path_vs_live_oracle_and_generic_kernels():
@@ -126,7 +163,7 @@ def test_bf16_fast_path_vs_live_oracle_and_generic_kernels():
     err = np.abs(logits - ref.detach().numpy()).max()
     err_autocast = np.abs(lo.numpy() - ref.detach().numpy()).max()
     print(f"bf16 fast path vs oracle: max |dlogit| {err:.3e} (torch bf16 autocast of the oracle: {err_autocast:.3e})")
-    assert err <= 2.5e-2 and err <= 2.0 * err_autocast + 2e-3
+    assert err <= BF16_LOGIT_TOL and err <= 2.0 * err_autocast + 2e-3
     worst = 0.0
     for n, gfast in grads_fast.items():
         want = p[n].grad

@@ -54,3 +54,65 @@ def test_not_held_when_something_reads_block_gradients_early():
     torch.cuda.synchronize()
     assert st.holding is False and st.arena.ws_blk is None
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_rebuilt_model_uploads_its_own_job_table():
+    """A model (and its arena) that dies hands its device addresses back to the caching allocator; the next model can get the
+    same addresses for its gradient buffer, workspaces and job table.  The table must be uploaded again (the record of what a
+    device table holds lives and dies with that table), not skipped because pointer and jobs look familiar."""
+    import gc
+    import test_fastpath_model as T
+    for rep in range(3):
+        m, sd, y, c, tgt = T.build("ti_d2_b64", torch.bfloat16)
+        m.train()
+        base, lb = _grads(m, y, c, tgt, torch.bfloat16)
+        m.defer_grad_reduction = True
+        held, lh = _grads(m, y, c, tgt, torch.bfloat16)
+        held2, _ = _grads(m, y, c, tgt, torch.bfloat16)
+        for n in base:
+            assert torch.equal(base[n], held[n]) and torch.equal(base[n], held2[n]), (n, rep)
+        del m, base, held, held2
+        gc.collect()                                        # no empty_cache(): the next build recycles the freed blocks
+
+
+def test_two_holding_models_in_one_backward_pass():
+    """One bracket per host thread: the second model's head closes the first model's bracket (its held jobs run, its remaining
+    blocks reduce at once) instead of dropping the jobs collected so far."""
+    import test_fastpath_model as T
+    m1, _, y, c, tgt = T.build("ti_d2_b64", torch.bfloat16)
+    m2, _, _, _, _ = T.build("ti_d2_b64", torch.bfloat16)
+    m1.train(), m2.train()
+
+    def both():
+        m1.zero_grad(set_to_none=True), m2.zero_grad(set_to_none=True)
+        loss = (rg.cls_transforms.cross_entropy(m1(y, c), tgt, grad_dtype=torch.bfloat16) +
+                rg.cls_transforms.cross_entropy(m2(y, c), tgt, grad_dtype=torch.bfloat16))
+        loss.backward()
+        torch.cuda.synchronize()
+        return [{n: p.grad.detach().clone() for n, p in m.named_parameters()} for m in (m1, m2)]
+
+    base = both()
+    m1.defer_grad_reduction = m2.defer_grad_reduction = True
+    for rep in range(2):
+        held = both()
+        for b, h in zip(base, held):
+            for n in b:
+                assert torch.equal(b[n], h[n]), (n, rep)
+
+
+def test_flat_sync_refuses_a_frozen_patch_embedding():
+    import torch.distributed as dist
+    import test_fastpath_model as T
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1)
+    try:
+        m, _, y, c, tgt = T.build("ti_d2_b64", torch.bfloat16)
+        m.train()
+        rg.parallel.FlatGradSync(m, broadcast=False)
+        for n, p in m.named_parameters():
+            if n.startswith("patchembed."):
+                p.requires_grad_(False)
+        with pytest.raises(RuntimeError, match="patch-embedding"):
+            m(y, c)
+    finally:
+        dist.destroy_process_group()

@@ -217,3 +217,41 @@ def test_swin_bf16_and_drop_path_training_step(golden):
         e1, e2 = m(y, c), m(y, c)
     assert torch.equal(e1, e2)
     np.testing.assert_allclose(e1.cpu().numpy(), g["sw3_logits"], atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_swinv2t_at_batch_64_vs_reference_golden(golden, dt):
+    """g20 (make_golden_r3.py): the reference SwinV2-T DCT itself at B = 64 -- every logit, the loss and the gradient norm of
+    every parameter -- in both compute modes (bench.py --arch swinv2t runs the same check before timing)."""
+    g = golden("g20_fullsize.npz")
+    tag, B = "swt_b64", 64
+    m, img, depths, heads, _ = _model("swt", DEV)
+    names = [str(n) for n in g[tag + "_names"]]
+    shapes = S.param_shapes(depths, heads)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in S.fill_params({n: shapes[n] for n in names}).items()}, strict=False)
+    nb = img // 8
+    y = torch.from_numpy(detfill.normalish((B, 1, nb, nb, 8, 8), 171)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, nb // 2, nb // 2, 8, 8), 172)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 173, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    m.train()
+    m.compute_dtype = dt
+    logits = m(y, c)
+    loss = rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=dt)
+    loss.backward()
+    torch.cuda.synchronize()
+    err = np.abs(logits.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
+    named = dict(m.named_parameters())
+    gn = np.array([named[n].grad.double().norm().item() for n in names])
+    rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-9)
+    print(f"[swt B=64 {dt}] max |dlogit| = {err:.3e}, loss {loss.item():.6f} vs {float(g[tag + '_loss']):.6f}, grad-norm rel "
+          f"median {np.median(rel):.3e} max {rel.max():.3e}")
+    if dt == torch.float32:
+        assert err <= 1e-4
+        assert abs(loss.item() - float(g[tag + "_loss"])) < 2e-5
+        np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=2e-3, atol=2e-7)
+    else:
+        assert err <= 6e-2
+        assert abs(loss.item() - float(g[tag + "_loss"])) < 5e-3
+        assert np.median(rel) < 3e-2

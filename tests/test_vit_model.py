@@ -4,7 +4,7 @@ the reference model (tests/golden/g11_model.npz) and against the torch fp32 orac
 Tolerances (north_star: logits within 1e-3 of the reference):
   * fp32 compute mode : |logits - reference| <= 1e-3 (measured ~1e-5), gradients rel 1e-3.
   * bf16 compute mode : bf16 operands cannot meet 1e-3 against an fp32 reference (torch's own bf16 autocast of
-    the reference deviates ~7e-3); the stated bound is 2.5e-2 abs on logits of magnitude
+    the reference deviates ~7e-3); the stated bound is 1e-2 abs on logits of magnitude
     <= 0.9 and the error must not exceed 2x the error of the oracle run under torch bf16 autocast.
 """
 import numpy as np
@@ -82,7 +82,7 @@ def test_bf16_logits_vs_reference_golden(golden, tag):
         lo = V.vit_forward(p, y.cpu(), c.cpu(), depth, heads, emb).float()
     err_autocast = np.abs(lo.numpy() - ref).max()
     print(f"[{tag}] bf16 max |dlogit| ours = {err:.3e}, torch-autocast oracle = {err_autocast:.3e}")
-    assert err <= 2.5e-2
+    assert err <= 1e-2
     assert err <= 2.0 * err_autocast + 2e-3
     loss = rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16)
     loss.backward()
@@ -277,7 +277,7 @@ def test_embed_type2_fp32_and_bf16_vs_reference_golden(golden, tag, emb, heads):
     lb = m(y, c)
     errb = np.abs(lb.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
     print(f"[{tag}] bf16 max |dlogit| = {errb:.3e}")
-    assert errb <= 2.5e-2
+    assert errb <= 1e-2
     rg.cls_transforms.cross_entropy(lb, tgt, grad_dtype=torch.bfloat16).backward()
     gnb = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
     rel = np.abs(gnb - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
@@ -325,7 +325,7 @@ def test_embed_type2_without_subblock_vs_reference_golden(golden, tag, emb, head
     lb = m(y, c)
     errb = np.abs(lb.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
     print(f"[{tag}] bf16 max |dlogit| = {errb:.3e}")
-    assert errb <= 2.5e-2
+    assert errb <= 1e-2
     rg.cls_transforms.cross_entropy(lb, tgt, grad_dtype=torch.bfloat16).backward()
     gnb = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
     rel = np.abs(gnb - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
@@ -371,7 +371,7 @@ def test_embed_type3_concat_vs_reference_golden(golden, tag, emb, heads, depth, 
     lb = m(y, c)
     errb = np.abs(lb.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
     print(f"[{tag}] bf16 max |dlogit| = {errb:.3e}")
-    assert errb <= 2.5e-2
+    assert errb <= 1e-2
     rg.cls_transforms.cross_entropy(lb, tgt, grad_dtype=torch.bfloat16).backward()
     gnb = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
     rel = np.abs(gnb - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
