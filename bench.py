@@ -593,7 +593,7 @@ def main():
                 sec = tms.value / 1e3
                 gbs, tfs = by.value / sec / 1e9, fl.value / sec / 1e12
                 # HBM bytes per launch from the PMC counters cannot be read inside this process: they come from separate
-                # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools/gpu_pass.sh,
+                # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools/gpu.sh pass,
                 # corrected as MI355X_MICROARCH.md prescribes) whose summary is committed under profiles/
                 traffic, traffic_src = None, None
                 tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.arch}.json")

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Copy the summaries of one `tools/gpu.sh pass <tag>` / `archs <tag>` run from gpurun_out/ (scratch) into profiles/ (tracked).
+
+    python tools/collect_profiles.py <tag> <name>          e.g.  collect_profiles.py final r03_final
+    python tools/collect_profiles.py <tag>/vits <name>     for the per-arch directories of `archs`
+
+Writes profiles/<name>_{bench_line.json,kernel_stats.csv,pmc_mfma.json,pmc_traffic.json} (those that exist) and refreshes
+profiles/pmc_traffic[_<arch>].json, the file bench.py reads `roofline.traffic` from."""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(tag, name):
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    arch = "vitti"
+    for f in ("bench_line.json", "kernel_stats.csv", "pmc_mfma.json", "pmc_traffic.json"):
+        p = os.path.join(src, f)
+        if os.path.exists(p) and os.path.getsize(p) > 0:
+            shutil.copy(p, os.path.join(dst, f"{name}_{f}"))
+            print("profiles/" + f"{name}_{f}")
+            if f == "bench_line.json":
+                try:
+                    arch = {"JPEG-Ti": "vitti", "JPEG-S": "vits", "SwinV2-T": "swinv2t"}[json.load(open(p))["metric"].split()[1]]
+                except Exception:       # noqa: BLE001
+                    pass
+    t = os.path.join(src, "pmc_traffic.json")
+    if os.path.exists(t):
+        out = "pmc_traffic.json" if arch == "vitti" else f"pmc_traffic_{arch}.json"
+        shutil.copy(t, os.path.join(dst, out))
+        print("profiles/" + out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

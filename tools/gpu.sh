@@ -1,0 +1,104 @@
+#!/bin/bash
+# One entry point for everything that runs on the GPU box (from the repo root):  gpurun -- 'bash tools/gpu.sh <cmd> ...'
+#
+#   pass <tag> [notests]            THE command that regenerates profiles/: all GPU tests, the bench line, rocprofv3 kernel stats,
+#                                   PMC passes (MFMA counters, FETCH / WRITE traffic) -> gpurun_out/<tag>/ ; then, in the container,
+#                                   `python tools/collect_profiles.py <tag> rNN_name` copies the summaries into profiles/
+#   archs <tag>                     the same for --arch vits and --arch swinv2t (bench line, kernel stats, traffic)
+#   tests <pytest args>             selected GPU tests (default: all), output tail
+#   bench <n> [bench args]          n runs of bench.py (value, ms/step) -- box-to-box variation is +-3 %, so:
+#   abopt <opt> <v0> <v1> [n]       interleaved A/B of one library option on the bench step (same box)
+#   abso <base.so> [n] [bench args] interleaved A/B of two BUILDS: the in-tree librgbnm.so against <base.so> (built before an edit;
+#                                   scratch copies live under tools/*.so, git-ignored)
+#   kstats <tag> [bench args]       rocprofv3 kernel stats of the bench step -> gpurun_out/<tag>/kernel_stats.csv
+#   variants <file.hip> <kernel-pattern> <-DFLAG ...>   rebuild ONE csrc file per flag on the box and print that kernel's time
+#   stalls <tag> [bench args]       SQ activity / wait / LDS-conflict counters per kernel (three --pmc passes)
+#   stress [n]                      bit-identity loop of the fused kernels + a 3000-step run (races show as a differing bit / NaN)
+export TMPDIR=/tmp
+CMD=$1; shift
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('$1', d['value'], d['ms_per_step'], r.get('avg_launch_us'), (d.get('parity_check') or {}).get('max_abs_dlogit'))"; }
+kstats() {   # kstats <outdir> <bench args...>
+  local OUT=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python bench.py --steps 24 --warmup 4 --prewarm-sec 1 --no-cpu-baseline --no-trace "$@" > $OUT/kt.log 2>&1
+  local f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -${KSTAT_LINES:-22} $OUT/kernel_stats.csv | cut -d, -f1-4 | cut -c1-150
+  rm -rf $OUT/kt
+}
+traffic() {  # traffic <outdir> <bench args...>: FETCH_SIZE / WRITE_SIZE in separate passes (eager: a graph capture would add dispatches)
+  local OUT=$1; shift
+  local B="python bench.py --steps 3 --warmup 1 --prewarm-sec 0 --no-cpu-baseline --no-trace --no-graph --no-parity-check $@"
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- $B > $OUT/pmc_fetch.log 2>&1
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- $B > $OUT/pmc_write.log 2>&1
+  python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json 2>&1 | tail -12
+}
+cleanup() { find $1 -name "*.csv" -size +3M -delete; find $1 -name "*.db" -delete; du -sh $1; }
+case $CMD in
+pass)
+  TAG=${1:-pass}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+  if [ "$2" != "notests" ]; then
+    timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $OUT/pytest.log; tail -3 $OUT/pytest.log
+  fi
+  timeout 400 python bench.py --steps 100 --warmup 10 > $OUT/bench_line.json 2> $OUT/bench.err; cat $OUT/bench_line.json
+  kstats $OUT
+  timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-sec 0 --no-cpu-baseline --no-trace --no-graph --no-parity-check > $OUT/pmc_mfma.log 2>&1
+  python tools/pmc_mfma.py $OUT/pmc_mfma $OUT/pmc_mfma.json 2>&1 | tail -30
+  traffic $OUT
+  cleanup $OUT ;;
+archs)
+  TAG=${1:-archs}
+  for A in vits swinv2t; do
+    OUT=gpurun_out/$TAG/$A; mkdir -p $OUT
+    timeout 900 python bench.py --arch $A --steps 30 --warmup 5 --cpu-baseline-images 32 > $OUT/bench_line.json 2> $OUT/bench.err; cat $OUT/bench_line.json; tail -2 $OUT/bench.err
+    KSTAT_LINES=16 kstats $OUT --arch $A --steps 8
+    traffic $OUT --arch $A
+    cleanup $OUT
+  done ;;
+tests)
+  timeout ${TEST_TIMEOUT:-2400} python -m pytest "${@:-tests}" -m gpu -q -s 2>&1 | grep -v "^$" | tail -${TAIL:-60} ;;
+bench)
+  N=$1; shift
+  for i in $(seq 1 $N); do timeout 400 python bench.py --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | line run$i; done ;;
+abopt)
+  OPT=$1; V0=$2; V1=$3; N=${4:-3}
+  for r in $(seq 1 $N); do for v in $V0 $V1; do
+    timeout 400 python bench.py --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline --opt $OPT=$v 2>/dev/null | tail -1 | line "$OPT=$v"
+  done; done ;;
+abso)
+  BASE=$1; N=${2:-2}; shift; shift
+  cp rgb-no-more_amd/librgbnm.so /tmp/new.so
+  for r in $(seq 1 $N); do for v in new base; do
+    if [ $v = base ]; then cp $BASE rgb-no-more_amd/librgbnm.so; else cp /tmp/new.so rgb-no-more_amd/librgbnm.so; fi
+    timeout 400 python bench.py --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline --no-parity-check "$@" 2>/dev/null | tail -1 | line $v
+  done; done
+  cp /tmp/new.so rgb-no-more_amd/librgbnm.so ;;
+kstats)
+  TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; kstats $OUT "$@" ;;
+variants)
+  F=$1; PAT=$2; shift; shift
+  OUT=gpurun_out/variants; mkdir -p $OUT
+  for V in base "$@"; do
+    touch rgb-no-more_amd/csrc/$F
+    if [ "$V" = base ]; then python rgb-no-more_amd/build.py > $OUT/build.log 2>&1; else RGBNM_HIPCC_FLAGS="$V" python rgb-no-more_amd/build.py > $OUT/build.log 2>&1; fi
+    KSTAT_LINES=40 kstats $OUT | grep "$PAT" | sed "s/^/$V: /"
+  done
+  touch rgb-no-more_amd/csrc/$F; python rgb-no-more_amd/build.py > /dev/null 2>&1 ;;
+stalls)
+  TAG=${1:-stalls}; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT
+  B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity-check --no-graph $@"
+  P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY"
+  P2="SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_MFMA"
+  P3="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVES"
+  i=0
+  for P in "$P1" "$P2" "$P3"; do
+    i=$((i+1)); timeout 600 rocprofv3 --pmc $P --kernel-trace -d $OUT/p$i -o p --output-format csv -- $B > $OUT/p$i.log 2>&1; tail -2 $OUT/p$i.log
+  done
+  python tools/pmc_kernels.py $OUT/stalls.json $OUT/p1 $OUT/p2 $OUT/p3; rm -rf $OUT/p1 $OUT/p2 $OUT/p3 ;;
+stress)
+  N=${1:-20}; fail=0
+  for i in $(seq 1 $N); do
+    timeout 600 python -m pytest tests/test_fastpath_model.py -m gpu -x -q -k "fused_mlp" 2>&1 | tail -1 | grep -q "passed" || { echo "iteration $i FAILED"; fail=1; break; }
+  done
+  echo "bit-identity loop: $N iterations, fail=$fail"
+  timeout 600 python bench.py --steps 3000 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | line long ;;
+*) echo "unknown command $CMD"; exit 2 ;;
+esac
