@@ -80,7 +80,7 @@ variants)
     touch rgb-no-more_amd/csrc/$F
     if [ "$V" = base ]; then python rgb-no-more_amd/build.py > $OUT/build.log 2>&1; else RGBNM_HIPCC_FLAGS="$V" python rgb-no-more_amd/build.py > $OUT/build.log 2>&1; fi
     if [ $? -ne 0 ]; then echo "$V: BUILD FAILED"; grep -m3 "error" $OUT/build.log; continue; fi
-    KSTAT_LINES=40 kstats $OUT | grep "$PAT" | sed "s/^/$V: /"
+    KSTAT_LINES=40 kstats $OUT $VARIANT_BENCH_ARGS | grep "$PAT" | sed "s/^/$V: /"
   done
   touch rgb-no-more_amd/csrc/$F; python rgb-no-more_amd/build.py > /dev/null 2>&1 ;;
 stalls)
