@@ -268,6 +268,18 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, c
                         const rgbnm_block_grads* g, const rgbnm_block_scratch* s, const void* dy, void* dx,
                         void* stream);
 
+/* Table GELU of the bf16 path (csrc/mlp_fused.hip): in bf16 mode the pre-activation is rounded to bf16 before the GELU
+ * (models/plainvit.py:487-488 under autocast), so gelu / gelu' are functions of 16 bits.  _init is a SET-UP call (it
+ * synchronises `stream`; not capturable; idempotent per device): it builds the table of the library's own GELU arithmetic for
+ * all 65536 inputs plus a compact LDS image of it, and reads the window back.  On devices where it has been called and the
+ * image fits, the fused FeedForwardBlock forward looks gelu / gelu' up instead of computing them (option gelu_table) -- the
+ * same bits as the arithmetic for every finite input except those whose u or u / 2 is a bf16 denormal (|u| < 2.36e-38), which
+ * give a denormal of the right sign instead of u / 2.  Never called: the arithmetic runs.
+ * _info (test / diagnostics, synchronises): win16 = {valid, A0, P1, N1, image dwords, ...}, full65536 (may be NULL) =
+ * gelu(u) | gelu'(u) << 16 per bf16 bit pattern u. */
+int rgbnm_gelu_table_init(void* stream);
+int rgbnm_gelu_table_info(int* win16, unsigned* full65536);
+
 /* Held gradient reductions.  Every backward entry point of this header (rgbnm_vit_block_bwd, rgbnm_head_bwd,
  * rgbnm_patch_embed_bwd, rgbnm_gemm_tn, rgbnm_layernorm_bwd, ...) finishes with a small reduction of its split partial
  * sums (reference: autograd accumulates straight into .grad, models/plainvit.py runs under torch.autograd).  A caller that

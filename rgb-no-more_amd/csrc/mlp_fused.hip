@@ -44,6 +44,7 @@
 // roles per barrier-separated slot, one on GELU while the other runs fc2 / fc1 / stores (84 us: the GELU slot stretches from
 // 1700 to 2600 ticks next to the MFMA wave); scalar instead of packed GELU arithmetic (88 us).
 #include "common.h"
+#include <mutex>
 #include "internal.h"
 #include "ln_bwd_rows.h"
 #include "../../include/rgbnm.h"
@@ -65,6 +66,17 @@ constexpr int B2_OFF = B1_OFF + H * 4;              // 192 floats
 constexpr int FLAG_OFF = B2_OFF + E * 4;            // one int: the last chunk whose tiles of waves 4-6 the DMA wave has taken
 constexpr int SMEM = FLAG_OFF + 16;                 // 159,504 B
 constexpr int CP = E + 4;                           // final staging pitch (elements)
+// ---- forward kernel: [GELU table image | ] weight ring | per-wave staging tiles sized by the LIVE rows | bias ring | b2 | flag.
+// With 32 x 7 = 224 staging rows but 196 live ones (one image per workgroup at B = 256) the seventh wave needs 4 rows, not
+// 32: sizing the tiles by the rows that exist frees 7 KB, the fc1 bias arriving per chunk (256 B with each weight chunk)
+// instead of resident (3 KB) frees the rest of what the 13 KB table image needs.
+constexpr int F_TAB_BYTES = 13328;                  // GELU table image at LDS offset 0 (16-bit packed byte offsets address it directly)
+constexpr int F_TAB_ROWS = 196;                     // most panel rows the table leaves room for
+constexpr int F_B1R = 2 * CH * 4;                   // bias ring: one chunk's 64 floats per stage
+__host__ __device__ constexpr int f_smem(int tab, int rows) {
+  return (tab ? F_TAB_BYTES : 0) + NSTAGE * STAGE + rows * 2 * CH * 2 + F_B1R + E * 4 + 16;
+}
+static_assert(f_smem(1, F_TAB_ROWS) <= 160 * 1024, "LDS");
 constexpr int LN_GROUPS = CTHREADS / 8, LN_ITERS = BM / LN_GROUPS;      // 56 row groups of 8 lanes, 4 rounds
 static_assert(SMEM <= 160 * 1024, "LDS");
 static_assert(BM * CP * 2 <= NSTAGE * STAGE, "final staging tile lives in the ring");
@@ -75,6 +87,8 @@ struct MlpArgs {
   int ldx, ldr, ldg, ldy;
   int M, rows_per_wg, npanels, cold;       // cold: 1 = nt stores, 2 = sc1 (write-through) stores for the saved tensors
   int offload;                             // 1: the DMA wave stores the gelu / gelu' tiles of waves 4-6 (option mlp_dmast)
+  const unsigned* tab_img;                 // g_gelu_img (device symbol), TAB kernels only
+  unsigned kneg, kpos, klo, koff, ksgn;    // packed-key constants of the table window
   const float* gamma; const float* beta; bf16* Y2; float* mean_o; float* rstd_o; float eps; int ldy2;   // gamma == null: no LN
 };
 
@@ -197,10 +211,17 @@ __device__ unsigned long long g_mlp_trace[16 * 8 * 80];
 #define MLP_BSTAMP(i)
 #endif
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+// TAB = false: the arithmetic GELU, fc1 bias resident, 32-row staging tiles (any panel height up to 224 rows).
+// TAB = true : GELU by table lookup; LDS = table image | ring | staging tiles of the LIVE rows | bias ring | b2 | flag
+//              (panel height <= F_TAB_ROWS; the host passes the window constants it read back once in rgbnm_gelu_table_init).
+template <bool TAB>
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* B1s = reinterpret_cast<float*>(smem + B1_OFF);
-  float* B2s = reinterpret_cast<float*>(smem + B2_OFF);
   const int panel = blockIdx.x;
   if (panel >= p.npanels) return;
   const int m0 = panel * p.rows_per_wg;
@@ -208,22 +229,38 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
+  constexpr bool tab = TAB;
+  unsigned char* ring = smem + (TAB ? F_TAB_BYTES : 0);
+  unsigned char* stg_all = ring + NSTAGE * STAGE;          // TAB: wave v has 2 tiles of live(v) rows at 256 * min(32 v, rows_per_wg)
+  float* B1r = reinterpret_cast<float*>(TAB ? stg_all + p.rows_per_wg * (2 * CH * 2) : smem + B1_OFF);   // TAB: [2][64]; else [768]
+  float* B2s = TAB ? B1r + 2 * CH : reinterpret_cast<float*>(smem + B2_OFF);
+  volatile int* flag = reinterpret_cast<volatile int*>(TAB ? reinterpret_cast<unsigned char*>(B2s + E) : smem + FLAG_OFF);
+  auto live_rows = [&](int v) { return TAB ? max(0, min(32, p.rows_per_wg - 32 * v)) : 32; };
+  auto stg_of = [&](int v) { return TAB ? stg_all + min(32 * v, p.rows_per_wg) * (2 * CH * 2) : smem + STG_OFF + v * STG_WAVE; };
   MLP_FSTAMP(0);
 #if defined(MLP_TRACE) && MLP_TRACE != 2
   if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 79] = __builtin_amdgcn_s_memrealtime();
 #endif
 
   if (w == NCW) {
-    // ---------------- DMA wave: biases once, then one 48 KB weight chunk per barrier, one chunk ahead of the math
+    // ---------------- DMA wave: table image and b2 once, then one 48 KB weight chunk (+ its 64 fc1 biases) per barrier, one
+    // chunk ahead of the math
+    if (tab) {
+      const int npiece = F_TAB_BYTES / 16;                            // 833 pieces of 16 bytes
+      for (int i = 0; i * 64 < npiece; ++i)
+        if (i * 64 + lane < npiece)
+          __builtin_amdgcn_global_load_lds((glb_ptr)(p.tab_img + (i * 64 + lane) * 4), (lds_ptr)(smem + i * 1024), 16, 0, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < H / 64; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(p.b1 + 64 * i + lane), (lds_ptr)(B1s + 64 * i), 4, 0, 0);
+      for (int i = 0; i < H / 64; ++i)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(p.b1 + 64 * i + lane), (lds_ptr)(B1r + 64 * i), 4, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < E / 64; ++i)
       __builtin_amdgcn_global_load_lds((glb_ptr)(p.b2 + 64 * i + lane), (lds_ptr)(B2s + 64 * i), 4, 0, 0);
     const int rl = lane >> 3, pc = lane & 7;
     auto issue = [&](int chunk) {
-      unsigned char* st = smem + (chunk & 1) * STAGE;
+      unsigned char* st = ring + (chunk & 1) * STAGE;
       const bf16* w1 = p.W1 + (size_t)chunk * CH * E;
 #pragma unroll
       for (int i = 0; i < W1_STAGE / 1024; ++i) {
@@ -238,25 +275,28 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
         __builtin_amdgcn_global_load_lds((glb_ptr)(w2 + (size_t)r8 * H + ((pc ^ fswz(r8)) * 8)),
                                          (lds_ptr)(st + W1_STAGE + i * 1024), 16, 0, 0);
       }
+      if (tab) __builtin_amdgcn_global_load_lds((glb_ptr)(p.b1 + chunk * CH + lane), (lds_ptr)(B1r + (chunk & 1) * CH), 4, 0, 0);
     };
     // offload: the younger wave of each SIMD pair (4, 5, 6) is the critical path of a chunk (stamps: it is starved while the
     // older one runs, then finishes alone and stores); its tile stores are taken over by this wave, which is idle between two
     // weight chunks.  After barrier c + 1 the tiles of chunk c are complete: read them into registers, raise the flag (the
     // owners poll it before they overwrite the tiles), issue the stores, then the next weight chunk (it has a whole chunk to land).
-    volatile int* flag = reinterpret_cast<volatile int*>(smem + FLAG_OFF);
     bf16x8 tv[3][2][4];
     const int trow = lane >> 3, tvec = lane & 7;
     auto take_tiles = [&]() {
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < 3; ++q) {
+        const unsigned char* sq = stg_of(4 + q);
+        const int lr = live_rows(4 + q);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int row = trow + 8 * i;
-            tv[q][t][i] = *reinterpret_cast<const bf16x8*>(smem + STG_OFF + (4 + q) * STG_WAVE + t * STG_TILE + row * (CH * 2) +
-                                                           ((tvec ^ (row & 7)) << 4));
+            if (row < lr)
+              tv[q][t][i] = *reinterpret_cast<const bf16x8*>(sq + t * lr * (CH * 2) + row * (CH * 2) + ((tvec ^ (row & 7)) << 4));
           }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     auto store_tiles = [&](int chunk) {
@@ -275,8 +315,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
     if (p.offload && lane == 0) *flag = 0;
     issue(0);
     for (int c = 0; c < NCHUNK; ++c) {
-      // chunk c (and, the first time, the biases) landed -- and the tile stores issued before it (vmcnt retires in order; the
-      // number of store instructions depends on the valid rows, so no counted wait)
+      // chunk c (and, the first time, the table and b2) landed -- and the tile stores issued before it (vmcnt retires in order;
+      // the number of store instructions depends on the valid rows, so no counted wait)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       MLP_FSTAMP(2 + 5 * c);
       __builtin_amdgcn_s_barrier();                       // ... and every compute wave is done with chunk c - 1
@@ -317,7 +357,16 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
 
   const int fl = fswz(l31);
   const int woff0 = l31 * (E * 2) + ((g ^ fl) << 4);      // W1 fragment c of LDS row l31: (woff0 ^ ((c % 4) << 5)) + 128 (c / 4)
-  unsigned char* stg = smem + STG_OFF + w * STG_WAVE;
+  unsigned char* stg = stg_of(w);
+  const int lrw = live_rows(w);                            // rows of this wave's two tiles (gelu | gelu')
+  const bool lane_live = TAB ? l31 < lrw : true;
+  // table constants (SGPRs, from the host): splats for the packed 16-bit key arithmetic
+  //   kneg: u16 min -- negative magnitudes stop at N1 (gelu = -0, gelu' constant beyond)
+  //   kpos: i16 min -- positive magnitudes stop at P1 (key only)      klo: u16 max -- everything tiny shares the entry below the window
+  //   koff: byte offset 4 (a - (A0 - 1)) mod 2^16                      ksgn: the negative half of the image starts here
+  const unsigned kneg = p.kneg, kpos = p.kpos, klo = p.klo, koff = p.koff, ksgn = p.ksgn;
+  unsigned k4v = 0x00040004u;                              // (a VGPR: an instruction takes one scalar operand)
+  asm volatile("" : "+v"(k4v));
 #if defined(MLP_TRACE) && MLP_TRACE != 2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -329,8 +378,9 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
     if (p.offload) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile writes of the previous chunk are in LDS
     __builtin_amdgcn_s_barrier();
     MLP_FSTAMP(3 + 5 * chunk);
-    const unsigned char* sW1 = smem + (chunk & 1) * STAGE;
+    const unsigned char* sW1 = ring + (chunk & 1) * STAGE;
     const unsigned char* sW2 = sW1 + W1_STAGE;
+    const float* bch = TAB ? B1r + (chunk & 1) * CH : B1r + chunk * CH;
 #pragma unroll
     for (int ht = 0; ht < 2; ++ht) {
       f32x16 a1;
@@ -347,32 +397,78 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
       }
       Frag<bf16> pg[2];
       if (handed && ht == 0 && chunk > 0) {               // the DMA wave has taken the previous chunk's tiles (normally long ago)
-        const volatile int* flag = reinterpret_cast<const volatile int*>(smem + FLAG_OFF);
         while (__builtin_amdgcn_readfirstlane(*flag) < chunk) __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
       for (int hs = 0; hs < 2; ++hs) {
         // registers 8 hs .. 8 hs + 7 of this lane = hidden units h0 .. h0 + 7 of the token l31 (rows were stored swap23-ed)
         const int hl = 32 * ht + 16 * hs + 8 * g;
-        const float* bp = B1s + chunk * CH + hl;
+        const float* bp = bch + hl;
         const f32x4 bl = *reinterpret_cast<const f32x4*>(bp), bh = *reinterpret_cast<const f32x4*>(bp + 4);
         bf16x8 gv, dv;
+        if constexpr (TAB) {
+          // gelu / gelu' of the eight elements: bf16 bits p of two elements -> packed 16-bit keys -> one ds_read_b32 of
+          // {D | gelu' << 16} per element (all eight in flight, one wait) -> |gelu| = max(a, 0x80) - D  (see the table comment
+          // above gelu_full_kernel).  Packed 16-bit VALU by inline asm: the compiler's own selection of the same arithmetic
+          // needed 28 instructions per pair against 17 here.
+          unsigned pb[4], agv[4], alo[4], ahi[4], e0[4], e1[4];
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const float u0 = a1[8 * hs + j] + (j < 4 ? bl[j] : bh[j - 4]);
-          const float u1 = a1[8 * hs + j + 1] + (j < 4 ? bl[j + 1] : bh[j - 3]);
-          const f32x2 u = {(float)(bf16)u0, (float)(bf16)u1};          // the unfused path rounds u to bf16 before GELU
-          f32x2 ge, dg;
-          gelu_pair_fast(u, ge, dg);
-          gv[j] = (bf16)ge[0];
-          gv[j + 1] = (bf16)ge[1];
-          dv[j] = (bf16)dg[0];
-          dv[j + 1] = (bf16)dg[1];
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = 2 * jj;
+            const f32x2 uu = f32x2{a1[8 * hs + j], a1[8 * hs + j + 1]} + (j < 4 ? f32x2{bl[j], bl[j + 1]} : f32x2{bh[j - 4], bh[j - 3]});
+            const bf16x2v pbv = {(bf16)uu[0], (bf16)uu[1]};                            // the unfused path rounds u to bf16 before GELU
+            pb[jj] = __builtin_bit_cast(unsigned, pbv);
+            unsigned p1, p2, ak, i4, sg;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(p1) : "v"(pb[jj]), "s"(kneg));
+            asm("v_pk_min_i16 %0, %1, %2" : "=v"(p2) : "v"(p1), "s"(kpos));
+            p1 &= 0x7FFF7FFFu;
+            p2 &= 0x7FFF7FFFu;
+            asm("v_pk_max_u16 %0, %1, %2" : "=v"(agv[jj]) : "v"(p1), "s"(0x00800080u));
+            asm("v_pk_max_u16 %0, %1, %2" : "=v"(ak) : "v"(p2), "s"(klo));
+            asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(i4) : "v"(ak), "v"(k4v), "s"(koff));
+            asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(sg) : "s"(0x000F000Fu), "v"(pb[jj]));   // (a literal 15 would shift the low half only)
+            asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(i4) : "v"(sg), "s"(ksgn), "v"(i4));
+            alo[jj] = i4 & 0xffffu;
+            ahi[jj] = i4 >> 16;
+          }
+          asm volatile(
+              "ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+              "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(e0[0]), "=&v"(e1[0]), "=&v"(e0[1]), "=&v"(e1[1]), "=&v"(e0[2]), "=&v"(e1[2]), "=&v"(e0[3]), "=&v"(e1[3])
+              : "v"(alo[0]), "v"(ahi[0]), "v"(alo[1]), "v"(ahi[1]), "v"(alo[2]), "v"(ahi[2]), "v"(alo[3]), "v"(ahi[3])
+              : "memory");
+          u32x4v gq, dq;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const unsigned dpair = __builtin_amdgcn_perm(e1[jj], e0[jj], 0x05040100u);
+            unsigned gm;
+            asm("v_pk_sub_u16 %0, %1, %2" : "=v"(gm) : "v"(agv[jj]), "v"(dpair));
+            gq[jj] = (pb[jj] & 0x80008000u) | gm;
+            dq[jj] = __builtin_amdgcn_perm(e1[jj], e0[jj], 0x07060302u);
+          }
+          gv = __builtin_bit_cast(bf16x8, gq);
+          dv = __builtin_bit_cast(bf16x8, dq);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const float u0 = a1[8 * hs + j] + (j < 4 ? bl[j] : bh[j - 4]);
+            const float u1 = a1[8 * hs + j + 1] + (j < 4 ? bl[j + 1] : bh[j - 3]);
+            const f32x2 u = {(float)(bf16)u0, (float)(bf16)u1};          // the unfused path rounds u to bf16 before GELU
+            f32x2 ge, dg;
+            gelu_pair_fast(u, ge, dg);
+            gv[j] = (bf16)ge[0];
+            gv[j + 1] = (bf16)ge[1];
+            dv[j] = (bf16)dg[0];
+            dv[j + 1] = (bf16)dg[1];
+          }
         }
         pg[hs].v = gv;
-        const int pcx = ((2 * (2 * ht + hs) + g) ^ (l31 & 7)) << 4;
-        *reinterpret_cast<bf16x8*>(stg + l31 * (CH * 2) + pcx) = gv;
-        *reinterpret_cast<bf16x8*>(stg + STG_TILE + l31 * (CH * 2) + pcx) = dv;
+        if (lane_live) {                                   // rows >= live(w) have no tile row (and are never stored)
+          const int pcx = ((2 * (2 * ht + hs) + g) ^ (l31 & 7)) << 4;
+          *reinterpret_cast<bf16x8*>(stg + l31 * (CH * 2) + pcx) = gv;
+          *reinterpret_cast<bf16x8*>(stg + lrw * (CH * 2) + l31 * (CH * 2) + pcx) = dv;
+        }
       }
 #pragma unroll
       for (int hs = 0; hs < 2; ++hs) {
@@ -387,16 +483,16 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
       if (ht == 0) MLP_FSTAMP(4 + 5 * chunk);
       else MLP_FSTAMP(5 + 5 * chunk);
     }
-    // ---- the chunk's gelu / gelu' tiles: 32 rows x 128 B each, out as whole row pieces (LDS runs a wave in order)
+    // ---- the chunk's gelu / gelu' tiles: live rows x 128 B each, out as whole row pieces (LDS runs a wave in order)
     const int ln = lane_id_here();
     if (!handed)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
-      const int so = row * (CH * 2) + ((vec ^ (row & 7)) << 4);
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + so);
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + STG_TILE + so);
-      if (32 * w + row < rows) {
+      if (row < lrw && 32 * w + row < rows) {
+        const int so = row * (CH * 2) + ((vec ^ (row & 7)) << 4);
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + so);
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + lrw * (CH * 2) + so);
         const size_t go = (size_t)(m0 + 32 * w + row) * p.ldg + chunk * CH + vec * 8;
         // gelu(u) / gelu'(u) are read again only in the backward, seconds of traffic later: with the non-temporal hint they do
         // not push the tensors the next kernels are about to read out of the Infinity Cache
@@ -412,7 +508,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
     MLP_FSTAMP(6 + 5 * chunk);
   }
   MLP_FSTAMP(62);
-  mlp_epilogue(p, smem, B2s, acc2, m0, rows, tid, w, l31, g);
+  mlp_epilogue(p, ring, B2s, acc2, m0, rows, tid, w, l31, g);
   MLP_FSTAMP(63);
 #if defined(MLP_TRACE) && MLP_TRACE != 2
   if (blockIdx.x < 16 && (threadIdx.x & 63) == 0) g_mlp_trace[(blockIdx.x * 8 + w) * 80 + 78] = __builtin_amdgcn_s_memrealtime();
@@ -648,6 +744,90 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(MlpBwdArgs p) {
   MLP_BSTAMP(63);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Table GELU.  In the bf16 path u is rounded to bf16 BEFORE the GELU (as the unfused epilogue does), so gelu(u) and gelu'(u)
+// are functions of 16 bits.  g_gelu_full holds the arithmetic of gelu_pair_fast for every bf16 input; the forward kernel looks
+// the pair up in a compact LDS image of it instead of spending ~35 VALU instructions (4 of them transcendental) per two
+// elements.  Outside a window of magnitudes the function has closed forms, all in terms of the 15-bit magnitude `a` of u and
+// ONE 16-bit subtraction  |gelu(u)| = max(a, 0x80) - D[key]  that the clamped keys at both ends of the window share:
+//     a <  A0 (tiny)          : gelu = u / 2  (exponent - 1: D = 0x80),  gelu' = 0.5
+//     a >= P1, u > 0 (large)  : gelu = u      (D = 0),                   gelu' = 1
+//     a >= N1, u < 0          : gelu = -0     (a clamped to N1, D = N1), gelu' = its constant there
+// (sign(gelu(u)) = sign(u) throughout).  A0, P1, N1 are not assumed: gelu_scan_kernel finds the widest tiny / narrowest large
+// regions in which the closed forms reproduce g_gelu_full bit for bit and writes the LDS image; if the window does not fit
+// the kernel's LDS the table is marked invalid and the arithmetic runs.  The only inputs whose result differs from the
+// arithmetic are those whose u or u / 2 is a bf16 DENORMAL (|u| < 2.36e-38): gelu = a denormal of the right sign, not u / 2.
+// Measured on MI355X: A0 = 2^-9, P1 = 4, N1 = 16 -> 3076 dwords = 12.0 KB.
+constexpr int GELU_IMG_MAX = 3336;                 // dwords of LDS the forward kernel can spare (13 344 B)
+__device__ unsigned g_gelu_full[65536];            // [bits of u] -> gelu(u) | gelu'(u) << 16 (bf16 each)
+__device__ unsigned g_gelu_img[GELU_IMG_MAX];      // [0] tiny | [1 .. NP] a = A0 .. P1-1 | [NP+1] large+ | [NP+2] tiny | a = A0 .. N1-1 | large-
+__device__ int g_gelu_win[16];                     // [0] valid [1] A0 [2] P1 [3] N1 [4] image dwords [5] gelu'(-large) bits [6..] splat constants
+
+__global__ __launch_bounds__(256) void gelu_full_kernel() {
+  const unsigned k = blockIdx.x * 256 + threadIdx.x;
+  const float u = (float)__builtin_bit_cast(bf16, (unsigned short)k);
+  const f32x2 x = {u, u};
+  f32x2 ge, dg;
+  gelu_pair_fast(x, ge, dg);
+  g_gelu_full[k] = (unsigned)__builtin_bit_cast(unsigned short, (bf16)ge[0]) |
+                   ((unsigned)__builtin_bit_cast(unsigned short, (bf16)dg[0]) << 16);
+}
+
+__global__ __launch_bounds__(1024) void gelu_scan_kernel() {
+  __shared__ int tiny_ok[256], pos_ok[256], neg_ok[256], win[4];
+  const int tid = threadIdx.x;
+  if (tid < 256) { tiny_ok[tid] = 1; pos_ok[tid] = 1; neg_ok[tid] = 1; }
+  __syncthreads();
+  const unsigned gpn = g_gelu_full[0xFF7F] >> 16;                  // gelu'(most negative finite)
+  {
+    const int row = tid >> 2;                                       // exponent row: 128 magnitudes
+    bool t_ok = true, p_ok = true, n_ok = true;
+    for (int m = (tid & 3) * 32; m < (tid & 3) * 32 + 32; ++m) {
+      const unsigned a = row * 128 + m;
+      const unsigned ep = g_gelu_full[a], en = g_gelu_full[0x8000 | a];
+      if (a >= 0x80) {
+        t_ok = t_ok && ep == ((a - 0x80) | (0x3F00u << 16)) && en == ((0x8000u | (a - 0x80)) | (0x3F00u << 16));
+      }
+      p_ok = p_ok && ep == (a | (0x3F80u << 16));
+      n_ok = n_ok && en == (0x8000u | (gpn << 16));
+    }
+    if (!t_ok) atomicAnd(&tiny_ok[row], 0);
+    if (!p_ok) atomicAnd(&pos_ok[row], 0);
+    if (!n_ok) atomicAnd(&neg_ok[row], 0);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int e0 = 2;                                     // rows 2 .. e0-1 are tiny (rows 0, 1: u or u / 2 is a denormal -- flushed)
+    while (e0 < 255 && tiny_ok[e0]) ++e0;
+    int ep = 255, en = 255;                                         // rows ep .. 254 / en .. 254 are large (255 = inf / nan)
+    while (ep > e0 && pos_ok[ep - 1]) --ep;
+    while (en > e0 && neg_ok[en - 1]) --en;
+    const int A0 = e0 * 128, P1 = ep * 128, N1 = en * 128;
+    const int ndw = (P1 - A0 + 2) + (N1 - A0 + 2);
+    win[0] = A0; win[1] = P1; win[2] = N1; win[3] = ndw;
+    g_gelu_win[1] = A0; g_gelu_win[2] = P1; g_gelu_win[3] = N1; g_gelu_win[4] = ndw; g_gelu_win[5] = (int)gpn;
+  }
+  __syncthreads();
+  const int A0 = win[0], P1 = win[1], N1 = win[2], ndw = win[3];
+  if (ndw <= GELU_IMG_MAX) {
+    const int NP = P1 - A0, NN = N1 - A0;
+    for (int i = tid; i < ndw; i += 1024) {
+      unsigned e;
+      if (i == 0 || i == NP + 2) e = 0x80u | (0x3F00u << 16);                       // tiny
+      else if (i <= NP) { const unsigned a = A0 + i - 1, f = g_gelu_full[a]; e = (a - (f & 0x7FFF)) | (f & 0xFFFF0000u); }
+      else if (i == NP + 1) e = 0u | (0x3F80u << 16);                               // large positive
+      else if (i <= NP + 2 + NN) { const unsigned a = A0 + (i - NP - 2) - 1, f = g_gelu_full[0x8000 | a]; e = (a - (f & 0x7FFF)) | (f & 0xFFFF0000u); }
+      else e = (unsigned)N1 | (gpn << 16);                                          // large negative
+      g_gelu_img[i] = e;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    g_gelu_win[0] = ndw <= GELU_IMG_MAX ? 1 : 0;
+  }
+}
+
 }  // namespace
 
 #ifdef MLP_TRACE
@@ -655,6 +835,42 @@ extern "C" int rgbnm_mlp_trace_read(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mlp_trace), sizeof(unsigned long long) * 16 * 8 * 80) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// Host-side record of the device table (per device): 0 = not built, 1 = valid, -1 = built but unusable
+struct GeluTabHost { std::atomic<int> state{0}; int A0 = 0, P1 = 0, N1 = 0; const unsigned* img = nullptr; };
+static GeluTabHost g_tab_host[64];
+
+// Builds the tables on `stream`, waits for them and reads the window back: a set-up call (SYNCHRONISES; not capturable).
+// Idempotent per device.  The forward launcher uses the table only on devices where this has been called.
+extern "C" int rgbnm_gelu_table_init(void* stream) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  GeluTabHost& T = g_tab_host[dev & 63];
+  if (T.state.load(std::memory_order_acquire) != 0) return RGBNM_OK;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (T.state.load(std::memory_order_acquire) != 0) return RGBNM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gelu_full_kernel, dim3(256), dim3(256), 0, st);
+  hipLaunchKernelGGL(gelu_scan_kernel, dim3(1), dim3(1024), 0, st);
+  LAUNCH_CHECK();
+  int win[16];
+  void* img = nullptr;
+  if (hipStreamSynchronize(st) != hipSuccess || hipMemcpyFromSymbol(win, HIP_SYMBOL(g_gelu_win), sizeof(win)) != hipSuccess ||
+      hipGetSymbolAddress(&img, HIP_SYMBOL(g_gelu_img)) != hipSuccess)
+    return RGBNM_ELAUNCH;
+  T.A0 = win[1]; T.P1 = win[2]; T.N1 = win[3]; T.img = (const unsigned*)img;
+  const bool ok = win[0] == 1 && win[4] * 4 <= F_TAB_BYTES && T.A0 >= 0x100 && T.P1 > T.A0 && T.N1 > T.A0;
+  T.state.store(ok ? 1 : -1, std::memory_order_release);
+  return RGBNM_OK;
+}
+// Test / diagnostics: the window descriptor (16 ints) and, optionally, the full table (65536 dwords) on the host.  Synchronises.
+extern "C" int rgbnm_gelu_table_info(int* win16, unsigned* full65536) {
+  if (hipDeviceSynchronize() != hipSuccess) return RGBNM_ELAUNCH;
+  if (win16 && hipMemcpyFromSymbol(win16, HIP_SYMBOL(g_gelu_win), 16 * sizeof(int)) != hipSuccess) return RGBNM_ELAUNCH;
+  if (full65536 && hipMemcpyFromSymbol(full65536, HIP_SYMBOL(g_gelu_full), 65536 * sizeof(unsigned)) != hipSuccess) return RGBNM_ELAUNCH;
+  return RGBNM_OK;
+}
 
 // 1 = shape not eligible (the caller runs fc1 and fc2 as two GEMM launches).
 int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2,
@@ -675,16 +891,34 @@ int rgbnm_launch_mlp_fwd(const void* X, int ldx, const void* W1, const float* b1
   if (rows > BM) rows = BM;
   p.rows_per_wg = rows;
   p.npanels = cdiv(M, rows);
+  // table GELU (option gelu_table): on devices where rgbnm_gelu_table_init found a usable table, for panels whose staging tiles
+  // leave the LDS for it
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const GeluTabHost& T = g_tab_host[dev & 63];
+  const bool table = rgbnm_get_option("gelu_table") && rows <= F_TAB_ROWS && T.state.load(std::memory_order_acquire) == 1;
+  p.tab_img = nullptr; p.kneg = p.kpos = p.klo = p.koff = p.ksgn = 0;
+  if (table) {
+    p.tab_img = T.img;
+    p.kneg = 0x00010001u * (unsigned)(0x8000 | T.N1);
+    p.kpos = 0x00010001u * (unsigned)T.P1;
+    p.klo = 0x00010001u * (unsigned)(T.A0 - 1);
+    p.koff = 0x00010001u * (unsigned)((0x10000 - 4 * (T.A0 - 1)) & 0xffff);
+    p.ksgn = 0x00010001u * (unsigned)(4 * (T.P1 - T.A0 + 2));
+  }
+  const int smem_bytes = table ? f_smem(1, rows) : SMEM;
   static DevOnce attr;
   if (attr.need()) {
-    if (hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, f_smem(1, F_TAB_ROWS)) != hipSuccess)
       return RGBNM_ELAUNCH;
     attr.done();
   }
   const double me = (double)M * E, mh = (double)M * H;
   // algorithmic bytes: xn2 + x_mid in, gelu + gelu' + x_out (+ xn_next) out, both weight matrices once
   const int slot = rgbnm_trace_begin(TR_NT, 4.0 * mh * E, (me * (gamma ? 4.0 : 3.0) + mh * 2.0) * 2.0 + 4.0 * E * H, st);
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(p.npanels), dim3(NTHREADS), SMEM, st, p);
+  if (table) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(p.npanels), dim3(NTHREADS), smem_bytes, st, p);
+  else hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(p.npanels), dim3(NTHREADS), smem_bytes, st, p);
   rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;

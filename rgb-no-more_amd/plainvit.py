@@ -645,6 +645,8 @@ class ViT(FlatParamModule):
         self._zc = {}
         self._build_names()
         self._arenas = {}
+        # set-up call (synchronises once per device): GELU table of the fused FeedForwardBlock forward (rgbnm.h)
+        L.check(L.lib().rgbnm_gelu_table_init(L.stream()), "gelu_table_init")
 
     def _zero_chroma(self, n, dtype):
         """(n, 2, 7, 7, 8, 8) zeros: the chroma argument of the sub-block kernel when the chroma planes themselves are
