@@ -185,6 +185,19 @@ int rgbnm_dct_augment_ex(const int16_t* Yq, const int16_t* CbCrq, const int16_t*
                          void* outC, int out_dtype, int size, int B, int Hy, int Wy, int Hc, int Wc, int entry_clamp,
                          int nops, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same pipeline on HOST-CROPPED input (loader.DCTBatchLoader(crop_on_host=True); SURVEY.md 8f f2: "ship only the crop
+ * box"): image b's crop box alone, as contiguous int16 blocks [crop_h][crop_w][64] at Ypacked + y_off[b] and
+ * [2][crop_h/2][crop_w/2][64] at Cpacked + c_off[b] (element offsets, device arrays of B entries; Cpacked NULL: grayscale).
+ * params[b].crop_* still hold the box in the ORIGINAL Hy x Wy grid (validated against it on the host exactly as in
+ * rgbnm_dct_augment); the kernels read the box from origin 0 with its own row pitch.  Output bit-identical to
+ * rgbnm_dct_augment_ex on the whole grids.  Replaces datasets.py:274-297 + pipeline_utils.py:70-73 (.to(device) of whole
+ * coefficient tensors). */
+int rgbnm_dct_augment_packed(const int16_t* Ypacked, const int16_t* Cpacked, const long long* y_off, const long long* c_off,
+                             const int16_t* quant, const rgbnm_aug_params* params_dev, const rgbnm_aug_params* params_host,
+                             const float* conv16, const float* filters, void* outY, void* outC, int out_dtype, int size, int B,
+                             int Hy, int Wy, int Hc, int Wc, int entry_clamp, int nops, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Train-step tail
  * ------------------------------------------------------------------------------------------- */

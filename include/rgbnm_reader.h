@@ -30,6 +30,14 @@ int rgbnm_read_coefficients_mem(const unsigned char* buf, size_t len, int32_t* d
  * chroma and unit chroma tables.  Returns the number of failed files; status[i] holds each file's code. */
 int rgbnm_read_coefficients_batch(const char* const* paths, int n, int threads, int Hb, int Wb, int Hbc, int Wbc,
                                   int16_t* Y, int16_t* CbCr, int16_t* quant, int32_t* status);
+/* The same with a crop box per file (luma blocks (top, left, height, width), all even; chroma box = halved): only the box
+ * is copied out of libjpeg's coefficient arrays, packed [height][width][64] at Ypacked + yoff[i] and
+ * [2][height/2][width/2][64] at Cpacked + coff[i] (element offsets).  For loader.DCTBatchLoader(crop_on_host=True): the crop
+ * of RandomResizedCrop_DCT (utils/custom_transforms.py:631-663) is taken on the host, before the H2D copy
+ * (datasets.py:274-297, pipeline_utils.py:70-73 ship whole coefficient tensors). */
+int rgbnm_read_coefficients_batch_crop(const char* const* paths, int n, int threads, int Hb, int Wb, int Hbc, int Wbc,
+                                       const int32_t* box, const int64_t* yoff, const int64_t* coff, int16_t* Ypacked,
+                                       int16_t* Cpacked, int16_t* quant, int32_t* status);
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,22 @@ int rgbnm_dct_augment_ex(const int16_t* Yq, const int16_t* CbCrq, const int16_t*
                        entry_clamp, nops, workspace, workspace_bytes, st);
 }
 
+int rgbnm_dct_augment_packed(const int16_t* Ypacked, const int16_t* Cpacked, const long long* y_off, const long long* c_off,
+                             const int16_t* quant, const rgbnm_aug_params* params_dev, const rgbnm_aug_params* params_host,
+                             const float* conv16, const float* filters, void* outY, void* outC, int out_dtype, int size, int B,
+                             int Hy, int Wy, int Hc, int Wc, int entry_clamp, int nops, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!Ypacked || !y_off || !c_off || !quant || !params_dev || !params_host || !conv16 || !outY || !outC || !workspace || B <= 0)
+    return RGBNM_EINVAL;
+  if (nops < 0 || nops > 2 || (size != 28 && size != 32)) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (size == 32)
+    return aug32::launch(Ypacked, Cpacked, quant, params_dev, params_host, conv16, filters, outY, outC, out_dtype, B, Hy, Wy, Hc,
+                         Wc, entry_clamp, nops, workspace, workspace_bytes, st, y_off, c_off);
+  return aug28::launch(Ypacked, Cpacked, quant, params_dev, params_host, conv16, filters, outY, outC, out_dtype, B, Hy, Wy, Hc, Wc,
+                       entry_clamp, nops, workspace, workspace_bytes, st, y_off, c_off);
+}
+
 int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* quant, const rgbnm_aug_params* params_dev,
                       const rgbnm_aug_params* params_host, const float* conv16, const float* filters, void* outY,
                       void* outC, int out_dtype, int B, int Hy, int Wy, int Hc, int Wc, int entry_clamp, int nops,

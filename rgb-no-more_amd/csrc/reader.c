@@ -43,8 +43,10 @@ static void set_err(char* err, int errlen, const char* msg) {
 }
 
 /* info[0] = ncomp; then per component: height_in_blocks, width_in_blocks, downsampled_height, downsampled_width */
+/* box (may be NULL) = (top, left, height, width) in luma blocks, all even: only that box is copied, packed
+ * [height][width][64] into Y and [2][height/2][width/2][64] into CbCr (the chroma box is the luma box halved). */
 static int read_impl(FILE* fp, const unsigned char* mem, size_t memlen, int32_t* info, int32_t* dim, int16_t* quant,
-                     int16_t* Y, int16_t* CbCr, const int32_t* expect, char* err, int errlen) {
+                     int16_t* Y, int16_t* CbCr, const int32_t* expect, const int32_t* box, char* err, int errlen) {
   struct jpeg_decompress_struct cinfo;
   struct rd_err jerr;
   memset(&cinfo, 0, sizeof(cinfo));
@@ -99,19 +101,33 @@ static int read_impl(FILE* fp, const unsigned char* mem, size_t memlen, int32_t*
       dim[2 * c + 0] = (int32_t)cinfo.comp_info[c].downsampled_height;
       dim[2 * c + 1] = (int32_t)cinfo.comp_info[c].downsampled_width;
     }
+  if (box) {
+    const int sh = nc >= 3 ? 1 : 0;      /* a chroma plane, if any, must cover the halved box */
+    if (box[0] < 0 || box[1] < 0 || box[2] <= 0 || box[3] <= 0 || ((box[0] | box[1] | box[2] | box[3]) & 1) ||
+        box[0] + box[2] > (int)cinfo.comp_info[0].height_in_blocks || box[1] + box[3] > (int)cinfo.comp_info[0].width_in_blocks ||
+        (sh && ((box[0] + box[2]) / 2 > (int)cinfo.comp_info[1].height_in_blocks ||
+                (box[1] + box[3]) / 2 > (int)cinfo.comp_info[1].width_in_blocks))) {
+      set_err(err, errlen, "crop box outside the coefficient grid (or not even)");
+      jpeg_destroy_decompress(&cinfo);
+      return RD_EARG;
+    }
+  }
   jvirt_barray_ptr* coefs = jpeg_read_coefficients(&cinfo);   /* entropy decode only: no IDCT, no colour conversion */
   for (int c = 0; c < nc && c < 3; ++c) {
     jpeg_component_info* ci = &cinfo.comp_info[c];
+    /* rows r0 .. r0 + nr - 1, blocks c0 .. c0 + ncol - 1 of this component, packed [nr][ncol][64] */
+    const JDIMENSION r0 = box ? (JDIMENSION)(c ? box[0] / 2 : box[0]) : 0, c0 = box ? (JDIMENSION)(c ? box[1] / 2 : box[1]) : 0;
+    const JDIMENSION nr = box ? (JDIMENSION)(c ? box[2] / 2 : box[2]) : ci->height_in_blocks;
+    const JDIMENSION ncol = box ? (JDIMENSION)(c ? box[3] / 2 : box[3]) : ci->width_in_blocks;
     int16_t* dst;
     if (c == 0) dst = Y;
     else {
       if (!CbCr) continue;
-      dst = CbCr + (size_t)(c - 1) * ci->height_in_blocks * ci->width_in_blocks * DCTSIZE2;
+      dst = CbCr + (size_t)(c - 1) * nr * ncol * DCTSIZE2;
     }
-    for (JDIMENSION r = 0; r < ci->height_in_blocks; ++r) {
-      JBLOCKARRAY rows = (*cinfo.mem->access_virt_barray)((j_common_ptr)&cinfo, coefs[c], r, 1, FALSE);
-      memcpy(dst + (size_t)r * ci->width_in_blocks * DCTSIZE2, rows[0][0],
-             (size_t)ci->width_in_blocks * DCTSIZE2 * sizeof(int16_t));
+    for (JDIMENSION r = 0; r < nr; ++r) {
+      JBLOCKARRAY rows = (*cinfo.mem->access_virt_barray)((j_common_ptr)&cinfo, coefs[c], r0 + r, 1, FALSE);
+      memcpy(dst + (size_t)r * ncol * DCTSIZE2, rows[0][c0], (size_t)ncol * DCTSIZE2 * sizeof(int16_t));
     }
     if (quant && ci->quant_table)
       for (int k = 0; k < DCTSIZE2; ++k) quant[c * DCTSIZE2 + k] = (int16_t)ci->quant_table->quantval[k];
@@ -132,14 +148,14 @@ int rgbnm_jpeg_info(const char* path, int32_t* info17, char* err, int errlen) {
     set_err(err, errlen, m);
     return RD_EOPEN;
   }
-  const int rc = read_impl(fp, NULL, 0, info17, NULL, NULL, NULL, NULL, NULL, err, errlen);
+  const int rc = read_impl(fp, NULL, 0, info17, NULL, NULL, NULL, NULL, NULL, NULL, err, errlen);
   fclose(fp);
   return rc;
 }
 
 int rgbnm_jpeg_info_mem(const unsigned char* buf, size_t len, int32_t* info17, char* err, int errlen) {
   if (!buf || !info17) return RD_EARG;
-  return read_impl(NULL, buf, len, info17, NULL, NULL, NULL, NULL, NULL, err, errlen);
+  return read_impl(NULL, buf, len, info17, NULL, NULL, NULL, NULL, NULL, NULL, err, errlen);
 }
 
 /* dim [C][2], quant [C][64], Y [Hb*Wb*64], CbCr [2*Hbc*Wbc*64] (may be NULL for 1-component files) */
@@ -153,7 +169,7 @@ int rgbnm_read_coefficients(const char* path, int32_t* dim, int16_t* quant, int1
     set_err(err, errlen, m);
     return RD_EOPEN;
   }
-  const int rc = read_impl(fp, NULL, 0, NULL, dim, quant, Y, CbCr, NULL, err, errlen);
+  const int rc = read_impl(fp, NULL, 0, NULL, dim, quant, Y, CbCr, NULL, NULL, err, errlen);
   fclose(fp);
   return rc;
 }
@@ -161,7 +177,7 @@ int rgbnm_read_coefficients(const char* path, int32_t* dim, int16_t* quant, int1
 int rgbnm_read_coefficients_mem(const unsigned char* buf, size_t len, int32_t* dim, int16_t* quant, int16_t* Y,
                                 int16_t* CbCr, char* err, int errlen) {
   if (!buf || !dim || !quant || !Y) return RD_EARG;
-  return read_impl(NULL, buf, len, NULL, dim, quant, Y, CbCr, NULL, err, errlen);
+  return read_impl(NULL, buf, len, NULL, dim, quant, Y, CbCr, NULL, NULL, err, errlen);
 }
 
 /* ---- batch: n files of identical grid (e.g. 512x512 4:2:0 -> 64x64 / 32x32 blocks) decoded by `threads` pthreads
@@ -173,6 +189,8 @@ struct batch_job {
   int32_t expect[4];
   int16_t *Y, *CbCr, *quant;
   int32_t* status;
+  const int32_t* box;            /* [n][4] or NULL: crop boxes (packed output at yoff / coff) */
+  const int64_t *yoff, *coff;
   pthread_mutex_t mu;
 };
 
@@ -187,26 +205,53 @@ static void* batch_worker(void* arg) {
     int32_t dim[6];
     int16_t* q = j->quant + (size_t)i * 192;
     for (int k = 0; k < 192; ++k) q[k] = 1;
-    memset(j->CbCr + (size_t)i * csz, 0, csz * sizeof(int16_t));
+    const int32_t* bx = j->box ? j->box + 4 * (size_t)i : NULL;
+    int16_t* yd = bx ? j->Y + j->yoff[i] : j->Y + (size_t)i * ysz;
+    int16_t* cd = bx ? j->CbCr + j->coff[i] : j->CbCr + (size_t)i * csz;
+    memset(cd, 0, (bx ? (size_t)2 * (bx[2] / 2) * (bx[3] / 2) * 64 : csz) * sizeof(int16_t));
     FILE* fp = fopen(j->paths[i], "rb");
     if (!fp) {
       j->status[i] = RD_EOPEN;
       continue;
     }
-    j->status[i] = read_impl(fp, NULL, 0, NULL, dim, q, j->Y + (size_t)i * ysz, j->CbCr + (size_t)i * csz, j->expect,
-                             NULL, 0);
+    j->status[i] = read_impl(fp, NULL, 0, NULL, dim, q, yd, cd, j->expect, bx, NULL, 0);
     fclose(fp);
   }
   return NULL;
 }
 
+static int batch_run(struct batch_job* jp, int threads);
+
 int rgbnm_read_coefficients_batch(const char* const* paths, int n, int threads, int Hb, int Wb, int Hbc, int Wbc,
                                   int16_t* Y, int16_t* CbCr, int16_t* quant, int32_t* status) {
   if (!paths || n <= 0 || !Y || !CbCr || !quant || !status || Hb <= 0 || Wb <= 0) return RD_EARG;
   struct batch_job j;
-  j.paths = paths; j.n = n; j.next = 0;
+  j.paths = paths; j.n = n; j.next = 0; j.box = NULL; j.yoff = j.coff = NULL;
   j.expect[0] = Hb; j.expect[1] = Wb; j.expect[2] = Hbc; j.expect[3] = Wbc;
   j.Y = Y; j.CbCr = CbCr; j.quant = quant; j.status = status;
+  return batch_run(&j, threads);
+}
+
+/* The same with a crop box per file: only box[i] = (top, left, height, width) (luma blocks, even) of file i is copied, packed
+ * [height][width][64] at Ypacked + yoff[i] and [2][height/2][width/2][64] at Cpacked + coff[i] (element offsets chosen by the
+ * caller: typically the running sums of the box sizes, so that one H2D copy of the used prefix ships the whole batch). */
+int rgbnm_read_coefficients_batch_crop(const char* const* paths, int n, int threads, int Hb, int Wb, int Hbc, int Wbc,
+                                       const int32_t* box, const int64_t* yoff, const int64_t* coff, int16_t* Ypacked,
+                                       int16_t* Cpacked, int16_t* quant, int32_t* status) {
+  if (!paths || n <= 0 || !Ypacked || !Cpacked || !quant || !status || !box || !yoff || !coff || Hb <= 0 || Wb <= 0) return RD_EARG;
+  struct batch_job j;
+  j.paths = paths; j.n = n; j.next = 0; j.box = box; j.yoff = yoff; j.coff = coff;
+  j.expect[0] = Hb; j.expect[1] = Wb; j.expect[2] = Hbc; j.expect[3] = Wbc;
+  j.Y = Ypacked; j.CbCr = Cpacked; j.quant = quant; j.status = status;
+  return batch_run(&j, threads);
+}
+
+static int batch_run(struct batch_job* jp, int threads) {
+  struct batch_job j = *jp;
+  const int n = j.n;
+  int32_t* status = j.status;
+  /* (expect / buffers set by the caller) */
+  j.next = 0;
   pthread_mutex_init(&j.mu, NULL);
   if (threads < 1) threads = 1;
   if (threads > 256) threads = 256;

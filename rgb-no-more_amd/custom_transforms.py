@@ -653,12 +653,18 @@ class FastParamSampler:
         return out, nops
 
 
-def apply_packed(transform, Yq, CbCrq, quant, packed, nops):
-    """Run the augment kernels with an AUG_DTYPE array produced by FastParamSampler.sample()."""
+def apply_packed(transform, Yq, CbCrq, quant, packed, nops, y_off=None, c_off=None, grid=None):
+    """Run the augment kernels with an AUG_DTYPE array produced by FastParamSampler.sample().
+    y_off / c_off (device int64 (B,)) + grid=(Hy, Wy): Yq / CbCrq are the flat HOST-CROPPED buffers of
+    dct_manip.read_coefficients_batch_crop (image b's crop box alone at Yq[y_off[b]:]); same output, bit for bit."""
     t = transform
-    B, _, Hy, Wy, _, _ = Yq.shape
-    Hc, Wc = (CbCrq.shape[2], CbCrq.shape[3]) if CbCrq is not None else (Hy // 2, Wy // 2)
     dev = Yq.device
+    if y_off is None:
+        B, _, Hy, Wy, _, _ = Yq.shape
+        Hc, Wc = (CbCrq.shape[2], CbCrq.shape[3]) if CbCrq is not None else (Hy // 2, Wy // 2)
+    else:
+        B, (Hy, Wy) = len(packed), grid
+        Hc, Wc = (Hy + 1) // 2, (Wy + 1) // 2
     host = np.ascontiguousarray(packed)
     pdev = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
     if t._conv16 is None or t._conv16.device != dev:
@@ -670,9 +676,17 @@ def apply_packed(transform, Yq, CbCrq, quant, packed, nops):
         t._ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     oy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=t.out_dtype)
     oc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=t.out_dtype)
-    L.check(L.lib().rgbnm_dct_augment_ex(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
-                                         host.ctypes.data, t._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),
-                                         oc.data_ptr(), L.dt_of(t.out_dtype), S, B, Hy, Wy, Hc, Wc,
-                                         0 if t.eval_mode else 1, nops, t._ws.data_ptr(), t._ws.numel(), L.stream()),
-            "dct_augment")
+    if y_off is None:
+        L.check(L.lib().rgbnm_dct_augment_ex(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
+                                             host.ctypes.data, t._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),
+                                             oc.data_ptr(), L.dt_of(t.out_dtype), S, B, Hy, Wy, Hc, Wc,
+                                             0 if t.eval_mode else 1, nops, t._ws.data_ptr(), t._ws.numel(), L.stream()),
+                "dct_augment")
+    else:
+        L.require_cuda(y_off, c_off)
+        L.check(L.lib().rgbnm_dct_augment_packed(Yq.data_ptr(), L.ptr(CbCrq), y_off.data_ptr(), c_off.data_ptr(),
+                                                 quant.data_ptr(), pdev.data_ptr(), host.ctypes.data, t._conv16.data_ptr(),
+                                                 L.ptr(filt), oy.data_ptr(), oc.data_ptr(), L.dt_of(t.out_dtype), S, B, Hy, Wy,
+                                                 Hc, Wc, 0 if t.eval_mode else 1, nops, t._ws.data_ptr(), t._ws.numel(),
+                                                 L.stream()), "dct_augment_packed")
     return oy, oc

@@ -37,8 +37,11 @@ def lib():
                                                   C.c_void_p, C.c_char_p, C.c_int]
         L.rgbnm_read_coefficients_batch.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rgbnm_read_coefficients_batch_crop.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.c_void_p, C.c_void_p]
         for f in ("rgbnm_jpeg_info", "rgbnm_jpeg_info_mem", "rgbnm_read_coefficients", "rgbnm_read_coefficients_mem",
-                  "rgbnm_read_coefficients_batch"):
+                  "rgbnm_read_coefficients_batch", "rgbnm_read_coefficients_batch_crop"):
             getattr(L, f).restype = C.c_int
         _lib = L
     return _lib
@@ -146,3 +149,62 @@ def read_coefficients_batch(paths, threads=8, grid=(64, 64), pin_memory=False, o
             raise RuntimeError(f"Unable to open file for reading: {paths[i]}")
         raise libjpeg_exception(f"{paths[i]}: reader error {code} ({bad} of {n} files failed)")
     return Y, CbCr, quant
+
+
+def _raise_batch(paths, status, bad):
+    i = int((status != 0).nonzero()[0])
+    code = int(status[i])
+    if code == -1:
+        raise RuntimeError(f"Unable to open file for reading: {paths[i]}")
+    raise libjpeg_exception(f"{paths[i]}: reader error {code} ({bad} of {len(paths)} files failed)")
+
+
+def alloc_packed(n, grid=(64, 64), pin_memory=True):
+    """Staging buffers for read_coefficients_batch_crop(out=...): flat int16 Y / CbCr buffers sized for n WHOLE grids (a
+    batch of crops never needs more), quant (n,3,8,8)."""
+    hb, wb = grid
+    hbc, wbc = (hb + 1) // 2, (wb + 1) // 2
+    kw = dict(dtype=torch.int16, pin_memory=pin_memory)
+    return (torch.empty(n * hb * wb * 64, **kw), torch.empty(n * 2 * hbc * wbc * 64, **kw), torch.empty((n, 3, 8, 8), **kw))
+
+
+def packed_offsets(boxes):
+    """boxes int (n,4) = (top, left, height, width) in luma blocks -> element offsets of every image's crop in the flat Y /
+    CbCr buffers (running sums of the box sizes) and the totals: (y_off int64 (n,), c_off int64 (n,), n_y, n_c)."""
+    b = torch.as_tensor(boxes, dtype=torch.int64)
+    ysz = b[:, 2] * b[:, 3] * 64
+    csz = 2 * (b[:, 2] // 2) * (b[:, 3] // 2) * 64
+    y_off = torch.cumsum(ysz, 0) - ysz
+    c_off = torch.cumsum(csz, 0) - csz
+    return y_off.contiguous(), c_off.contiguous(), int(ysz.sum()), int(csz.sum())
+
+
+def read_coefficients_batch_crop(paths, boxes, threads=8, grid=(64, 64), pin_memory=False, out=None):
+    """Decode len(paths) same-grid JPEGs and keep only each file's crop box (luma blocks (top, left, height, width), all
+    even; the chroma box is the luma box halved), packed back to back: returns (Ypacked, Cpacked, quant, y_off, c_off) --
+    flat int16 buffers trimmed to the used length, image i's luma crop [h][w][8][8] at Ypacked[y_off[i]:], its chroma crop
+    [2][h/2][w/2][8][8] at Cpacked[c_off[i]:].  What crosses PCIe afterwards is the crop, not the 64 x 64 grid."""
+    L = lib()
+    n = len(paths)
+    hb, wb = grid
+    hbc, wbc = (hb + 1) // 2, (wb + 1) // 2
+    bx = torch.as_tensor(boxes, dtype=torch.int32).contiguous()
+    if tuple(bx.shape) != (n, 4):
+        raise ValueError("boxes must be (len(paths), 4)")
+    y_off, c_off, ny, ncc = packed_offsets(bx)
+    if out is None:
+        out = alloc_packed(n, grid, pin_memory)
+    Yp, Cp, quant = out
+    if Yp.numel() < ny or Cp.numel() < ncc or tuple(quant.shape)[1:] != (3, 8, 8) or quant.shape[0] < n or \
+            any(t.dtype != torch.int16 or not t.is_contiguous() for t in out):
+        raise ValueError("out buffers too small for this batch (use alloc_packed)")
+    status = torch.zeros(n, dtype=torch.int32)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    bad = L.rgbnm_read_coefficients_batch_crop(arr, n, int(threads), hb, wb, hbc, wbc, bx.data_ptr(), y_off.data_ptr(),
+                                               c_off.data_ptr(), Yp.data_ptr(), Cp.data_ptr(), quant.data_ptr(),
+                                               status.data_ptr())
+    if bad:
+        if int(status[(status != 0).nonzero()[0]]) == -3:
+            raise ValueError("crop box outside the coefficient grid (or not even)")
+        _raise_batch(paths, status, bad)
+    return Yp[:ny], Cp[:ncc], quant[:n], y_off, c_off

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "rgbnm_dct_augment_workspace_ex": (_sz, [_i, _i]),
     "rgbnm_dct_augment_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                   _sz, _vp]),
+    "rgbnm_dct_augment_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+                                      _i, _vp, _sz, _vp]),
     "rgbnm_softxent": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "rgbnm_mixup": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _vp]),
     "rgbnm_mixup_target": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

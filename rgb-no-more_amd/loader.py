@@ -20,6 +20,12 @@ transform (de-quantise + crop + resize + flip + RandAugment + ToRange) on the ra
 collate, no worker processes.  Sharding follows torch's DistributedSampler(shuffle, drop_last=False) index for index
 (seed + epoch permutation, padded by wrapping, rank-strided), so a run is reproducible against the reference's sampler.
 
+`crop_on_host=True` (train transform only): the crop boxes and the augmentation draws of a batch are sampled BEFORE its files
+are decoded, the reader copies only each file's crop box out of libjpeg's coefficient arrays, back to back into flat pinned
+buffers, and ONE H2D copy of the used prefix ships the batch: 787 KB -> ~380 KB per image on the sampler's mix of crop sides
+("768 KB/img raw coefficients also make PCIe the next limit -- crop on host before H2D, or ship only the crop
+box").  The kernels read the packed boxes in place (rgbnm_dct_augment_packed): same output bits as the whole-grid path.
+
 Everything except the H2D copy and the transform is host logic and runs (and is tested) without a GPU: with device="cpu"
 the loader yields the raw (Yq, CbCrq, quant) batches.  Files must share one coefficient grid (default 64 x 64 luma blocks =
 512 x 512, the pre-resized layout of the reference's dataset, README "resize to 512"); a file with another grid or an
@@ -35,7 +41,7 @@ from . import dct_manip as dm
 
 class DCTBatchLoader:
     def __init__(self, paths, labels, batch_size, device="cuda", grid=(64, 64), threads=None, prefetch=2, shuffle=True,
-                 seed=0, rank=0, world_size=1, drop_last=False, transform=None):
+                 seed=0, rank=0, world_size=1, drop_last=False, transform=None, crop_on_host=False):
         if len(paths) != len(labels):
             raise ValueError("paths and labels differ in length")
         if batch_size <= 0 or prefetch < 1:
@@ -46,6 +52,13 @@ class DCTBatchLoader:
         self.shuffle, self.seed, self.rank, self.world_size, self.drop_last = shuffle, seed, rank, world_size, drop_last
         self.device = torch.device(device)
         self.transform = transform
+        self.crop_on_host = bool(crop_on_host)
+        if self.crop_on_host:
+            from . import custom_transforms as CT
+            if not isinstance(transform, CT.TrainTransform_DCT) or transform.eval_mode or self.device.type != "cuda":
+                raise ValueError("crop_on_host needs the fused train transform (TrainTransform_DCT) and a HIP device: the crop "
+                                 "boxes are drawn before the decode; the eval transform reads the whole grid")
+        self.last_packed = None        # crop_on_host: the (packed parameters, nops) of the batch yielded last (tests)
         self.epoch = 0
         n = len(self.paths)
         # DistributedSampler(drop_last=False): every rank gets ceil(n / world) indices, the list is padded by wrapping
@@ -81,7 +94,8 @@ class DCTBatchLoader:
     def _buffers(self):
         if self._ring is None:
             pin = self.device.type == "cuda"
-            self._ring = [dm.alloc_batch(self.batch_size, self.grid, pin_memory=pin) for _ in range(self.prefetch + 2)]
+            alloc = dm.alloc_packed if self.crop_on_host else dm.alloc_batch
+            self._ring = [alloc(self.batch_size, self.grid, pin_memory=pin) for _ in range(self.prefetch + 2)]
         return self._ring
 
     def __iter__(self):
@@ -91,6 +105,11 @@ class DCTBatchLoader:
         ring = self._buffers()
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
+        sampler = None
+        if self.crop_on_host:
+            from . import custom_transforms as CT
+            # one stream of draws per (seed, epoch, rank): the producer samples a batch's parameters before decoding it
+            sampler = CT.FastParamSampler(self.transform, seed=[self.seed, self.epoch, self.rank])
 
         def producer():
             try:
@@ -98,9 +117,15 @@ class DCTBatchLoader:
                     if stop.is_set():
                         return
                     buf = ring[k % len(ring)]
-                    view = tuple(t[:len(bi)] for t in buf)          # the last batch of an epoch may be short
-                    out = dm.read_coefficients_batch([self.paths[i] for i in bi], threads=self.threads, grid=self.grid, out=view)
-                    item = (out, self.labels[bi])
+                    if sampler is not None:
+                        packed, nops = sampler.sample(len(bi), self.grid[0], self.grid[1])
+                        Yp, Cp, Qp, yo, co = dm.read_coefficients_batch_crop([self.paths[i] for i in bi], packed["crop"],
+                                                                             threads=self.threads, grid=self.grid, out=buf)
+                        item = ((Yp, Cp, Qp, yo, co, packed, nops), self.labels[bi])
+                    else:
+                        view = tuple(t[:len(bi)] for t in buf)          # the last batch of an epoch may be short
+                        out = dm.read_coefficients_batch([self.paths[i] for i in bi], threads=self.threads, grid=self.grid, out=view)
+                        item = (out, self.labels[bi])
                     while not stop.is_set():
                         try:
                             q.put(item, timeout=0.1)
@@ -121,6 +146,19 @@ class DCTBatchLoader:
                     return
                 if isinstance(item, BaseException):
                     raise item
+                if sampler is not None:
+                    from . import custom_transforms as CT
+                    (Yp, Cp, Qp, yo, co, packed, nops), lab = item
+                    with torch.cuda.stream(copy_stream):
+                        dev = [t.to(self.device, non_blocking=True) for t in (Yp, Cp, Qp, yo.pin_memory(), co.pin_memory(), lab)]
+                    copy_stream.synchronize()          # the pinned buffers go back to the decoder ring after this
+                    for t in dev:
+                        t.record_stream(torch.cuda.current_stream(self.device))
+                    self.last_packed = (packed, nops)
+                    self.h2d_bytes = 2 * (Yp.numel() + Cp.numel())
+                    yield tuple(CT.apply_packed(self.transform, dev[0], dev[1], dev[2], packed, nops, y_off=dev[3], c_off=dev[4],
+                                                grid=self.grid)), dev[5]
+                    continue
                 (Y, C, Q), lab = item
                 if copy_stream is None:
                     yield self._finish(Y.clone(), C.clone(), Q.clone(), lab)     # host buffers are recycled: hand out copies

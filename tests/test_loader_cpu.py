@@ -89,3 +89,24 @@ def test_errors_name_the_file_and_stop_the_decoder(files, tmp_path):
     assert threading.active_count() <= before + 0
     with pytest.raises(ValueError):
         DCTBatchLoader(paths, labels[:-1], batch_size=2)
+
+
+def test_cropped_batch_read_is_a_slice_of_the_full_read(files):
+    """rgbnm_read_coefficients_batch_crop: only each file's crop box leaves libjpeg's coefficient arrays, packed back to
+    back -- and it is exactly the slice [top:top+h, left:left+w] of what the whole-grid reader returns (chroma: halved box)."""
+    paths, _, g = files
+    Y, C, Q = dm.read_coefficients_batch(paths[:5], threads=2, grid=(8, 8))
+    boxes = [(0, 0, 8, 8), (2, 4, 4, 4), (6, 0, 2, 8), (0, 6, 8, 2), (4, 2, 2, 2)]
+    Yp, Cp, Qp, yo, co = dm.read_coefficients_batch_crop(paths[:5], boxes, threads=3, grid=(8, 8))
+    assert torch.equal(Q, Qp)
+    assert Yp.numel() == sum(h * w * 64 for _, _, h, w in boxes) and Cp.numel() == sum(2 * (h // 2) * (w // 2) * 64 for _, _, h, w in boxes)
+    for b, (i, j, h, w) in enumerate(boxes):
+        y = Yp[int(yo[b]):int(yo[b]) + h * w * 64].view(h, w, 8, 8)
+        c = Cp[int(co[b]):int(co[b]) + 2 * (h // 2) * (w // 2) * 64].view(2, h // 2, w // 2, 8, 8)
+        assert torch.equal(y, Y[b, 0, i:i + h, j:j + w]), b
+        assert torch.equal(c, C[b, :, i // 2:(i + h) // 2, j // 2:(j + w) // 2]), b
+    for bad in ((1, 0, 2, 2), (0, 0, 10, 2), (0, 8, 2, 2), (0, 0, 0, 2)):       # odd / outside the 8 x 8 grid / empty
+        with pytest.raises(ValueError):
+            dm.read_coefficients_batch_crop(paths[:1], [bad], grid=(8, 8))
+    with pytest.raises(ValueError):
+        DCTBatchLoader(paths, list(range(11)), batch_size=4, device="cpu", grid=(8, 8), crop_on_host=True)

@@ -44,3 +44,37 @@ def test_loader_feeds_the_fused_eval_transform(tmp_path):
         assert Y.dtype == torch.bfloat16 and float(Y.float().abs().max()) <= 1.0 and torch.isfinite(C.float()).all()
         n += Y.shape[0]
     assert n == 10
+
+
+def test_crop_on_host_ships_the_crop_and_gives_the_same_bits(tmp_path):
+    """crop_on_host=True: the crop boxes are drawn before the decode, only the boxes cross PCIe (packed back to back), the
+    augment kernels read them in place -- and every output equals the whole-grid path run with the same parameters."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    paths, labels = [], []
+    for i in range(24):
+        small = rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)
+        img = np.asarray(PIL.fromarray(small).resize((512, 512), PIL.BICUBIC), dtype=np.float32)
+        img = np.clip(img + rng.normal(0, 8, img.shape), 0, 255).astype(np.uint8)
+        p = tmp_path / f"c{i}.jpg"
+        if i % 7 == 3:
+            PIL.fromarray(img[..., 0]).save(str(p), quality=90)                  # a grayscale file: zero chroma
+        else:
+            PIL.fromarray(img).save(str(p), quality=90, subsampling="4:2:0")
+        paths.append(str(p))
+        labels.append(i)
+    tr = rg.datasets.get_transform("imagenet_dct", "train", ops_list=CT.VITTI_OPS, ops_magnitude=3, dtype=torch.float32, fused=True)
+    ld = DCTBatchLoader(paths, labels, batch_size=8, device="cuda", threads=4, seed=5, shuffle=False, transform=tr, crop_on_host=True)
+    seen, sides, shipped = 0, set(), 0
+    for (Y, C), lab in ld:
+        packed, nops = ld.last_packed
+        li = lab.tolist()
+        Yf, Cf, Qf = dm.read_coefficients_batch([paths[i] for i in li], threads=4)
+        wy, wc = CT.apply_packed(tr, Yf.cuda(), Cf.cuda(), Qf.cuda(), packed, nops)
+        assert torch.equal(Y, wy) and torch.equal(C, wc)
+        sides |= set(packed["crop"][:, 2].tolist())
+        shipped += ld.h2d_bytes
+        seen += len(li)
+    assert seen == 24 and len(sides) >= 2
+    assert shipped < 0.8 * seen * (64 * 64 + 2 * 32 * 32) * 128, shipped           # less than the whole grids (787 KB each)
+    print(f"crop_on_host: {shipped / seen / 1024:.0f} KB per image shipped (whole grid: 768 KB), crop sides {sorted(sides)}")
