@@ -24,6 +24,12 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
 int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
                            int N, int heads, float scale, hipStream_t st);
 
+// attention forward + output projection + residual + LayerNorm of one ViT block in one launch (attention_v2.hip: 196 tokens,
+// 3 heads, bf16); 1 = not eligible.
+int rgbnm_launch_attn_proj_fwd(const void* qkv, void* out, float* lse, const void* Wp, const float* bp, const void* R, void* X,
+                               const float* gamma, const float* beta, void* Y2, float* mean, float* rstd, float eps, int B, int N,
+                               int heads, float scale, hipStream_t st);
+
 // per-kernel HIP-event tracing (vit.hip); tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd
 enum { TR_NT = 1, TR_TN = 2, TR_ATTN_FWD = 3, TR_ATTN_BWD = 4 };
 // Weight-resident K = 192 bf16 NT GEMM (gemm_nt_wres.hip).  Returns RGBNM_OK / error, or 1 if the shape is not eligible.

@@ -306,3 +306,38 @@ def test_row_panel_gemm_two_workgroups_per_cu_equals_one():
             assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), n
         else:
             assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("tag", ["ti_d2_b64", "ti_d12_b256"])
+def test_fused_attention_projection_equals_the_separate_launches(tag):
+    """attn3_proj_fwd_kernel (option attn_proj, default off: measured slower): attention of the three heads of an image, the
+    output projection, the residual add and LayerNorm 2 in one launch -- same operand rounding, same k order, same row
+    arithmetic as attn3_fwd + gemm_nt_kpipe<EPI_RES_LN>, so the saved attention output, the log-sum-exp, x_mid, LN2's output and
+    statistics, the logits and every gradient agree bit for bit."""
+    lib = L.lib()
+    m, sd, y, c, tgt = build(tag, torch.bfloat16)
+    m.train()
+
+    def snapshot():
+        m.zero_grad()
+        logits = m(y, c)
+        ar = logits.grad_fn.st.arena
+        torch.cuda.synchronize()
+        b0, bl = ar.blk[0], ar.blk[-1]
+        snap = {"attn0": b0["attn"].clone(), "lse0": b0["lse"].clone(), "x_mid0": b0["x_mid"].clone(), "xn2_0": b0["xn2"].clone(),
+                "mean2_0": b0["mean2"].clone(), "rstd2_0": b0["rstd2"].clone(), "x_mid_last": bl["x_mid"].clone(),
+                "logits": logits.detach().clone()}
+        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
+        snap["grads"] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+        return snap
+
+    old = lib.rgbnm_get_option(b"attn_proj")
+    try:
+        L.check(lib.rgbnm_set_option(b"attn_proj", 0))
+        plain = snapshot()
+        L.check(lib.rgbnm_set_option(b"attn_proj", 1))
+        fused = snapshot()
+    finally:
+        L.check(lib.rgbnm_set_option(b"attn_proj", old))
+    for k in fused:
+        assert torch.equal(fused[k], plain[k]), k
