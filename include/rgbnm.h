@@ -337,6 +337,9 @@ typedef struct rgbnm_head_grads {
 } rgbnm_head_grads;
 int rgbnm_head_fwd(const rgbnm_vit_cfg* cfg, const rgbnm_head_params* p, const rgbnm_head_acts* a, void* stream);
 /* dlogits [B,C] in cfg->dtype; da, dpooled: [B,E] scratch; dx [M,E] out. */
+/* Workspace that lets rgbnm_head_bwd keep its three sets of split partial sums side by side (needed when the call sits inside
+ * a rgbnm_reduce_hold_begin / _end bracket; with less -- rgbnm_vit_workspace_ex -- they re-use one region, outside a bracket). */
+size_t rgbnm_head_bwd_workspace(const rgbnm_vit_cfg* cfg, int n_classes);
 int rgbnm_head_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_head_params* p, const rgbnm_head_acts* a,
                    const rgbnm_head_grads* g, const void* dlogits, void* da, void* dpooled, void* dx, void* ws,
                    size_t ws_bytes, void* stream);

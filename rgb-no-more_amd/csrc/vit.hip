@@ -313,17 +313,31 @@ int rgbnm_head_fwd(const rgbnm_vit_cfg* c, const rgbnm_head_params* p, const rgb
   return RGBNM_OK;
 }
 
+size_t rgbnm_head_bwd_workspace(const rgbnm_vit_cfg* c, int n_classes) {
+  if (!c) return 0;
+  return ((rgbnm_gemm_tn_workspace(c->B, n_classes, c->E) + 255) & ~(size_t)255) + ((rgbnm_gemm_tn_workspace(c->B, c->E, c->E) + 255) & ~(size_t)255) +
+         (size_t)c->B * 2 * c->E * sizeof(float);
+}
+
 int rgbnm_head_bwd(const rgbnm_vit_cfg* c, const rgbnm_head_params* p, const rgbnm_head_acts* a,
                    const rgbnm_head_grads* g, const void* dlogits, void* da, void* dpooled, void* dx, void* ws,
                    size_t ws_bytes, void* st) {
   if (!c || !p || !a || !g || !dlogits || !da || !dpooled || !dx) return RGBNM_EINVAL;
   const int dt = c->dtype, E = c->E, C = p->n_classes, B = c->B;
-  TRY(rgbnm_gemm_tn(dt, dlogits, C, a->h1, E, g->dw2, g->db2, B, C, E, 0, 0, ws, ws_bytes, st));
+  // three split-sum producers: side by side when the workspace has room for all of them (rgbnm_head_bwd_workspace: required
+  // inside a held-reduction bracket, where the partial sums live until rgbnm_reduce_hold_end), else one after the other in place
+  const size_t s1 = (rgbnm_gemm_tn_workspace(B, C, E) + 255) & ~(size_t)255, s2 = (rgbnm_gemm_tn_workspace(B, E, E) + 255) & ~(size_t)255;
+  const size_t s3 = (size_t)B * 2 * E * sizeof(float);
+  const bool apart = ws_bytes >= s1 + s2 + s3;
+  char* w1 = (char*)ws;
+  char* w2 = apart ? w1 + s1 : w1;
+  char* w3 = apart ? w2 + s2 : w1;
+  const size_t b1 = apart ? s1 : ws_bytes, b2 = apart ? s2 : ws_bytes, b3 = apart ? ws_bytes - s1 - s2 : ws_bytes;
+  TRY(rgbnm_gemm_tn(dt, dlogits, C, a->h1, E, g->dw2, g->db2, B, C, E, 0, 0, w1, b1, st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DTANH, dlogits, C, p->w2_t, C, da, E, 0, a->h1, E, 0, 0, 0, 0, B, E, C, 0, st));
-  TRY(rgbnm_gemm_tn(dt, da, E, a->pooled, E, g->dw1, g->db1, B, E, E, 0, 0, ws, ws_bytes, st));
+  TRY(rgbnm_gemm_tn(dt, da, E, a->pooled, E, g->dw1, g->db1, B, E, E, 0, 0, w2, b2, st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, da, E, p->w1_t, E, dpooled, E, 0, 0, 0, 0, 0, 0, 0, B, E, E, 0, st));
-  TRY(rgbnm_head_pool_bwd(dt, dpooled, a->x, p->ln_g, a->mean, a->rstd, dx, g->dln_g, g->dln_b, B, c->N, E, 0, ws,
-                          ws_bytes, st));
+  TRY(rgbnm_head_pool_bwd(dt, dpooled, a->x, p->ln_g, a->mean, a->rstd, dx, g->dln_g, g->dln_b, B, c->N, E, 0, w3, b3, st));
   return RGBNM_OK;
 }
 

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "rgbnm_clip_adamw_wd_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _sz, _vp]),
     "rgbnm_vit_workspace": (_sz, [_P(VitCfg)]),
     "rgbnm_vit_workspace_ex": (_sz, [_P(VitCfg), _i]),
+    "rgbnm_head_bwd_workspace": (_sz, [_vp, _i]),
     "rgbnm_gelu_table_init": (_i, [_vp]),
     "rgbnm_gelu_table_info": (_i, [_vp, _vp]),
     "rgbnm_reduce_hold_begin": (_i, []),

@@ -172,7 +172,7 @@ class _Arena:
             self.scratch = L.BlockScratch(self.du.data_ptr(), self.dxn.data_ptr(), self.dx_mid.data_ptr(),
                                           self.dattn.data_ptr(), self.dqkv.data_ptr(), self.ws.data_ptr(), ws_bytes)
         self.ws_bytes = ws_bytes
-        self.ws_blk = self.hold_table = self.hold_table_host = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
+        self.ws_blk = self.ws_head = self.hold_table = self.hold_table_host = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
         self.acts = []
         for i in range(D):
             b = self.blk[i if need_grad else 0]
@@ -212,6 +212,8 @@ class _FwdState:
             return                                     # a frozen patch embedding has no backward node to close the bracket
         if a.ws_blk is None:                           # the partial sums of every block now live until the end of the pass
             a.ws_blk = torch.empty(m.depth * a.ws_bytes, device=a.ws.device, dtype=torch.uint8)
+            # ... and the head's three producers side by side (a.ws stays the patch embedding's)
+            a.ws_head = torch.empty(L.lib().rgbnm_head_bwd_workspace(C.byref(a.cfg), m.n_classes), device=a.ws.device, dtype=torch.uint8)
             a.hold_table = torch.zeros(L.lib().rgbnm_reduce_hold_table_bytes(), device=a.ws.device, dtype=torch.uint8)
             # host record of what hold_table holds: allocated and freed WITH it (rgbnm.h), so a recycled device address
             # never inherits somebody else's "already uploaded"
@@ -268,12 +270,18 @@ class _PatchEmbedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx0):
         st = ctx.st
-        st.end_hold()          # held reductions of the encoder blocks run now (before this node's own, and before the exchange)
         m, a = st.model, st.arena
         dx0 = dx0.contiguous()
         gw, gb = m._gview(st.gbuf, "patchembed.projection.0.weight"), m._gview(st.gbuf, "patchembed.projection.0.bias")
-        L.check(L.lib().rgbnm_patch_embed_bwd(C.byref(a.cfg), dx0.data_ptr(), a.feat.data_ptr(), gw.data_ptr(),
-                                              gb.data_ptr(), a.ws.data_ptr(), a.ws_bytes, L.stream()), "patch_embed_bwd")
+        # held reductions (head, encoder blocks and this node's own: a.ws is no other node's region) run as ONE launch now, before
+        # the exchange
+        try:
+            L.check(L.lib().rgbnm_patch_embed_bwd(C.byref(a.cfg), dx0.data_ptr(), a.feat.data_ptr(), gw.data_ptr(),
+                                                  gb.data_ptr(), a.ws.data_ptr(), a.ws_bytes, L.stream()), "patch_embed_bwd")
+        except BaseException:
+            st.cancel_hold()
+            raise
+        st.end_hold()
         if m._grad_sync is not None:            # last gradients of the step: flush the exchange (parallel.py)
             m._grad_sync.ready(st.gbuf, ["patchembed.projection.0.weight", "patchembed.projection.0.bias"], last=True)
         return None, None, None, gw, gb
@@ -513,12 +521,17 @@ class _HeadFn(torch.autograd.Function):
         grads = [m._gview(st.gbuf, n) for n in names]
         g = L.HeadGrads(*[t.data_ptr() for t in grads])
         dx = a.dx[0]
-        L.check(L.lib().rgbnm_head_bwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(ctx.acts), C.byref(g),
-                                       dl.data_ptr(), a.da.data_ptr(), a.dpooled.data_ptr(), dx.data_ptr(),
-                                       a.ws.data_ptr(), a.ws_bytes, L.stream()), "head_bwd")
-        if m._grad_sync is not None:
-            m._grad_sync.ready(st.gbuf, names)
-        st.begin_hold()
+        st.begin_hold()            # the bracket opens in front of the head: its own split sums join the one launch at the end
+        ws = a.ws_head if st.holding else a.ws
+        try:
+            L.check(L.lib().rgbnm_head_bwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(ctx.acts), C.byref(g),
+                                           dl.data_ptr(), a.da.data_ptr(), a.dpooled.data_ptr(), dx.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), L.stream()), "head_bwd")
+            if m._grad_sync is not None:
+                m._grad_sync.ready(st.gbuf, names)
+        except BaseException:
+            st.cancel_hold()
+            raise
         by_name = dict(zip(names, grads))
         return (dx, None) + tuple(by_name[n] for n in m._head_param_order)
 

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--threads", type=int, default=dm.default_threads())
+    ap.add_argument("--crop-on-host", type=int, default=1, help="1: only the crop boxes cross PCIe (loader crop_on_host)")
     a = ap.parse_args()
     dev = "cuda:0"
     torch.cuda.set_device(0)
@@ -74,14 +75,18 @@ def main():
     from rgb_no_more_amd.loader import DCTBatchLoader
     nb = a.warmup + a.steps + 4
     loader = DCTBatchLoader([batch_paths[i % B] for i in range(nb * B)], [int(v) for v in torch.randint(0, 999, (nb * B,))], B,
-                            device=dev, threads=a.threads, prefetch=2, shuffle=False)
+                            device=dev, threads=a.threads, prefetch=2, shuffle=False,
+                            transform=aug if a.crop_on_host else None, crop_on_host=bool(a.crop_on_host))
     it = iter(loader)
 
     def step():
-        (Yd, Cd, Qd), labd = next(it)
         opt.zero_grad(set_to_none=True)
-        packed, nops = sampler.sample(B, 64, 64)
-        y, c = CT.apply_packed(aug, Yd, Cd, Qd, packed, nops)
+        if a.crop_on_host:
+            (y, c), labd = next(it)
+        else:
+            (Yd, Cd, Qd), labd = next(it)
+            packed, nops = sampler.sample(B, 64, 64)
+            y, c = CT.apply_packed(aug, Yd, Cd, Qd, packed, nops)
         (my, mc), mt = mix((y, c), labd)
         loss = rg.cls_transforms.cross_entropy(model(my, mc), mt, grad_dtype=torch.bfloat16)
         loss.backward()
@@ -101,7 +106,8 @@ def main():
            "value": round(B * a.steps / dt, 1), "unit": "images/sec", "n_gpus": 1, "steps": a.steps,
            "ms_per_step": round(1e3 * dt / a.steps, 3), "per_gpu_batch": B, "host_threads": a.threads,
            "host_decode_only_images_per_sec": round(dec, 1), "avg_jpeg_bytes": round(fsize),
-           "h2d_bytes_per_image": 64 * 64 * 64 * 2 + 2 * 32 * 32 * 64 * 2 + 3 * 64 * 2,
+           "h2d_bytes_per_image": round(loader.h2d_bytes / B) if a.crop_on_host else 64 * 64 * 64 * 2 + 2 * 32 * 32 * 64 * 2 + 3 * 64 * 2,
+           "crop_on_host": bool(a.crop_on_host),
            "loss": round(float(loss.item()), 4),
            "note": "one process; decoder thread (pthread pool inside librgbnm_reader.so, GIL released) runs two batches "
                    "ahead; bounded by the host Huffman decode when value ~ host_decode_only"}
