@@ -26,7 +26,10 @@ constexpr int A_ROW = 256, B_ROW = 384;        // bytes per token row (128 / 192
 constexpr int A_STAGE = TK * A_ROW;            // 16 KB
 constexpr int B_STAGE = TK * B_ROW;            // 24 KB
 constexpr int STAGE = A_STAGE + B_STAGE;       // 40 KB
-constexpr int NSTAGE = 3;
+#ifndef TN_NSTAGE
+#define TN_NSTAGE 3
+#endif
+constexpr int NSTAGE = TN_NSTAGE;              // 3: two tiles (80 KB) in flight; 4: three (120 KB), all 160 KB of LDS
 constexpr int SMEM = NSTAGE * STAGE;           // 120 KB
 
 struct TnPipe {
@@ -154,17 +157,19 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   for (int e = 0; e < 8; ++e) ones.v[e] = (bf16)1.0f;
 
   int st_issue = 0, st_comp = 0;
-  issue(0);
-  st_issue = 1;
-  if (T > 1) {
-    issue(1);
-    st_issue = 2;
-  }
+#pragma unroll
+  for (int i = 0; i < NSTAGE - 1; ++i)
+    if (i < T) {
+      issue(i);
+      st_issue = i + 1 == NSTAGE ? 0 : i + 1;
+    }
   for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    // tile t landed; NSTAGE - 2 younger tiles (5 DMA instructions each) may stay in flight
+    if (NSTAGE >= 4 && t + 2 < T) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // tile t landed for every wave; every wave is done with tile t-1
-    if (t + 2 < T) {
+    if (t + NSTAGE - 1 < T) {
       issue(st_issue);
       st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
     }
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
 constexpr int Q_ROW = 384;
 constexpr int Q_HALF = TK * Q_ROW;             // 24 KB per operand per stage
 constexpr int Q_STAGE = 2 * Q_HALF;            // 48 KB
-constexpr int Q_SMEM = NSTAGE * Q_STAGE;       // 144 KB
+constexpr int Q_NSTAGE = 3;
+constexpr int Q_SMEM = Q_NSTAGE * Q_STAGE;     // 144 KB
 
 template <int C>
 __device__ __forceinline__ void tr_chunk_q(unsigned aA0, unsigned aA1, unsigned aB0, unsigned aB1, unsigned aB2,
@@ -321,10 +327,10 @@ __global__ __launch_bounds__(384) void gemm_tn_pipe_q_kernel(TnPipe p) {
     __builtin_amdgcn_s_barrier();     // tile t landed for every wave; every wave is done with tile t-1
     if (t + 2 < T) {
       issue(st_issue);
-      st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
+      st_issue = st_issue == Q_NSTAGE - 1 ? 0 : st_issue + 1;
     }
     const unsigned sb = lds0 + st_comp * Q_STAGE;
-    st_comp = st_comp == NSTAGE - 1 ? 0 : st_comp + 1;
+    st_comp = st_comp == Q_NSTAGE - 1 ? 0 : st_comp + 1;
     Frag<bf16> fa[2], fb[3];
 #define CHUNKQ(C)                                                              \
     tr_chunk_q<C>(sb + oA0, sb + oA1, sb + oB0, sb + oB1, sb + oB2, fa, fb);   \
