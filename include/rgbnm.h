@@ -87,6 +87,9 @@ typedef struct rgbnm_linear_desc {
   int N, K;
   int perm_heads;      /* >0 for the qkv Linear: number of heads                      */
   int add_identity;    /* shadows hold W + I (residual Linear y = x W^T + x, plainvit.py:345-347) */
+  int ldn;             /* row stride of the [K,N] shadow; 0 = N.  > N pads N for 16-byte rows (a class count that is not a
+                          multiple of 8: the [N,K] shadow then has ldn rows too, the extra ones left as the caller zeroed them) */
+  int reserved;
 } rgbnm_linear_desc;
 
 /* master fp32 -> per-step operand shadows for every Linear (descs_dev: device array of ndesc descriptors). */

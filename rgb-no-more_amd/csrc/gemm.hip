@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + ty + 8 * k, r = r0 + tx;
-      if (r < d.N && c < d.K) shadow[d.wst_off + (size_t)c * d.N + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+      if (r < d.N && c < d.K) shadow[d.wst_off + (size_t)c * (d.ldn > 0 ? d.ldn : d.N) + r] = from_f32<T>(tile[tx][ty + 8 * k]);
     }
     __syncthreads();
   }

@@ -505,33 +505,50 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, st, *params):
         m, a = st.model, st.arena
-        logits = torch.empty(a.B, m.n_classes, device=x.device, dtype=torch.float32)
+        logits = torch.empty(a.B, m._ncls_pad, device=x.device, dtype=torch.float32)
         acts = L.HeadActs(x.data_ptr(), a.hmean.data_ptr(), a.hrstd.data_ptr(), a.pooled.data_ptr(),
                           a.h1.data_ptr(), logits.data_ptr())
         L.check(L.lib().rgbnm_head_fwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(acts), L.stream()), "head_fwd")
         ctx.st, ctx.acts, ctx.x = st, acts, x
-        return logits
+        return logits if m._ncls_pad == m.n_classes else logits[:, :m.n_classes].contiguous()
 
     @staticmethod
     def backward(ctx, dlogits):
         st = ctx.st
         m, a = st.model, st.arena
-        dl = dlogits.to(a.cdtype).contiguous()
         names = m._head_names
         grads = [m._gview(st.gbuf, n) for n in names]
-        g = L.HeadGrads(*[t.data_ptr() for t in grads])
+        padded = m._ncls_pad != m.n_classes
+        if padded:                 # zero columns for the padded classes; dW2 / db2 land in padded buffers and are cut below
+            dl = torch.zeros(a.B, m._ncls_pad, device=dlogits.device, dtype=a.cdtype)
+            dl[:, :m.n_classes].copy_(dlogits)
+            dw2p = torch.empty(m._ncls_pad, m.emb_size, device=dlogits.device, dtype=torch.float32)
+            db2p = torch.empty(m._ncls_pad, device=dlogits.device, dtype=torch.float32)
+            ptrs = [t.data_ptr() for t in grads]
+            ptrs[names.index("classhead.ch_linear2.weight")] = dw2p.data_ptr()
+            ptrs[names.index("classhead.ch_linear2.bias")] = db2p.data_ptr()
+            g = L.HeadGrads(*ptrs)
+        else:
+            dl = dlogits.to(a.cdtype).contiguous()
+            g = L.HeadGrads(*[t.data_ptr() for t in grads])
         dx = a.dx[0]
-        st.begin_hold()            # the bracket opens in front of the head: its own split sums join the one launch at the end
+        if not padded:
+            st.begin_hold()        # the bracket opens in front of the head: its own split sums join the one launch at the end
         ws = a.ws_head if st.holding else a.ws
         try:
             L.check(L.lib().rgbnm_head_bwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(ctx.acts), C.byref(g),
                                            dl.data_ptr(), a.da.data_ptr(), a.dpooled.data_ptr(), dx.data_ptr(),
                                            ws.data_ptr(), ws.numel(), L.stream()), "head_bwd")
+            if padded:             # (the padded head reduces at once: its gradients are cut out of the padded buffers here)
+                grads[names.index("classhead.ch_linear2.weight")].copy_(dw2p[:m.n_classes])
+                grads[names.index("classhead.ch_linear2.bias")].copy_(db2p[:m.n_classes])
             if m._grad_sync is not None:
                 m._grad_sync.ready(st.gbuf, names)
         except BaseException:
             st.cancel_hold()
             raise
+        if padded:
+            st.begin_hold()
         by_name = dict(zip(names, grads))
         return (dx, None) + tuple(by_name[n] for n in m._head_param_order)
 
@@ -564,11 +581,13 @@ class ViT(FlatParamModule):
             raise NotImplementedError("HIP kernels cover head_size 64 and emb_size 192/384 (JPEG-Ti / JPEG-S)")
         if dtype != torch.float32:
             raise NotImplementedError("parameters are fp32 masters; choose bf16 compute with autocast")
-        if n_classes < 8 or n_classes % 8:
-            raise NotImplementedError(f"n_classes = {n_classes}: the head GEMMs move 16-byte rows, so the class count must "
-                                      "be a multiple of 8 (ImageNet-1k: 1000)")
+        if n_classes < 1:
+            raise ValueError("n_classes must be positive")
         self.pixel_space = pixel_space
         self.emb_size, self.depth, self.n_classes = emb_size, depth, n_classes
+        # the head GEMMs move 16-byte rows: a class count that is not a multiple of 8 is padded INSIDE (operand shadows, bias,
+        # logits and their gradient carry zero columns; parameters, state_dict and the returned logits keep the real count)
+        self._ncls_pad = (n_classes + 7) // 8 * 8
         self.num_heads, self.inner = num_heads, num_heads * head_size
         self.n_tokens = 294 if ver == 3 else 196          # ver 3: 14x14 luma + 2 x 7x7 chroma tokens
         E = emb_size
@@ -631,13 +650,14 @@ class ViT(FlatParamModule):
         self._sh_off, so, bo = {}, 0, 0
         for k, (key, name, ph) in enumerate(lin):
             Nn, Kk = self._shapes[name + ".weight"]
-            ws, wst = so, so + _align(Nn * Kk)
-            so = wst + _align(Nn * Kk)
+            Np = self._ncls_pad if key == "h2" else Nn          # shadow rows / transposed-shadow stride (padded class count)
+            ws, wst = so, so + _align(Np * Kk)
+            so = wst + _align(Np * Kk)
             bp = bo
             if ph:
                 bo += _align(Nn)
             descs[k] = L.LinearDesc(offs[name + ".weight"], offs[name + ".bias"], ws, wst, bp, Nn, Kk, ph,
-                                    1 if key == "peM" else 0)
+                                    1 if key == "peM" else 0, Np if Np != Nn else 0, 0)
             self._sh_off[key] = (ws, wst, bp)
         self._ndesc, self._sh_total = len(lin), so
         self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
@@ -739,12 +759,17 @@ class ViT(FlatParamModule):
                     self._sh_ptr(f"proj{i}", "ws"), self._sh_ptr(f"proj{i}", "wst"),
                     self._sh_ptr(f"fc1{i}", "ws"), self._sh_ptr(f"fc1{i}", "wst"),
                     self._sh_ptr(f"fc2{i}", "ws"), self._sh_ptr(f"fc2{i}", "wst")))
+            if self._ncls_pad != self.n_classes and getattr(self, "_b2pad", None) is None:
+                self._b2pad = torch.zeros(self._ncls_pad, device=self._flat.device, dtype=torch.float32)
+            b2 = self._b2pad.data_ptr() if self._ncls_pad != self.n_classes else self._pptr("classhead.ch_linear2.bias")
             hp = L.HeadParams(self._pptr("classhead.ch_lrnorm.weight"), self._pptr("classhead.ch_lrnorm.bias"),
-                              self._pptr("classhead.ch_linear1.bias"), self._pptr("classhead.ch_linear2.bias"),
+                              self._pptr("classhead.ch_linear1.bias"), b2,
                               self._sh_ptr("h1", "ws"), self._sh_ptr("h1", "wst"), self._sh_ptr("h2", "ws"),
-                              self._sh_ptr("h2", "wst"), self.n_classes, 0)
+                              self._sh_ptr("h2", "wst"), self._ncls_pad, 0)
             self._bparams_by_dtype[cdtype] = (bps, hp)
         self._bparams, self._hparams = self._bparams_by_dtype[cdtype]
+        if self._ncls_pad != self.n_classes:
+            self._b2pad[:self.n_classes].copy_(self._named["classhead.ch_linear2.bias"].detach())
 
     # ---------------------------------------------------------------- arenas
     def _acquire_arena(self, B, cdtype, need_grad):

@@ -437,3 +437,40 @@ def test_bf16_training_memorises_a_fixed_batch():
     assert abs(losses[0] - np.log(1000)) < 0.3
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.5 * losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncls", [10, 37])
+def test_class_counts_that_are_not_multiples_of_eight(ncls):
+    """The reference's ctor takes any n_classes (models/plainvit.py:542-557); the head GEMMs move 16-byte rows, so such a count
+    is padded inside (zero weight rows / bias / logit-gradient columns): logits, loss and every gradient against the oracle."""
+    emb, heads, depth, B = 192, 3, 2, 4
+    m = rg.ViT(3, 16, emb, depth=depth, n_classes=ncls, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
+               pixel_space="DCT", ver=1, use_subblock=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert shapes["classhead.ch_linear2.weight"] == (ncls, emb)
+    sd = detfill.fill_state_dict(shapes, base_seed=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    lab = torch.from_numpy(detfill.integers((B,), 74, 0, ncls - 1, np.int64)).to(DEV)
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
+    ref = V.vit_forward(p, y.cpu(), c.cpu(), depth, heads, emb)
+    lref = torch.nn.functional.cross_entropy(ref, lab.cpu())
+    lref.backward()
+    for mode, tol, gtol in ((torch.float32, 1e-4, 1e-3), (torch.bfloat16, 1e-2, 6e-2)):
+        m.compute_dtype = mode
+        for rep in range(2):
+            m.zero_grad()
+            logits = m(y, c)
+            assert tuple(logits.shape) == (B, ncls)
+            loss = rg.cls_transforms.cross_entropy(logits, lab, grad_dtype=mode)
+            loss.backward()
+        torch.cuda.synchronize()
+        err = (logits.detach().cpu() - ref.detach()).abs().max().item()
+        assert err <= tol, (mode, err)
+        assert abs(loss.item() - lref.item()) < (1e-5 if mode == torch.float32 else 5e-3)
+        for n, q in m.named_parameters():
+            want = p[n].grad
+            rel = ((q.grad.cpu() - want).norm() / (want.norm() + 1e-20)).item()
+            assert rel < gtol, (mode, n, rel)
