@@ -9,22 +9,29 @@
 namespace {
 
 
-// NV = E / 64 : each of the 16 lanes of a row group holds NV vectors of 4 consecutive elements,
-// element index e = (v*16 + l16)*4 + i.
-template <typename T, int NV>
+// E = NV * LPR * 4 : each of the LPR lanes of a row group holds NV vectors of 4 consecutive elements,
+// element index e = (v*LPR + l16)*4 + i.  LPR = 16 (E = 192 / 384: JPEG-Ti / JPEG-S) or 64 (one wave per row; E = 512 / 768 /
+// 1024: utils/configs.py:104-122 vitb / vitl) -- the wide rows would not fit one lane's registers at 16 lanes per row.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+  if constexpr (LPR == 16) return group16_sum(v);
+  else return wave_sum(v);
+}
+
+template <typename T, int NV, int LPR = 16>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                      float eps) {
-  constexpr int E = NV * 64;
-  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  constexpr int E = NV * LPR * 4, G = 256 / LPR;   // LPR lanes own one row, G rows per workgroup pass
+  const int l16 = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
   f32x4 gm[NV], bt[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * 16 + l16) * 4);
-    bt[v] = *reinterpret_cast<const f32x4*>(beta + (v * 16 + l16) * 4);
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * LPR + l16) * 4);
+    bt[v] = *reinterpret_cast<const f32x4*>(beta + (v * LPR + l16) * 4);
   }
-  for (int row = blockIdx.x * 16 + grp; row < M; row += gridDim.x * 16) {
+  for (int row = blockIdx.x * G + grp; row < M; row += gridDim.x * G) {
     // every fused multiply-add is spelled out and contraction is off: the residual + LayerNorm epilogue of the row-panel
     // GEMM (gemm_nt_kpipe.hip, EPI_RES_LN) repeats this arithmetic in another lane layout and must produce the same bits
 #pragma clang fp contract(off)
@@ -32,10 +39,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      xv[v] = load4<T>(x + (size_t)row * E + (v * 16 + l16) * 4);
+      xv[v] = load4<T>(x + (size_t)row * E + (v * LPR + l16) * 4);
       s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
     }
-    const float mu = group16_sum(s) * (1.f / E);
+    const float mu = row_sum<LPR>(s) * (1.f / E);
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -44,13 +51,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const float d = xv[v][i] - mu;
         q = __builtin_fmaf(d, d, q);
       }
-    const float rs = rsqrtf(__builtin_fmaf(group16_sum(q), 1.f / E, eps));
+    const float rs = rsqrtf(__builtin_fmaf(row_sum<LPR>(q), 1.f / E, eps));
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       f32x4 o;
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf((xv[v][i] - mu) * rs, gm[v][i], bt[v][i]);
-      store4<T>(y + (size_t)row * E + (v * 16 + l16) * 4, o);
+      store4<T>(y + (size_t)row * E + (v * LPR + l16) * 4, o);
     }
     if (l16 == 0) {
       mean[row] = mu;
@@ -60,28 +67,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // dx = [dres +] rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block.
-template <typename T, int NV>
+template <typename T, int NV, int LPR = 16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ part, int M) {
-  constexpr int E = NV * 64;
-  __shared__ float red[16][E + 4];
-  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  constexpr int E = NV * LPR * 4, G = 256 / LPR;   // LPR lanes own one row, G rows per workgroup pass
+  __shared__ float red[G][E + 4];
+  const int l16 = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
   f32x4 gm[NV], dg[NV], db[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * 16 + l16) * 4);
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * LPR + l16) * 4);
     dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * 16 + grp; row < M; row += gridDim.x * 16) {
+  for (int row = blockIdx.x * G + grp; row < M; row += gridDim.x * G) {
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NV], gv[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const size_t off = (size_t)row * E + (v * 16 + l16) * 4;
+      const size_t off = (size_t)row * E + (v * LPR + l16) * 4;
       const f32x4 xv = load4<T>(x + off);
       const f32x4 dv = load4<T>(dy + off);
 #pragma unroll
@@ -91,10 +98,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         xh[v][i] = xh_; gv[v][i] = gv_; dg[v][i] = dg_; db[v][i] = db_;
       }
     }
-    const float c1 = group16_sum(s1) * (1.f / E), c2 = group16_sum(s2) * (1.f / E);
+    const float c1 = row_sum<LPR>(s1) * (1.f / E), c2 = row_sum<LPR>(s2) * (1.f / E);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const size_t off = (size_t)row * E + (v * 16 + l16) * 4;
+      const size_t off = (size_t)row * E + (v * LPR + l16) * 4;
       f32x4 o, rv = {0.f, 0.f, 0.f, 0.f};
       if (dres) rv = load4<T>(dres + off);
 #pragma unroll
@@ -108,12 +115,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) red[grp][(v * 16 + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
+      for (int i = 0; i < 4; ++i) red[grp][(v * LPR + l16) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
     __syncthreads();
     for (int e = threadIdx.x; e < E; e += 256) {
       float a = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a += red[r][e];
+      for (int r = 0; r < G; ++r) a += red[r][e];
       part[((size_t)blockIdx.x * 2 + pass) * E + e] = a;
     }
   }
@@ -131,28 +138,28 @@ int submit_ln_reduce(const float* part, float* dgamma, float* dbeta, int nblk, i
 }
 
 // ---- head pooling: pooled[b] = mean_t LN(x[b,t,:])  (one workgroup per image) ------------------------
-template <typename T, int NV>
+template <typename T, int NV, int LPR = 16>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, T* __restrict__ pooled,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int N,
                                                        float eps) {
-  constexpr int E = NV * 64;
-  __shared__ float red[16][E + 4];
+  constexpr int E = NV * LPR * 4, G = 256 / LPR;   // LPR lanes own one row, G rows per workgroup pass
+  __shared__ float red[G][E + 4];
   const int b = blockIdx.x;
-  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int l16 = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
   f32x4 acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int t = grp; t < N; t += 16) {
+  for (int t = grp; t < N; t += G) {
     const size_t row = (size_t)b * N + t;
     f32x4 xv[NV];
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      xv[v] = load4<T>(x + row * E + (v * 16 + l16) * 4);
+      xv[v] = load4<T>(x + row * E + (v * LPR + l16) * 4);
       s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
     }
-    const float mu = group16_sum(s) * (1.f / E);
+    const float mu = row_sum<LPR>(s) * (1.f / E);
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, 
         const float d = xv[v][i] - mu;
         q += d * d;
       }
-    const float rs = rsqrtf(group16_sum(q) * (1.f / E) + eps);
+    const float rs = rsqrtf(row_sum<LPR>(q) * (1.f / E) + eps);
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -174,45 +181,45 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[grp][(v * 16 + l16) * 4 + i] = acc[v][i];
+    for (int i = 0; i < 4; ++i) red[grp][(v * LPR + l16) * 4 + i] = acc[v][i];
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += 256) {
     float a = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a += red[r][e];
+    for (int r = 0; r < G; ++r) a += red[r][e];
     // mean_t (xhat*gamma + beta) = gamma * mean_t(xhat) + beta
     pooled[(size_t)b * E + e] = from_f32<T>(a * (1.f / N) * gamma[e] + beta[e]);
   }
 }
 
 // dx[b,t,:] = LN-backward of dy = dpooled[b,:]/N (same for every token); partial dgamma/dbeta per image.
-template <typename T, int NV>
+template <typename T, int NV, int LPR = 16>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dpooled, const T* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, T* __restrict__ dx,
                                                        float* __restrict__ part, int N) {
-  constexpr int E = NV * 64;
-  __shared__ float red[16][E + 4];
+  constexpr int E = NV * LPR * 4, G = 256 / LPR;   // LPR lanes own one row, G rows per workgroup pass
+  __shared__ float red[G][E + 4];
   const int b = blockIdx.x;
-  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int l16 = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
   const float invN = 1.f / N;
   f32x4 gm[NV], dv[NV], dg[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * 16 + l16) * 4);
-    dv[v] = load4<T>(dpooled + (size_t)b * E + (v * 16 + l16) * 4);
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * LPR + l16) * 4);
+    dv[v] = load4<T>(dpooled + (size_t)b * E + (v * LPR + l16) * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dv[v][i] *= invN;
     dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int t = grp; t < N; t += 16) {
+  for (int t = grp; t < N; t += G) {
     const size_t row = (size_t)b * N + t;
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NV], gv[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const f32x4 xv = load4<T>(x + row * E + (v * 16 + l16) * 4);
+      const f32x4 xv = load4<T>(x + row * E + (v * LPR + l16) * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         xh[v][i] = (xv[i] - mu) * rs;
@@ -222,24 +229,24 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dpo
         dg[v][i] += dv[v][i] * xh[v][i];
       }
     }
-    const float c1 = group16_sum(s1) * (1.f / E), c2 = group16_sum(s2) * (1.f / E);
+    const float c1 = row_sum<LPR>(s1) * (1.f / E), c2 = row_sum<LPR>(s2) * (1.f / E);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       f32x4 o;
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2);
-      store4<T>(dx + row * E + (v * 16 + l16) * 4, o);
+      store4<T>(dx + row * E + (v * LPR + l16) * 4, o);
     }
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[grp][(v * 16 + l16) * 4 + i] = dg[v][i];
+    for (int i = 0; i < 4; ++i) red[grp][(v * LPR + l16) * 4 + i] = dg[v][i];
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += 256) {
     float a = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a += red[r][e];
+    for (int r = 0; r < G; ++r) a += red[r][e];
     part[((size_t)b * 2 + 0) * E + e] = a;
     // dbeta contribution of this image = sum_t dy = dpooled[b,e]
     part[((size_t)b * 2 + 1) * E + e] = to_f32(dpooled[(size_t)b * E + e]);
@@ -251,9 +258,12 @@ constexpr int LN_BWD_BLOCKS = 2048;  // 8 workgroups per CU: the row loop has no
 template <typename T>
 int ln_fwd_t(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int E, float eps,
              hipStream_t st) {
-  const int grid = min(cdiv(M, 16), 4096);
+  const int grid = min(cdiv(M, E <= 384 ? 16 : 4), 4096);
   if (E == 192) hipLaunchKernelGGL((ln_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (T*)y, mean, rstd, M, eps);
   else if (E == 384) hipLaunchKernelGGL((ln_fwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (T*)y, mean, rstd, M, eps);
+  else if (E == 512) hipLaunchKernelGGL((ln_fwd_kernel<T, 2, 64>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (T*)y, mean, rstd, M, eps);
+  else if (E == 768) hipLaunchKernelGGL((ln_fwd_kernel<T, 3, 64>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (T*)y, mean, rstd, M, eps);
+  else if (E == 1024) hipLaunchKernelGGL((ln_fwd_kernel<T, 4, 64>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (T*)y, mean, rstd, M, eps);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
   return RGBNM_OK;
@@ -262,9 +272,12 @@ int ln_fwd_t(const void* x, const float* g, const float* b, void* y, float* mean
 template <typename T>
 int ln_bwd_t(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, const void* dres,
              void* dx, float* dgamma, float* dbeta, int M, int E, int accumulate, float* ws, hipStream_t st) {
-  const int grid = min(cdiv(M, 16), LN_BWD_BLOCKS);
+  const int grid = min(cdiv(M, E <= 384 ? 16 : 4), LN_BWD_BLOCKS);
   if (E == 192) hipLaunchKernelGGL((ln_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else if (E == 384) hipLaunchKernelGGL((ln_bwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
+  else if (E == 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
+  else if (E == 768) hipLaunchKernelGGL((ln_bwd_kernel<T, 3, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
+  else if (E == 1024) hipLaunchKernelGGL((ln_bwd_kernel<T, 4, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
   return submit_ln_reduce(ws, dgamma, dbeta, grid, E, accumulate, st);
@@ -302,11 +315,17 @@ int rgbnm_head_pool_fwd(int dtype, const void* x, const float* gamma, const floa
                         float* rstd, int B, int N, int E, float eps, void* stream) {
   if (!x || !gamma || !beta || !pooled || !mean || !rstd || B <= 0 || N <= 0) return RGBNM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-#define POOL(T, NV) hipLaunchKernelGGL((pool_fwd_kernel<T, NV>), dim3(B), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)pooled, mean, rstd, N, eps)
+#define POOL(T, ...) hipLaunchKernelGGL((pool_fwd_kernel<T, __VA_ARGS__>), dim3(B), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)pooled, mean, rstd, N, eps)
   if (dtype == DT_BF16 && E == 192) POOL(bf16, 3);
   else if (dtype == DT_BF16 && E == 384) POOL(bf16, 6);
   else if (dtype == DT_F32 && E == 192) POOL(float, 3);
   else if (dtype == DT_F32 && E == 384) POOL(float, 6);
+  else if (dtype == DT_BF16 && E == 512) POOL(bf16, 2, 64);
+  else if (dtype == DT_BF16 && E == 768) POOL(bf16, 3, 64);
+  else if (dtype == DT_BF16 && E == 1024) POOL(bf16, 4, 64);
+  else if (dtype == DT_F32 && E == 512) POOL(float, 2, 64);
+  else if (dtype == DT_F32 && E == 768) POOL(float, 3, 64);
+  else if (dtype == DT_F32 && E == 1024) POOL(float, 4, 64);
   else return RGBNM_EINVAL;
 #undef POOL
   LAUNCH_CHECK();
@@ -320,11 +339,17 @@ int rgbnm_head_pool_bwd(int dtype, const void* dpooled, const void* x, const flo
   if (workspace_bytes < (size_t)B * 2 * E * sizeof(float)) return RGBNM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
-#define POOLB(T, NV) hipLaunchKernelGGL((pool_bwd_kernel<T, NV>), dim3(B), dim3(256), 0, st, (const T*)dpooled, (const T*)x, gamma, mean, rstd, (T*)dx, ws, N)
+#define POOLB(T, ...) hipLaunchKernelGGL((pool_bwd_kernel<T, __VA_ARGS__>), dim3(B), dim3(256), 0, st, (const T*)dpooled, (const T*)x, gamma, mean, rstd, (T*)dx, ws, N)
   if (dtype == DT_BF16 && E == 192) POOLB(bf16, 3);
   else if (dtype == DT_BF16 && E == 384) POOLB(bf16, 6);
   else if (dtype == DT_F32 && E == 192) POOLB(float, 3);
   else if (dtype == DT_F32 && E == 384) POOLB(float, 6);
+  else if (dtype == DT_BF16 && E == 512) POOLB(bf16, 2, 64);
+  else if (dtype == DT_BF16 && E == 768) POOLB(bf16, 3, 64);
+  else if (dtype == DT_BF16 && E == 1024) POOLB(bf16, 4, 64);
+  else if (dtype == DT_F32 && E == 512) POOLB(float, 2, 64);
+  else if (dtype == DT_F32 && E == 768) POOLB(float, 3, 64);
+  else if (dtype == DT_F32 && E == 1024) POOLB(float, 4, 64);
   else return RGBNM_EINVAL;
 #undef POOLB
   LAUNCH_CHECK();

@@ -577,8 +577,9 @@ class ViT(FlatParamModule):
             raise NotImplementedError("embed_type 1 / 3 without sub-block conversion are not in any reference config")
         if drop_p not in (0, 0.0):
             raise NotImplementedError("dropout p must be 0 (cfg.TRAIN.DROP default, configs.py:27)")
-        if head_size != 64 or emb_size not in (192, 384) or input_embed >= 0:
-            raise NotImplementedError("HIP kernels cover head_size 64 and emb_size 192/384 (JPEG-Ti / JPEG-S)")
+        if head_size != 64 or emb_size not in (192, 384, 512, 768, 1024) or input_embed >= 0:
+            raise NotImplementedError("HIP kernels cover head_size 64 and emb_size 192 / 384 (JPEG-Ti / JPEG-S; tuned) and "
+                                      "512 / 768 / 1024 (vitb / vitl of utils/configs.py:104-122; generic kernels)")
         if dtype != torch.float32:
             raise NotImplementedError("parameters are fp32 masters; choose bf16 compute with autocast")
         if n_classes < 1:

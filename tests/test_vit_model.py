@@ -439,16 +439,12 @@ def test_bf16_training_memorises_a_fixed_batch():
     assert losses[-1] < 0.5 * losses[0]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("ncls", [10, 37])
-def test_class_counts_that_are_not_multiples_of_eight(ncls):
-    """The reference's ctor takes any n_classes (models/plainvit.py:542-557); the head GEMMs move 16-byte rows, so such a count
-    is padded inside (zero weight rows / bias / logit-gradient columns): logits, loss and every gradient against the oracle."""
-    emb, heads, depth, B = 192, 3, 2, 4
+def _fp32_and_bf16_vs_oracle(emb, heads, depth, B, ncls, bf16_tol=1e-2):
     m = rg.ViT(3, 16, emb, depth=depth, n_classes=ncls, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
                pixel_space="DCT", ver=1, use_subblock=True)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert shapes["classhead.ch_linear2.weight"] == (ncls, emb)
+    assert shapes["encoder.0.0.fn.eb_mha.qkv.weight"] == (3 * 64 * heads, emb)
     sd = detfill.fill_state_dict(shapes, base_seed=1)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
@@ -458,7 +454,7 @@ def test_class_counts_that_are_not_multiples_of_eight(ncls):
     ref = V.vit_forward(p, y.cpu(), c.cpu(), depth, heads, emb)
     lref = torch.nn.functional.cross_entropy(ref, lab.cpu())
     lref.backward()
-    for mode, tol, gtol in ((torch.float32, 1e-4, 1e-3), (torch.bfloat16, 1e-2, 6e-2)):
+    for mode, tol, gtol in ((torch.float32, 1e-4, 1e-3), (torch.bfloat16, bf16_tol, 6e-2)):
         m.compute_dtype = mode
         for rep in range(2):
             m.zero_grad()
@@ -468,9 +464,27 @@ def test_class_counts_that_are_not_multiples_of_eight(ncls):
             loss.backward()
         torch.cuda.synchronize()
         err = (logits.detach().cpu() - ref.detach()).abs().max().item()
+        print(f"[E={emb} heads={heads} classes={ncls}] {mode}: max |dlogit| = {err:.3e}")
         assert err <= tol, (mode, err)
         assert abs(loss.item() - lref.item()) < (1e-5 if mode == torch.float32 else 5e-3)
         for n, q in m.named_parameters():
             want = p[n].grad
             rel = ((q.grad.cpu() - want).norm() / (want.norm() + 1e-20)).item()
             assert rel < gtol, (mode, n, rel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncls", [10, 37])
+def test_class_counts_that_are_not_multiples_of_eight(ncls):
+    """The reference's ctor takes any n_classes (models/plainvit.py:542-557); the head GEMMs move 16-byte rows, so such a count
+    is padded inside (zero weight rows / bias / logit-gradient columns): logits, loss and every gradient against the oracle."""
+    _fp32_and_bf16_vs_oracle(192, 3, 2, 4, ncls)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("emb,heads", [(768, 12), (1024, 12), (512, 8)])
+def test_wide_embeddings_vitb_vitl(emb, heads):
+    """utils/configs.py:104-122: vitb = 768 wide / 12 heads, vitl = 1024 wide / 12 heads of 64 (inner 768 != emb: the qkv and
+    projection Linears are rectangular, and the softmax scale stays 1/sqrt(emb), plainvit.py:459).  These widths run the
+    generic kernels (one wave per LayerNorm row); no launch is tuned for them -- the test is that the model is usable."""
+    _fp32_and_bf16_vs_oracle(emb, heads, 2, 3, 1000)
