@@ -15,6 +15,7 @@ namespace {
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
   if constexpr (LPR == 16) return group16_sum(v);
+  else if constexpr (LPR == 32) return group16_sum(v + __shfl_xor(v, 16, 64));
   else return wave_sum(v);
 }
 
@@ -84,8 +85,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
   for (int row = blockIdx.x * G + grp; row < M; row += gridDim.x * G) {
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NV], gv[NV];
+    f32x4 xh[NV], gv[NV], rv[NV];
     float s1 = 0.f, s2 = 0.f;
+    // the residual gradient is requested with the other two operands: asked for after the row sums it was a second, fully
+    // exposed round trip per row (44 -> 30 us at M = 50176, E = 384)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      rv[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (dres) rv[v] = load4<T>(dres + (size_t)row * E + (v * LPR + l16) * 4);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const size_t off = (size_t)row * E + (v * LPR + l16) * 4;
@@ -102,10 +110,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const size_t off = (size_t)row * E + (v * LPR + l16) * 4;
-      f32x4 o, rv = {0.f, 0.f, 0.f, 0.f};
-      if (dres) rv = load4<T>(dres + off);
+      f32x4 o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = ln_bwd_dx(rs, gv[v][i], c1, xh[v][i], c2, rv[i]);
+      for (int i = 0; i < 4; ++i) o[i] = ln_bwd_dx(rs, gv[v][i], c1, xh[v][i], c2, rv[v][i]);
       store4<T>(dx + off, o);
     }
   }
@@ -272,9 +279,11 @@ int ln_fwd_t(const void* x, const float* g, const float* b, void* y, float* mean
 template <typename T>
 int ln_bwd_t(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, const void* dres,
              void* dx, float* dgamma, float* dbeta, int M, int E, int accumulate, float* ws, hipStream_t st) {
-  const int grid = min(cdiv(M, E <= 384 ? 16 : 4), LN_BWD_BLOCKS);
+  // every workgroup walks the same number of row passes: 3136 passes on 2048 workgroups left a third of them a second pass
+  // E = 384 runs 32 lanes per row: at 16 its six vectors per operand cost 162 VGPRs (3 waves per SIMD)
+  const int P = cdiv(M, E == 192 ? 16 : E == 384 ? 8 : 4), grid = cdiv(P, cdiv(P, LN_BWD_BLOCKS));
   if (E == 192) hipLaunchKernelGGL((ln_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
-  else if (E == 384) hipLaunchKernelGGL((ln_bwd_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
+  else if (E == 384) hipLaunchKernelGGL((ln_bwd_kernel<T, 3, 32>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else if (E == 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else if (E == 768) hipLaunchKernelGGL((ln_bwd_kernel<T, 3, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);
   else if (E == 1024) hipLaunchKernelGGL((ln_bwd_kernel<T, 4, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, ws, M);

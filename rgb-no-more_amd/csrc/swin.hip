@@ -186,6 +186,173 @@ __global__ __launch_bounds__(256) void ln_generic_bwd_kernel(const T* __restrict
     part[(size_t)blockIdx.x * 2 * E + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm, Swin widths
+// The four stage widths of SwinV2-T (models/swinv2.py: embed_dim 96 doubling per stage: 96 / 192 / 384 / 768) with the row split
+// over LPR lanes (8 / 16 / 32 / 64) so that every lane of a wave carries data -- the any-width kernel above puts one wave on a
+// row, 24 of 64 lanes busy at width 96 and one 192-byte request in flight per wave, and took 15 % of the SwinV2-T step.
+// E = NV * LPR * 4; element index e = (v * LPR + l) * 4 + i; G = 256 / LPR rows per workgroup pass.  Same formulas as above.
+template <int LPR>
+__device__ __forceinline__ float lpr_sum(float v) {
+  if constexpr (LPR == 8) return group8_sum(v);
+  else if constexpr (LPR == 16) return group16_sum(v);
+  else if constexpr (LPR == 32) return group16_sum(v + __shfl_xor(v, 16, 64));
+  else return wave_sum(v);
+}
+
+template <typename T, int NV, int LPR>
+__global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const T* __restrict__ res,
+                                                          const float* __restrict__ sscale, int rows_per_sample,
+                                                          T* __restrict__ y, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, int M, float eps) {
+  constexpr int E = NV * LPR * 4, G = 256 / LPR;
+  const int l = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
+  f32x4 gm[NV], bt[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * LPR + l) * 4);
+    bt[v] = *reinterpret_cast<const f32x4*>(beta + (v * LPR + l) * 4);
+  }
+  for (int row = blockIdx.x * G + grp; row < M; row += gridDim.x * G) {
+    f32x4 xv[NV], rv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) xv[v] = load4<T>(x + (size_t)row * E + (v * LPR + l) * 4);
+    if (res) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) rv[v] = load4<T>(res + (size_t)row * E + (v * LPR + l) * 4);
+    }
+    const float sc = sscale ? sscale[row / rows_per_sample] : 1.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+    const float mu = lpr_sum<LPR>(s) / E;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float d = xv[v][i] - mu;
+        q += d * d;
+      }
+    const float rs = rsqrtf(lpr_sum<LPR>(q) / E + eps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = ((xv[v][i] - mu) * rs * gm[v][i] + bt[v][i]) * sc;
+      if (res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += rv[v][i];
+      }
+      store4<T>(y + (size_t)row * E + (v * LPR + l) * 4, o);
+    }
+    if (l == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+template <typename T, int NV, int LPR>
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ sscale,
+                                                          int rows_per_sample, T* __restrict__ dx, float* __restrict__ part,
+                                                          int M) {
+  constexpr int E = NV * LPR * 4, G = 256 / LPR;
+  __shared__ float red[G][E + 4];
+  const int l = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
+  f32x4 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + (v * LPR + l) * 4);
+    dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * G + grp; row < M; row += gridDim.x * G) {
+    f32x4 xh[NV], gv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xh[v] = load4<T>(x + (size_t)row * E + (v * LPR + l) * 4);
+      gv[v] = load4<T>(dy + (size_t)row * E + (v * LPR + l) * 4);
+    }
+    const float mu = mean[row], rs = rstd[row];
+    const float sc = sscale ? sscale[row / rows_per_sample] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float d = gv[v][i] * sc;
+        xh[v][i] = (xh[v][i] - mu) * rs;
+        gv[v][i] = d * gm[v][i];
+        s1 += gv[v][i];
+        s2 += gv[v][i] * xh[v][i];
+        dg[v][i] += d * xh[v][i];
+        db[v][i] += d;
+      }
+    const float c1 = lpr_sum<LPR>(s1) / E, c2 = lpr_sum<LPR>(s2) / E;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2);
+      store4<T>(dx + (size_t)row * E + (v * LPR + l) * 4, o);
+    }
+  }
+  // column sums over the G row groups of the workgroup, fixed order: part[blk][2][E]
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[grp][(v * LPR + l) * 4 + i] = pass == 0 ? dg[v][i] : db[v][i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < G; ++r) a += red[r][e];
+      part[((size_t)blockIdx.x * 2 + pass) * E + e] = a;
+    }
+  }
+}
+
+constexpr int LN_ROWS_BWD_BLOCKS = 2048;
+static inline int ln_rows_lpr(int E) { return E == 96 ? 8 : E == 192 ? 16 : E == 384 ? 32 : E == 768 ? 64 : 0; }   // three vectors per lane at every width
+// workgroups of the backward: every workgroup walks the same number of row passes (a ragged last round would idle most of the chip)
+static inline int ln_rows_bwd_grid(int M, int E) {
+  const int G = 256 / ln_rows_lpr(E), P = (M + G - 1) / G, it = (P + LN_ROWS_BWD_BLOCKS - 1) / LN_ROWS_BWD_BLOCKS;
+  return (P + it - 1) / it;
+}
+
+template <typename T>
+bool ln_rows_fwd(const void* x, const float* g, const float* b, const void* res, const float* ss, int rps, void* y, float* mean,
+                 float* rstd, int M, int E, float eps, hipStream_t st) {
+  const int lpr = ln_rows_lpr(E);
+  if (!lpr) return false;
+  const int G = 256 / lpr, grid = min((M + G - 1) / G, 8192);
+#define LNF(NV, LPR) hipLaunchKernelGGL((ln_rows_fwd_kernel<T, NV, LPR>), dim3(grid), dim3(256), 0, st, (const T*)x, g, b, (const T*)res, ss, rps, (T*)y, mean, rstd, M, eps)
+  if (E == 96) LNF(3, 8);
+  else if (E == 192) LNF(3, 16);
+  else if (E == 384) LNF(3, 32);
+  else LNF(3, 64);
+#undef LNF
+  return true;
+}
+
+template <typename T>
+int ln_rows_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, const float* ss, int rps,
+                void* dx, float* part, int M, int E, hipStream_t st) {
+  const int grid = ln_rows_bwd_grid(M, E);
+#define LNB(NV, LPR) hipLaunchKernelGGL((ln_rows_bwd_kernel<T, NV, LPR>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, g, mean, rstd, ss, rps, (T*)dx, part, M)
+  if (E == 96) LNB(3, 8);
+  else if (E == 192) LNB(3, 16);
+  else if (E == 384) LNB(3, 32);
+  else LNB(3, 64);
+#undef LNB
+  return grid;
+}
+
 // ------------------------------------------------------------------------------------------------ merge / mean
 // fwd: out[b, (y/2)(res/2) + x/2, (dy + 2 dx) C + c] = in[b, y res + x, c];  bwd: the inverse copy
 template <typename T>
@@ -242,7 +409,7 @@ int rgbnm_swin_embed(int in_dtype, int out_dtype, const void* y, const void* cbc
 
 size_t rgbnm_ln_generic_bwd_workspace(int M, int E) {
   int blocks = (M + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > LN_ROWS_BWD_BLOCKS) blocks = LN_ROWS_BWD_BLOCKS;   // covers the any-width kernel (<= 1024) and the stage-width one
   return (size_t)blocks * 2 * E * sizeof(float);
 }
 
@@ -251,9 +418,16 @@ int rgbnm_ln_generic_fwd(int dtype, const void* x, const float* gamma, const flo
                          float eps, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || E % 4 || E > 768 || (sample_scale && rows_per_sample <= 0))
     return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (rgbnm_get_option("ln_rows") && ln_rows_lpr(E)) {
+    if (dtype == DT_BF16) ln_rows_fwd<bf16>(x, gamma, beta, res, sample_scale, rows_per_sample, y, mean, rstd, M, E, eps, st);
+    else if (dtype == DT_F32) ln_rows_fwd<float>(x, gamma, beta, res, sample_scale, rows_per_sample, y, mean, rstd, M, E, eps, st);
+    else return RGBNM_EINVAL;
+    LAUNCH_CHECK();
+    return RGBNM_OK;
+  }
   int grid = (M + 3) / 4;
   if (grid > 4096) grid = 4096;
-  hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(ln_generic_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, (const bf16*)res, sample_scale, rows_per_sample, (bf16*)y, mean, rstd, M, E, eps);
   else if (dtype == DT_F32)
@@ -274,7 +448,11 @@ int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* 
   if (grid > 1024) grid = 1024;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  if (dtype == DT_BF16)
+  if (rgbnm_get_option("ln_rows") && ln_rows_lpr(E)) {
+    if (dtype == DT_BF16) grid = ln_rows_bwd<bf16>(dy, x, gamma, mean, rstd, sample_scale, rows_per_sample, dx, part, M, E, st);
+    else if (dtype == DT_F32) grid = ln_rows_bwd<float>(dy, x, gamma, mean, rstd, sample_scale, rows_per_sample, dx, part, M, E, st);
+    else return RGBNM_EINVAL;
+  } else if (dtype == DT_BF16)
     hipLaunchKernelGGL(ln_generic_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, sample_scale, rows_per_sample, (bf16*)dx, part, M, E);
   else if (dtype == DT_F32)
     hipLaunchKernelGGL(ln_generic_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, sample_scale, rows_per_sample, (float*)dx, part, M, E);

@@ -78,9 +78,11 @@ def test_embed_decomposition_is_exact_index_work_plus_fp32_products():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("E", [96, 192, 768])
-def test_layernorm_any_width_with_residual_and_sample_scale(dt, E):
-    B, N = 3, 70
+@pytest.mark.parametrize("E,N", [(96, 70), (192, 70), (384, 70), (768, 70), (100, 70), (96, 4099), (768, 1031)])
+def test_layernorm_any_width_with_residual_and_sample_scale(dt, E, N):
+    """Stage widths 96 / 192 / 384 / 768 take the lanes-per-row kernels, any other width (100) one wave per row; the long cases
+    walk several row passes per workgroup with a ragged last one."""
+    B = 3
     M = B * N
     x = torch.from_numpy(detfill.normalish((M, E), 11)).to(DEV).to(dt)
     res = torch.from_numpy(detfill.normalish((M, E), 12)).to(DEV).to(dt)
