@@ -4,17 +4,23 @@
 //   logits[i][j] = cos(q_i, k_j) * exp(min(logit_scale_h, ln 100)) + bias_h[i][j] + shift_mask[i][j],  8x8 windows,
 //   head_dim 32, softmax over the 64 keys of the window, O = P V.
 //
-// One wave per (window, head): the 64 tokens of a window are the 64 lanes.  Each lane gathers ITS token's q, k, v
-// (cyclic shift + window partition are index arithmetic: token = f(window, lane, shift); outputs are scattered back
-// the same way, so no rolled / partitioned copy of the activations exists), L2-normalises q and k, and parks the rows
-// in wave-private LDS tiles (row-major for operands reduced over d, transposed for operands reduced over tokens).
-// The math then follows the ViT attention kernels (attention.hip): swapped orientation S^T = K_n Q_n^T so a lane owns
-// one query and 16 keys per 32-key tile in registers - softmax is register-local plus one lane^32 exchange, and the
-// probabilities are the next MFMA's B operand straight from registers.  16 MFMAs forward, 56 backward per (window,
-// head) in bf16 (32x32x16) - the first generation of this kernel needed 8192 VALU FMAs per lane for the same work.
-// Backward: a wave walks `wpw` windows of ONE head and keeps that head's d(bias) in 64 registers (accumulator layout);
-// it leaves as one partial slice per wave, summed by the batched deterministic reduction (no atomics);
-// d(logit_scale) leaves as one partial per (window, head).  Templated on T in {float, bf16} (fp32 = exact 32x32x2 MFMA, the parity mode).
+// One wave per (window, head).  Gather: the head slice of a token is 64 contiguous bytes (bf16), so LPT = 4 lanes fetch one
+// token with a 16-byte load each -- 16 tokens per load instruction, 4 instructions per operand (a lane-per-token gather with
+// 8-byte loads touched 64 cache lines per instruction, 40 instructions per window in the backward: the texture-address path,
+// not HBM, set the pace: 1.1 TB/s).  Cyclic shift + window partition are index arithmetic (token = f(window, position, shift));
+// outputs are scattered back the same way, so no rolled / partitioned copy of the activations exists.  |q|, |k| and
+// D = dO . O are 4-lane DPP sums; the L2-normalised rows are parked in wave-private LDS tiles (row-major for operands reduced
+// over d, transposed for operands reduced over tokens).  The math then follows the ViT attention kernels (attention.hip):
+// swapped orientation S^T = K_n Q_n^T so a lane owns one query and 16 keys per 32-key tile in registers - softmax is
+// register-local plus one lane^32 exchange, and the probabilities are the next MFMA's B operand straight from registers.
+// 16 MFMAs forward, 56 backward per (window, head) in bf16 (32x32x16).
+// Launch: persistent.  Every workgroup belongs to ONE head: that head's 64 x 64 position bias sits in LDS (pitch 68: row reads
+// for the query-major phase, column reads for the key-major phase -- no transposed copy, no per-lane global row reads), and
+// each wave walks a contiguous range of windows, the next window's operands requested before the current one is computed
+// (bf16; registers are free at one wave per SIMD, which the LDS tiles dictate).  Backward: the wave keeps its head's d(bias)
+// in 64 registers (accumulator layout) over all its windows; it leaves as one partial slice per wave, summed by the batched
+// deterministic reduction (no atomics); d(logit_scale) leaves as one partial per (window, head).
+// Templated on T in {float, bf16} (fp32 = exact 32x32x2 MFMA, the parity mode).
 #include "common.h"
 #include "../../include/rgbnm.h"
 #include "internal.h"
@@ -24,6 +30,8 @@ namespace {
 constexpr int WS = 8, WT = 64, HD = 32;
 constexpr int RP = HD + 8;        // row-major tile pitch (elements): 16-byte aligned rows, staggered banks
 constexpr int TP = WT + 4;        // transposed tile pitch
+constexpr int BP = WT + 4;        // position-bias pitch in LDS (floats): float4 row reads and column reads both conflict free
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct WA {
   static constexpr int EPL = Frag<T>::EPL;
@@ -33,11 +41,56 @@ template <typename T> struct WA {
   static constexpr int ROW_T = WT * RP * (int)sizeof(T);  // bytes of a row-major tile
   static constexpr int TR_T = HD * TP * (int)sizeof(T);   // bytes of a transposed tile
   static constexpr int SMALL = 5 * WT * 4;                // lse, D, |q|, |k|, mask id
-  static constexpr int FWD_WAVE = 2 * ROW_T + TR_T + SMALL;
+  static constexpr int FWD_WAVE = 2 * ROW_T + TR_T + WT * 4;   // Qn, Kn, V^T, mask id
   static constexpr int BWD_WAVE = 4 * ROW_T + 3 * TR_T + SMALL;
   static constexpr int FWD_WAVES = 4;
   static constexpr int BWD_WAVES = sizeof(T) == 2 ? 4 : 2;
+  static constexpr int BIAS = WT * BP * 4;                // the workgroup's head: bias[64][BP] fp32
+  static constexpr int FWD_LDS = BIAS + FWD_WAVES * FWD_WAVE;
+  static constexpr int BWD_LDS = BIAS + BWD_WAVES * BWD_WAVE;
+  // gather geometry: LPT lanes fetch one token's head slice (HD elements) as 16-byte pieces of EP elements
+  static constexpr int LPT = HD * (int)sizeof(T) / 16;    // 4 / 8
+  static constexpr int EP = 16 / (int)sizeof(T);          // 8 / 4
+  static constexpr int TPI = 64 / LPT;                    // tokens per load instruction: 16 / 8
+  static constexpr int NI = WT / TPI;                     // load instructions per operand: 4 / 8
+  static constexpr bool PREFETCH = sizeof(T) == 2;        // next window's operands in registers during the math (80 VGPRs)
 };
+
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& r, float (&f)[WA<T>::EP]) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+    }
+  } else {
+    const f32x4 t = __builtin_bit_cast(f32x4, r);
+    f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; f[3] = t[3];
+  }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float (&f)[WA<T>::EP]) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    return __builtin_bit_cast(u32x4, v);
+  } else {
+    return (u32x4){__builtin_bit_cast(unsigned, f[0]), __builtin_bit_cast(unsigned, f[1]), __builtin_bit_cast(unsigned, f[2]),
+                   __builtin_bit_cast(unsigned, f[3])};
+  }
+}
+// sum over the LPT consecutive lanes that share a token
+template <typename T> __device__ __forceinline__ float token_sum(float v) {
+  v += lane_xor1(v);
+  v += lane_xor2(v);
+  if constexpr (WA<T>::LPT == 8) v += lane_xor4(v);
+  return v;
+}
+// the workgroup's head bias [64][64] -> LDS [64][BP]
+__device__ __forceinline__ void stage_bias(float* Bs, const float* __restrict__ bias_h) {
+  for (int i = threadIdx.x; i < WT * WT / 4; i += blockDim.x)
+    *reinterpret_cast<f32x4*>(Bs + (i >> 4) * BP + (i & 15) * 4) = *reinterpret_cast<const f32x4*>(bias_h + i * 4);
+}
 
 __device__ __forceinline__ int region(int s, int res, int shift) { return s < res - WS ? 0 : (s < res - shift ? 1 : 2); }
 // token index (in the un-shifted image) and mask id of local position i of window (wy, wx)
@@ -82,121 +135,184 @@ template <typename T> __device__ __forceinline__ void put_col(T* img, int col, c
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// raw 16-byte pieces of one window's q, k, v rows for this lane: piece n covers token n * TPI + lane / LPT, elements (lane % LPT) * EP ..
+template <typename T> struct RawQKV { u32x4 q[WA<T>::NI], k[WA<T>::NI], v[WA<T>::NI]; };
+
+template <typename T>
+__device__ __forceinline__ void fetch_qkv(RawQKV<T>& r, const T* __restrict__ qkv, long long win, int h, int nw, int res, int C,
+                                          int shift, int lane) {
+  using A = WA<T>;
+  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+#pragma unroll
+  for (int n = 0; n < A::NI; ++n) {
+    int mid;
+    const int tok = win_token(n * A::TPI + lane / A::LPT, wy, wx, res, shift, mid);
+    const T* row = qkv + ((size_t)b * res * res + tok) * 3 * C + h * HD + (lane % A::LPT) * A::EP;
+    r.q[n] = *reinterpret_cast<const u32x4*>(row);
+    r.k[n] = *reinterpret_cast<const u32x4*>(row + C);
+    r.v[n] = *reinterpret_cast<const u32x4*>(row + 2 * C);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
                                                            const float* __restrict__ scale, T* __restrict__ out,
                                                            float* __restrict__ lse, int B, int res, int C, int heads,
-                                                           int shift) {
+                                                           int shift, int bph) {
   using A = WA<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned char* base = win_smem + w * A::FWD_WAVE;
+  float* Bs = reinterpret_cast<float*>(win_smem);
+  unsigned char* base = win_smem + A::BIAS + w * A::FWD_WAVE;
   T* Qn = reinterpret_cast<T*>(base);
   T* Kn = reinterpret_cast<T*>(base + A::ROW_T);
   T* Vt = reinterpret_cast<T*>(base + 2 * A::ROW_T);
   int* Mid = reinterpret_cast<int*>(base + 2 * A::ROW_T + A::TR_T);
+  const int h = blockIdx.x / bph;
+  stage_bias(Bs, bias + (size_t)h * WT * WT);
+  __syncthreads();
   const int nw = res / WS;
-  const long long unit = (long long)blockIdx.x * A::FWD_WAVES + w, total = (long long)B * nw * nw * heads;
-  if (unit >= total) return;
-  const int h = (int)(unit % heads);
-  const long long win = unit / heads;
-  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+  const long long nwin = (long long)B * nw * nw;
+  const int wph = bph * A::FWD_WAVES, wih = (blockIdx.x % bph) * A::FWD_WAVES + w;      // waves of this head, index among them
+  const long long win_lo = nwin * wih / wph, win_hi = nwin * (wih + 1) / wph;
   const int l31 = lane & 31, g = lane >> 5;
-  {
-    int mid;
-    const int tok = win_token(lane, wy, wx, res, shift, mid);
-    const T* row = qkv + ((size_t)b * res * res + tok) * 3 * C + h * HD;
-    float q[HD], k[HD], v[HD];
-    float nq = 0.f, nk = 0.f;
+  const float sc = scale[h];
+  RawQKV<T> raw;
+  if (A::PREFETCH && win_lo < win_hi) fetch_qkv<T>(raw, qkv, win_lo, h, nw, res, C, shift, lane);
+#pragma unroll 1
+  for (long long win = win_lo; win < win_hi; ++win) {
+    const long long unit = win * heads + h;
+    const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+    if (!A::PREFETCH) fetch_qkv<T>(raw, qkv, win, h, nw, res, C, shift, lane);
+    __builtin_amdgcn_wave_barrier();                   // the previous window's LDS reads are done (same wave, in order)
 #pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
+    for (int n = 0; n < A::NI; ++n) {
+      const int tk = n * A::TPI + lane / A::LPT, ch = lane % A::LPT;
+      float q[A::EP], k[A::EP], v[A::EP];
+      unpack16<T>(raw.q[n], q);
+      unpack16<T>(raw.k[n], k);
+      unpack16<T>(raw.v[n], v);
+      float nq = 0.f, nk = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q[d + e] = a[e]; k[d + e] = k4[e]; v[d + e] = v4[e];
-        nq += a[e] * a[e];
-        nk += k4[e] * k4[e];
+      for (int e = 0; e < A::EP; ++e) {
+        nq += q[e] * q[e];
+        nk += k[e] * k[e];
+      }
+      const float iq = 1.f / fmaxf(sqrtf(token_sum<T>(nq)), 1e-12f);            // F.normalize(eps = 1e-12)
+      const float ik = 1.f / fmaxf(sqrtf(token_sum<T>(nk)), 1e-12f);
+#pragma unroll
+      for (int e = 0; e < A::EP; ++e) {
+        q[e] *= iq;
+        k[e] *= ik;
+      }
+      *reinterpret_cast<u32x4*>(Qn + tk * RP + ch * A::EP) = pack16<T>(q);
+      *reinterpret_cast<u32x4*>(Kn + tk * RP + ch * A::EP) = pack16<T>(k);
+#pragma unroll
+      for (int e = 0; e < A::EP; ++e) Vt[(ch * A::EP + e) * TP + tk] = from_f32<T>(v[e]);
+      if (ch == 0) {
+        int mid;
+        (void)win_token(tk, wy, wx, res, shift, mid);
+        Mid[tk] = mid;
       }
     }
-    put_row<T>(Qn, lane, q, 1.f / fmaxf(sqrtf(nq), 1e-12f));            // F.normalize(eps = 1e-12)
-    put_row<T>(Kn, lane, k, 1.f / fmaxf(sqrtf(nk), 1e-12f));
-    put_col<T>(Vt, lane, v, 1.f);
-    Mid[lane] = mid;
-  }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const float sc = scale[h];
+    if (A::PREFETCH && win + 1 < win_hi) fetch_qkv<T>(raw, qkv, win + 1, h, nw, res, C, shift, lane);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
-  for (int i = 0; i < 2; ++i) {
-    const int q = 32 * i + l31;
-    int midq;
-    const int tokq = win_token(q, wy, wx, res, shift, midq);
-    Frag<T> qf[A::NCH];
+    for (int i = 0; i < 2; ++i) {
+      const int q = 32 * i + l31;
+      int midq;
+      const int tokq = win_token(q, wy, wx, res, shift, midq);
+      Frag<T> qf[A::NCH];
 #pragma unroll
-    for (int c = 0; c < A::NCH; ++c) qf[c] = rowfrag<T>(Qn, q, c, g);
-    const float* brow = bias + ((size_t)h * WT + q) * WT;
-    float s[2][16];
-    float m = -INFINITY;
+      for (int c = 0; c < A::NCH; ++c) qf[c] = rowfrag<T>(Qn, q, c, g);
+      const float* brow = Bs + q * BP;
+      float s[2][16];
+      float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x16 acc;
+      for (int t = 0; t < 2; ++t) {
+        f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int c = 0; c < A::NCH; ++c) mma(acc, rowfrag<T>(Kn, 32 * t + l31, c, g), qf[c]);
+        for (int c = 0; c < A::NCH; ++c) mma(acc, rowfrag<T>(Kn, 32 * t + l31, c, g), qf[c]);
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {                 // registers 4 q4 .. +3 <-> keys 32 t + 8 q4 + 4 g + 0..3
-        const int k0 = 32 * t + 8 * q4 + 4 * g;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
+        for (int q4 = 0; q4 < 4; ++q4) {                 // registers 4 q4 .. +3 <-> keys 32 t + 8 q4 + 4 g + 0..3
+          const int k0 = 32 * t + 8 * q4 + 4 * g;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[4 * q4 + e] * sc + b4[e];
-          if (shift && Mid[k0 + e] != midq) v += -100.f;
-          s[t][4 * q4 + e] = v;
-          m = fmaxf(m, v);
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[4 * q4 + e] * sc + b4[e];
+            if (shift && Mid[k0 + e] != midq) v += -100.f;
+            s[t][4 * q4 + e] = v;
+            m = fmaxf(m, v);
+          }
         }
       }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[t][r] = __expf(s[t][r] - m);
-        sum += s[t][r];
+        for (int r = 0; r < 16; ++r) {
+          s[t][r] = __expf(s[t][r] - m);
+          sum += s[t][r];
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      if (g == 0) lse[unit * WT + q] = m + __logf(sum);
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] *= inv;
+#pragma unroll
+        for (int fi = 0; fi < A::FPT; ++fi) mma(o, tfrag<T>(Vt, l31, t, fi, g), pfrag<T>(s[t], fi));
       }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-    if (g == 0) lse[unit * WT + q] = m + __logf(sum);
-    f32x16 o;
+      T* orow = out + ((size_t)b * res * res + tokq) * C + h * HD;       // o[r] = O[q][acc_row(r)]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] *= inv;
-#pragma unroll
-      for (int fi = 0; fi < A::FPT; ++fi) mma(o, tfrag<T>(Vt, l31, t, fi, g), pfrag<T>(s[t], fi));
+      for (int rq = 0; rq < 4; ++rq)
+        store4<T>(orow + rq * 8 + g * 4, (f32x4){o[rq * 4 + 0], o[rq * 4 + 1], o[rq * 4 + 2], o[rq * 4 + 3]});
     }
-    T* orow = out + ((size_t)b * res * res + tokq) * C + h * HD;       // o[r] = O[q][acc_row(r)]
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
-      store4<T>(orow + rq * 8 + g * 4, (f32x4){o[rq * 4 + 0], o[rq * 4 + 1], o[rq * 4 + 2], o[rq * 4 + 3]});
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+template <typename T> struct RawBwd { u32x4 q[WA<T>::NI], k[WA<T>::NI], v[WA<T>::NI], g[WA<T>::NI], o[WA<T>::NI]; };
+
+template <typename T>
+__device__ __forceinline__ void fetch_bwd(RawBwd<T>& r, const T* __restrict__ qkv, const T* __restrict__ out,
+                                          const T* __restrict__ dout, long long win, int h, int nw, int res, int C, int shift,
+                                          int lane) {
+  using A = WA<T>;
+  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+#pragma unroll
+  for (int n = 0; n < A::NI; ++n) {
+    int mid;
+    const int tok = win_token(n * A::TPI + lane / A::LPT, wy, wx, res, shift, mid);
+    const size_t trow = (size_t)b * res * res + tok;
+    const int col = h * HD + (lane % A::LPT) * A::EP;
+    const T* row = qkv + trow * 3 * C + col;
+    r.q[n] = *reinterpret_cast<const u32x4*>(row);
+    r.k[n] = *reinterpret_cast<const u32x4*>(row + C);
+    r.v[n] = *reinterpret_cast<const u32x4*>(row + 2 * C);
+    r.g[n] = *reinterpret_cast<const u32x4*>(dout + trow * C + col);
+    r.o[n] = *reinterpret_cast<const u32x4*>(out + trow * C + col);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout, const float* __restrict__ bias,
-    const float* __restrict__ bias_t, const float* __restrict__ scale, const float* __restrict__ lse,
-    T* __restrict__ dqkv, float* __restrict__ dpart, float* __restrict__ dscale_part, int B, int res, int C, int heads,
-    int shift, int wpw) {
+    const float* __restrict__ scale, const float* __restrict__ lse, T* __restrict__ dqkv, float* __restrict__ dpart,
+    float* __restrict__ dscale_part, int B, int res, int C, int heads, int shift, int bph) {
   using A = WA<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned char* base = win_smem + w * A::BWD_WAVE;
+  float* Bs = reinterpret_cast<float*>(win_smem);
+  unsigned char* base = win_smem + A::BIAS + w * A::BWD_WAVE;
   T* Qn = reinterpret_cast<T*>(base);
   T* Kn = reinterpret_cast<T*>(base + A::ROW_T);
   T* Vr = reinterpret_cast<T*>(base + 2 * A::ROW_T);
@@ -209,13 +325,13 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
   float* Rq = Ds + WT;
   float* Rk = Rq + WT;
   int* Mid = reinterpret_cast<int*>(Rk + WT);
+  const int h = blockIdx.x / bph;
+  stage_bias(Bs, bias + (size_t)h * WT * WT);
+  __syncthreads();
   const int nw = res / WS;
   const long long nwin = (long long)B * nw * nw;
-  const long long groups = (nwin + wpw - 1) / wpw;
-  const long long gid = (long long)blockIdx.x * A::BWD_WAVES + w;
-  if (gid >= groups * heads) return;
-  const int h = (int)(gid / groups);
-  const long long win0 = (gid % groups) * wpw;
+  const int wph = bph * A::BWD_WAVES, wih = (blockIdx.x % bph) * A::BWD_WAVES + w;      // waves of this head, index among them
+  const long long win_lo = nwin * wih / wph, win_hi = nwin * (wih + 1) / wph;
   const int l31 = lane & 31, g = lane >> 5;
   const float sc = scale[h];
   float dbacc[2][2][16];                    // this head's d(bias) in accumulator layout: [query tile][key tile][r]
@@ -226,46 +342,58 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) dbacc[i][t][r] = 0.f;
 
+  RawBwd<T> raw;
+  if (A::PREFETCH && win_lo < win_hi) fetch_bwd<T>(raw, qkv, out, dout, win_lo, h, nw, res, C, shift, lane);
 #pragma unroll 1
-  for (int wi = 0; wi < wpw; ++wi) {
-    const long long win = win0 + wi;
-    if (win >= nwin) break;
+  for (long long win = win_lo; win < win_hi; ++win) {
     const long long unit = win * heads + h;            // (window, head) index of lse / dscale_part (forward's order)
     const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+    if (!A::PREFETCH) fetch_bwd<T>(raw, qkv, out, dout, win, h, nw, res, C, shift, lane);
     __builtin_amdgcn_wave_barrier();                   // the previous window's LDS reads are done (same wave, in order)
-    {
-      int mid;
-      const int tok = win_token(lane, wy, wx, res, shift, mid);
-      const size_t trow = (size_t)b * res * res + tok;
-      const T* row = qkv + trow * 3 * C + h * HD;
-      float q[HD], k[HD], v[HD], gg[HD];
+#pragma unroll
+    for (int n = 0; n < A::NI; ++n) {
+      const int tk = n * A::TPI + lane / A::LPT, ch = lane % A::LPT;
+      float q[A::EP], k[A::EP], gg[A::EP], oo[A::EP];
+      unpack16<T>(raw.q[n], q);
+      unpack16<T>(raw.k[n], k);
+      unpack16<T>(raw.g[n], gg);
+      unpack16<T>(raw.o[n], oo);
       float nq = 0.f, nk = 0.f, Dq = 0.f;
 #pragma unroll
-      for (int d = 0; d < HD; d += 4) {
-        const f32x4 a = load4<T>(row + d), k4 = load4<T>(row + C + d), v4 = load4<T>(row + 2 * C + d);
-        const f32x4 g4 = load4<T>(dout + trow * C + h * HD + d), o4 = load4<T>(out + trow * C + h * HD + d);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          q[d + e] = a[e]; k[d + e] = k4[e]; v[d + e] = v4[e]; gg[d + e] = g4[e];
-          nq += a[e] * a[e];
-          nk += k4[e] * k4[e];
-          Dq += g4[e] * o4[e];                       // D_i = sum_j p_ij dP_ij = dO_i . O_i
-        }
+      for (int e = 0; e < A::EP; ++e) {
+        nq += q[e] * q[e];
+        nk += k[e] * k[e];
+        Dq += gg[e] * oo[e];                           // D_i = sum_j p_ij dP_ij = dO_i . O_i
       }
-      const float rq = fmaxf(sqrtf(nq), 1e-12f), rk = fmaxf(sqrtf(nk), 1e-12f);
-      put_row<T>(Qn, lane, q, 1.f / rq);
-      put_row<T>(Kn, lane, k, 1.f / rk);
-      put_row<T>(Vr, lane, v, 1.f);
-      put_row<T>(Gr, lane, gg, 1.f);
-      put_col<T>(Qnt, lane, q, 1.f / rq);
-      put_col<T>(Knt, lane, k, 1.f / rk);
-      put_col<T>(Gt, lane, gg, 1.f);
-      Ls[lane] = lse[unit * WT + lane];
-      Ds[lane] = Dq;
-      Rq[lane] = rq;
-      Rk[lane] = rk;
-      Mid[lane] = mid;
+      const float rq = fmaxf(sqrtf(token_sum<T>(nq)), 1e-12f), rk = fmaxf(sqrtf(token_sum<T>(nk)), 1e-12f);
+      Dq = token_sum<T>(Dq);
+      const float iq = 1.f / rq, ik = 1.f / rk;
+#pragma unroll
+      for (int e = 0; e < A::EP; ++e) {
+        q[e] *= iq;
+        k[e] *= ik;
+      }
+      *reinterpret_cast<u32x4*>(Qn + tk * RP + ch * A::EP) = pack16<T>(q);
+      *reinterpret_cast<u32x4*>(Kn + tk * RP + ch * A::EP) = pack16<T>(k);
+      *reinterpret_cast<u32x4*>(Vr + tk * RP + ch * A::EP) = raw.v[n];
+      *reinterpret_cast<u32x4*>(Gr + tk * RP + ch * A::EP) = raw.g[n];
+#pragma unroll
+      for (int e = 0; e < A::EP; ++e) {
+        Qnt[(ch * A::EP + e) * TP + tk] = from_f32<T>(q[e]);
+        Knt[(ch * A::EP + e) * TP + tk] = from_f32<T>(k[e]);
+        Gt[(ch * A::EP + e) * TP + tk] = from_f32<T>(gg[e]);
+      }
+      if (ch == 0) {
+        int mid;
+        (void)win_token(tk, wy, wx, res, shift, mid);
+        Ls[tk] = lse[unit * WT + tk];
+        Ds[tk] = Dq;
+        Rq[tk] = rq;
+        Rk[tk] = rk;
+        Mid[tk] = mid;
+      }
     }
+    if (A::PREFETCH && win + 1 < win_hi) fetch_bwd<T>(raw, qkv, out, dout, win + 1, h, nw, res, C, shift, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ================= phase A: lane = query (two 32-query tiles) -> dq, d(bias), d(scale) =================
@@ -282,7 +410,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         gf[c] = rowfrag<T>(Gr, q, c, g);
       }
       const float lq = Ls[q], Dq = Ds[q];
-      const float* brow = bias + ((size_t)h * WT + q) * WT;
+      const float* brow = Bs + q * BP;
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -353,7 +481,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         kf[c] = rowfrag<T>(Kn, key, c, g);
         vf[c] = rowfrag<T>(Vr, key, c, g);
       }
-      const float* btrow = bias_t + ((size_t)h * WT + key) * WT;       // bias_t[h][key][query]
+      const float* bcol = Bs + key;                                    // bias[h][query][key]: a column of the LDS copy
       f32x16 dk, dv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
@@ -371,7 +499,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           const int q0 = 32 * i + 8 * q4 + 4 * g;
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(btrow + q0);
+          const f32x4 b4 = {bcol[q0 * BP], bcol[(q0 + 1) * BP], bcol[(q0 + 2) * BP], bcol[(q0 + 3) * BP]};
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + q0), d4 = *reinterpret_cast<const f32x4*>(Ds + q0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -416,10 +544,10 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
       }
     }
   }
-  // d(bias)[h][query][key] of this wave's windows -> its own partial slice [group][head][64][64]; summed over groups
+  // d(bias)[h][query][key] of this wave's windows -> its own partial slice [wave of the head][head][64][64]; summed over waves
   // by the batched deterministic reduction (reduce.hip).  (Global atomics here cost 5 ms of a 20 ms step: every
   // window of the batch adds into the same 64 x 64 x heads addresses.)
-  float* dp = dpart + (((gid % groups) * heads + h) * (size_t)(WT * WT));
+  float* dp = dpart + (((size_t)wih * heads + h) * (size_t)(WT * WT));
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -431,48 +559,62 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
 template <typename T> int set_attrs() {
   static DevOnce done;
   if (!done.need()) return RGBNM_OK;
-  if (hipFuncSetAttribute((const void*)win_attn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          WA<T>::FWD_WAVE * WA<T>::FWD_WAVES) != hipSuccess ||
-      hipFuncSetAttribute((const void*)win_attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          WA<T>::BWD_WAVE * WA<T>::BWD_WAVES) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)win_attn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, WA<T>::FWD_LDS) != hipSuccess ||
+      hipFuncSetAttribute((const void*)win_attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, WA<T>::BWD_LDS) != hipSuccess)
     return RGBNM_ELAUNCH;
   done.done();
   return RGBNM_OK;
+}
+
+int num_cus() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  int c = cached[dev].load(std::memory_order_acquire);
+  if (c > 0) return c;
+  if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+  cached[dev].store(c, std::memory_order_release);
+  return c;
+}
+// workgroups per head: one resident round of the chip split evenly between the heads (a workgroup holds ONE head's bias);
+// `per_cu` = workgroups of this kernel that fit a CU (LDS).  Never more waves than windows.
+int blocks_per_head(long long nwin, int heads, int per_cu, int waves) {
+  long long bph = (long long)num_cus() * per_cu / heads;
+  const long long cap = (nwin + waves - 1) / waves;
+  if (bph > cap) bph = cap;
+  return bph < 1 ? 1 : (int)bph;
 }
 
 template <typename T>
 int launch_fwd(const void* qkv, const float* bias, const float* scale, void* out, float* lse, int B, int res, int C,
                int heads, int shift, hipStream_t st) {
   if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
-  const long long units = (long long)B * (res / WS) * (res / WS) * heads;
-  const int grid = (int)((units + WA<T>::FWD_WAVES - 1) / WA<T>::FWD_WAVES);
-  hipLaunchKernelGGL(win_attn_fwd_kernel<T>, dim3(grid), dim3(64 * WA<T>::FWD_WAVES), WA<T>::FWD_WAVE * WA<T>::FWD_WAVES, st,
-                     (const T*)qkv, bias, scale, (T*)out, lse, B, res, C, heads, shift);
+  const long long nwin = (long long)B * (res / WS) * (res / WS);
+  const int bph = blocks_per_head(nwin, heads, 160 * 1024 / WA<T>::FWD_LDS, WA<T>::FWD_WAVES);
+  hipLaunchKernelGGL(win_attn_fwd_kernel<T>, dim3(bph * heads), dim3(64 * WA<T>::FWD_WAVES), WA<T>::FWD_LDS, st,
+                     (const T*)qkv, bias, scale, (T*)out, lse, B, res, C, heads, shift, bph);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
 
-// windows per wave: keep ~4096 waves in flight (bounds the partial d(bias) buffer to 4096 x 16 KB = 64 MB)
-int bwd_wpw(long long nwin, int heads) {
-  int wpw = (int)(nwin * heads / 4096);
-  return wpw < 1 ? 1 : (wpw > 64 ? 64 : wpw);
+template <typename T> int bwd_bph(long long nwin, int heads) {
+  return blocks_per_head(nwin, heads, 160 * 1024 / WA<T>::BWD_LDS, WA<T>::BWD_WAVES);
 }
 
 template <typename T>
-int launch_bwd(const void* qkv, const void* out, const void* dout, const float* bias, const float* bias_t,
-               const float* scale, const float* lse, void* dqkv, float* dbias, float* dscale_part, float* dpart, int B,
-               int res, int C, int heads, int shift, hipStream_t st) {
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* bias, const float* scale, const float* lse,
+               void* dqkv, float* dbias, float* dscale_part, float* dpart, int B, int res, int C, int heads, int shift,
+               hipStream_t st) {
   if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
   const long long nwin = (long long)B * (res / WS) * (res / WS);
-  const int wpw = bwd_wpw(nwin, heads);
-  const long long groups = (nwin + wpw - 1) / wpw, waves = groups * heads;
-  const int grid = (int)((waves + WA<T>::BWD_WAVES - 1) / WA<T>::BWD_WAVES);
-  hipLaunchKernelGGL(win_attn_bwd_kernel<T>, dim3(grid), dim3(64 * WA<T>::BWD_WAVES), WA<T>::BWD_WAVE * WA<T>::BWD_WAVES, st,
-                     (const T*)qkv, (const T*)out, (const T*)dout, bias, bias_t, scale, lse, (T*)dqkv, dpart, dscale_part,
-                     B, res, C, heads, shift, wpw);
+  const int bph = bwd_bph<T>(nwin, heads);
+  hipLaunchKernelGGL(win_attn_bwd_kernel<T>, dim3(bph * heads), dim3(64 * WA<T>::BWD_WAVES), WA<T>::BWD_LDS, st,
+                     (const T*)qkv, (const T*)out, (const T*)dout, bias, scale, lse, (T*)dqkv, dpart, dscale_part, B, res, C,
+                     heads, shift, bph);
   LAUNCH_CHECK();
   RgbnmReduceJob j;
-  j.part = dpart; j.stride = (long long)heads * WT * WT; j.out = dbias; j.n = heads * WT * WT; j.S = (int)groups;
+  j.part = dpart; j.stride = (long long)heads * WT * WT; j.out = dbias; j.n = heads * WT * WT; j.S = bph * WA<T>::BWD_WAVES;
   j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
   return rgbnm_reduce_submit(j, st);
 }
@@ -492,9 +634,11 @@ int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, co
 }
 
 size_t rgbnm_window_attention_bwd_workspace(int B, int res, int heads) {
+  // one d(bias) slice per wave: the fp32 geometry (2 waves per workgroup, as many workgroups) bounds both dtypes
   const long long nwin = (long long)B * (res / WS) * (res / WS);
-  const int wpw = bwd_wpw(nwin, heads);
-  return (size_t)((nwin + wpw - 1) / wpw) * heads * WT * WT * sizeof(float);
+  const long long waves_bf = (long long)bwd_bph<bf16>(nwin, heads) * WA<bf16>::BWD_WAVES;
+  const long long waves_f = (long long)bwd_bph<float>(nwin, heads) * WA<float>::BWD_WAVES;
+  return (size_t)(waves_bf > waves_f ? waves_bf : waves_f) * heads * WT * WT * sizeof(float);
 }
 
 int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
@@ -508,11 +652,9 @@ int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, cons
   hipStream_t st = (hipStream_t)stream;
   float* dpart = (float*)workspace;
   if (dtype == DT_BF16)
-    return launch_bwd<bf16>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads,
-                            shift, st);
+    return launch_bwd<bf16>(qkv, out, dout, bias, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads, shift, st);
   if (dtype == DT_F32)
-    return launch_bwd<float>(qkv, out, dout, bias, bias_t, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads,
-                             shift, st);
+    return launch_bwd<float>(qkv, out, dout, bias, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads, shift, st);
   return RGBNM_EINVAL;
 }
 
