@@ -22,10 +22,18 @@
 // deterministic reduction (no atomics); d(logit_scale) leaves as one partial per (window, head).
 // Templated on T in {float, bf16} (fp32 = exact 32x32x2 MFMA, the parity mode).
 #include "common.h"
+#include <type_traits>
 #include "../../include/rgbnm.h"
 #include "internal.h"
 
 namespace {
+
+#ifdef WIN_PROF   // experiments only: cycle stamps of every wave's second window (tools/winattn_prof.py)
+__device__ unsigned long long g_win_prof[1024 * 4 * 8];
+#define WPROF(i) do { if (lane == 0 && win == win_lo + 1 && blockIdx.x < 1024) g_win_prof[(blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WPROF(i) do { } while (0)
+#endif
 
 constexpr int WS = 8, WT = 64, HD = 32;
 constexpr int RP = HD + 8;        // row-major tile pitch (elements): 16-byte aligned rows, staggered banks
@@ -41,8 +49,11 @@ template <typename T> struct WA {
   static constexpr int ROW_T = WT * RP * (int)sizeof(T);  // bytes of a row-major tile
   static constexpr int TR_T = HD * TP * (int)sizeof(T);   // bytes of a transposed tile
   static constexpr int SMALL = 5 * WT * 4;                // lse, D, |q|, |k|, mask id
-  static constexpr int FWD_WAVE = 2 * ROW_T + TR_T + WT * 4;   // Qn, Kn, V^T, mask id
-  static constexpr int BWD_WAVE = 4 * ROW_T + 3 * TR_T + SMALL;
+  // bf16 reads operands whose reduction axis is the token axis (V^T, K^T, Q^T, dO^T) out of the ROW-major tiles with
+  // ds_read_b64_tr_b16; fp32 has no transposing read and parks transposed copies
+  static constexpr bool TRREAD = sizeof(T) == 2;
+  static constexpr int FWD_WAVE = 2 * ROW_T + (TRREAD ? ROW_T : TR_T) + WT * 4;   // Qn, Kn, V (bf16) / V^T (fp32), mask id
+  static constexpr int BWD_WAVE = 4 * ROW_T + (TRREAD ? 0 : 3 * TR_T) + SMALL;
   static constexpr int FWD_WAVES = 4;
   static constexpr int BWD_WAVES = sizeof(T) == 2 ? 4 : 2;
   static constexpr int BIAS = WT * BP * 4;                // the workgroup's head: bias[64][BP] fp32
@@ -103,6 +114,28 @@ __device__ __forceinline__ int win_token(int i, int wy, int wx, int res, int shi
   return yy * res + xx;
 }
 
+// window coordinates (image, window row, window column), walked incrementally: a 64-bit `win % nw` per window and per
+// prefetch cost more than the window's MFMAs
+struct WinPos {
+  int b, wy, wx;
+  __device__ __forceinline__ void set(long long win, int nw) {
+    wx = (int)(win % nw);
+    wy = (int)((win / nw) % nw);
+    b = (int)(win / ((long long)nw * nw));
+  }
+  __device__ __forceinline__ void next(int nw) {
+    if (++wx == nw) {
+      wx = 0;
+      if (++wy == nw) {
+        wy = 0;
+        ++b;
+      }
+    }
+  }
+};
+// 1 / max(|x|, 1e-12) from |x|^2  (F.normalize's eps; v_rsq_f32 is 1 ulp)
+__device__ __forceinline__ float inv_norm(float n2) { return fminf(__builtin_amdgcn_rsqf(n2), 1e12f); }
+
 template <typename T> __device__ __forceinline__ Frag<T> rowfrag(const T* tile, int row, int c, int g) {
   return load_frag<T>(tile + row * RP + c * WA<T>::CH + g * WA<T>::EPL);
 }
@@ -119,6 +152,35 @@ template <typename T> __device__ __forceinline__ Frag<T> tfrag(const T* img, int
   }
   return f;
 }
+// bf16: the same fragment as tfrag(img, d = lane & 31, t, fi, g) read from the row-major tile [token][RP].  A 16-lane group
+// (fixed g, G1) hands ds_read_b64_tr_b16 a 4-row x 16-column block -- lane (k, l3) points at row 4 g + k, columns
+// 16 G1 + 4 l3 .. +3 -- and gets back column 16 G1 + 4 k + l3 (= lane & 31) of rows 4 g .. 4 g + 3; the second read takes the
+// rows 8 further down (tfrag's `hi` half).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned tr_base(const bf16* tile, int lane) {
+  const int g = lane >> 5, G1 = (lane >> 4) & 1, k = (lane >> 2) & 3, l3 = lane & 3;
+  return (unsigned)(size_t)tile + (unsigned)((4 * g + k) * RP * 2 + (16 * G1 + 4 * l3) * 2);
+}
+__device__ __forceinline__ Frag<bf16> trfrag(unsigned a) {   // a = tr_base + byte offset of fragment (t, fi): (32 t + 16 fi) rows
+  u32x2 lo, hi;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %2\n\t"
+      "ds_read_b64_tr_b16 %1, %2 offset:%3\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(lo), "=&v"(hi)
+      : "v"(a), "i"(8 * RP * 2)
+      : "memory");
+  Frag<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+  return f;
+}
+// fragment (t, fi) of a token-reduced operand: transposing read of the row tile (bf16) or plain read of the transposed copy
+template <typename T>
+__device__ __forceinline__ Frag<T> tok_frag(unsigned trb, const T* timg, int l31, int t, int fi, int g) {
+  if constexpr (sizeof(T) == 2) return trfrag(trb + (unsigned)((32 * t + 16 * fi) * RP * 2));
+  else return tfrag<T>(timg, l31, t, fi, g);
+}
+
 template <typename T> __device__ __forceinline__ Frag<T> pfrag(const float (&p)[16], int fi) {
   Frag<T> f;
 #pragma unroll
@@ -139,10 +201,10 @@ template <typename T> __device__ __forceinline__ void put_col(T* img, int col, c
 template <typename T> struct RawQKV { u32x4 q[WA<T>::NI], k[WA<T>::NI], v[WA<T>::NI]; };
 
 template <typename T>
-__device__ __forceinline__ void fetch_qkv(RawQKV<T>& r, const T* __restrict__ qkv, long long win, int h, int nw, int res, int C,
+__device__ __forceinline__ void fetch_qkv(RawQKV<T>& r, const T* __restrict__ qkv, const WinPos& wp, int h, int res, int C,
                                           int shift, int lane) {
   using A = WA<T>;
-  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+  const int wx = wp.wx, wy = wp.wy, b = wp.b;
 #pragma unroll
   for (int n = 0; n < A::NI; ++n) {
     int mid;
@@ -166,8 +228,10 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
   unsigned char* base = win_smem + A::BIAS + w * A::FWD_WAVE;
   T* Qn = reinterpret_cast<T*>(base);
   T* Kn = reinterpret_cast<T*>(base + A::ROW_T);
-  T* Vt = reinterpret_cast<T*>(base + 2 * A::ROW_T);
-  int* Mid = reinterpret_cast<int*>(base + 2 * A::ROW_T + A::TR_T);
+  T* Vt = reinterpret_cast<T*>(base + 2 * A::ROW_T);          // bf16: V row-major [token][RP]; fp32: V^T [d][TP]
+  int* Mid = reinterpret_cast<int*>(base + A::FWD_WAVE - WT * 4);
+  unsigned trV = 0;
+  if constexpr (A::TRREAD) trV = tr_base(Vt, lane);
   const int h = blockIdx.x / bph;
   stage_bias(Bs, bias + (size_t)h * WT * WT);
   __syncthreads();
@@ -178,12 +242,16 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
   const int l31 = lane & 31, g = lane >> 5;
   const float sc = scale[h];
   RawQKV<T> raw;
-  if (A::PREFETCH && win_lo < win_hi) fetch_qkv<T>(raw, qkv, win_lo, h, nw, res, C, shift, lane);
+  WinPos nxt;
+  nxt.set(win_lo, nw);
+  if (A::PREFETCH && win_lo < win_hi) fetch_qkv<T>(raw, qkv, nxt, h, res, C, shift, lane);
 #pragma unroll 1
   for (long long win = win_lo; win < win_hi; ++win) {
     const long long unit = win * heads + h;
-    const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
-    if (!A::PREFETCH) fetch_qkv<T>(raw, qkv, win, h, nw, res, C, shift, lane);
+    const int wx = nxt.wx, wy = nxt.wy, b = nxt.b;
+    const bool masked = shift && (wy == nw - 1 || wx == nw - 1);      // only the last row / column of windows mixes regions
+    if (!A::PREFETCH) fetch_qkv<T>(raw, qkv, nxt, h, res, C, shift, lane);
+    nxt.next(nw);
     __builtin_amdgcn_wave_barrier();                   // the previous window's LDS reads are done (same wave, in order)
 #pragma unroll
     for (int n = 0; n < A::NI; ++n) {
@@ -198,8 +266,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
         nq += q[e] * q[e];
         nk += k[e] * k[e];
       }
-      const float iq = 1.f / fmaxf(sqrtf(token_sum<T>(nq)), 1e-12f);            // F.normalize(eps = 1e-12)
-      const float ik = 1.f / fmaxf(sqrtf(token_sum<T>(nk)), 1e-12f);
+      const float iq = inv_norm(token_sum<T>(nq)), ik = inv_norm(token_sum<T>(nk));   // F.normalize(eps = 1e-12)
 #pragma unroll
       for (int e = 0; e < A::EP; ++e) {
         q[e] *= iq;
@@ -207,15 +274,19 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
       }
       *reinterpret_cast<u32x4*>(Qn + tk * RP + ch * A::EP) = pack16<T>(q);
       *reinterpret_cast<u32x4*>(Kn + tk * RP + ch * A::EP) = pack16<T>(k);
+      if constexpr (A::TRREAD) {
+        *reinterpret_cast<u32x4*>(Vt + tk * RP + ch * A::EP) = raw.v[n];
+      } else {
 #pragma unroll
-      for (int e = 0; e < A::EP; ++e) Vt[(ch * A::EP + e) * TP + tk] = from_f32<T>(v[e]);
+        for (int e = 0; e < A::EP; ++e) Vt[(ch * A::EP + e) * TP + tk] = from_f32<T>(v[e]);
+      }
       if (ch == 0) {
         int mid;
         (void)win_token(tk, wy, wx, res, shift, mid);
         Mid[tk] = mid;
       }
     }
-    if (A::PREFETCH && win + 1 < win_hi) fetch_qkv<T>(raw, qkv, win + 1, h, nw, res, C, shift, lane);
+    if (A::PREFETCH && win + 1 < win_hi) fetch_qkv<T>(raw, qkv, nxt, h, res, C, shift, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
@@ -236,18 +307,24 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int c = 0; c < A::NCH; ++c) mma(acc, rowfrag<T>(Kn, 32 * t + l31, c, g), qf[c]);
+        auto logits = [&](auto MK) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {                 // registers 4 q4 .. +3 <-> keys 32 t + 8 q4 + 4 g + 0..3
-          const int k0 = 32 * t + 8 * q4 + 4 * g;
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
+          for (int q4 = 0; q4 < 4; ++q4) {               // registers 4 q4 .. +3 <-> keys 32 t + 8 q4 + 4 g + 0..3
+            const int k0 = 32 * t + 8 * q4 + 4 * g;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[4 * q4 + e] * sc + b4[e];
-            if (shift && Mid[k0 + e] != midq) v += -100.f;
-            s[t][4 * q4 + e] = v;
-            m = fmaxf(m, v);
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[4 * q4 + e] * sc + b4[e];
+              if constexpr (decltype(MK)::value) {
+                if (Mid[k0 + e] != midq) v += -100.f;
+              }
+              s[t][4 * q4 + e] = v;
+              m = fmaxf(m, v);
+            }
           }
-        }
+        };
+        if (masked) logits(std::true_type{});
+        else logits(std::false_type{});
       }
       m = fmaxf(m, __shfl_xor(m, 32, 64));
       float sum = 0.f;
@@ -269,7 +346,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] *= inv;
 #pragma unroll
-        for (int fi = 0; fi < A::FPT; ++fi) mma(o, tfrag<T>(Vt, l31, t, fi, g), pfrag<T>(s[t], fi));
+        for (int fi = 0; fi < A::FPT; ++fi) mma(o, tok_frag<T>(trV, Vt, l31, t, fi, g), pfrag<T>(s[t], fi));
       }
       T* orow = out + ((size_t)b * res * res + tokq) * C + h * HD;       // o[r] = O[q][acc_row(r)]
 #pragma unroll
@@ -280,14 +357,15 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <typename T> struct RawBwd { u32x4 q[WA<T>::NI], k[WA<T>::NI], v[WA<T>::NI], g[WA<T>::NI], o[WA<T>::NI]; };
+template <typename T> struct RawBwd { u32x4 q[WA<T>::NI], k[WA<T>::NI], v[WA<T>::NI], g[WA<T>::NI], o[WA<T>::NI]; float lse; };
 
 template <typename T>
 __device__ __forceinline__ void fetch_bwd(RawBwd<T>& r, const T* __restrict__ qkv, const T* __restrict__ out,
-                                          const T* __restrict__ dout, long long win, int h, int nw, int res, int C, int shift,
-                                          int lane) {
+                                          const T* __restrict__ dout, const float* __restrict__ lse_unit, const WinPos& wp, int h,
+                                          int res, int C, int shift, int lane) {
   using A = WA<T>;
-  const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
+  const int wx = wp.wx, wy = wp.wy, b = wp.b;
+  r.lse = lse_unit[lane];                              // with the operands: asked for inside the park it was an exposed round trip
 #pragma unroll
   for (int n = 0; n < A::NI; ++n) {
     int mid;
@@ -317,10 +395,16 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
   T* Kn = reinterpret_cast<T*>(base + A::ROW_T);
   T* Vr = reinterpret_cast<T*>(base + 2 * A::ROW_T);
   T* Gr = reinterpret_cast<T*>(base + 3 * A::ROW_T);
-  T* Knt = reinterpret_cast<T*>(base + 4 * A::ROW_T);
+  T* Knt = reinterpret_cast<T*>(base + 4 * A::ROW_T);          // transposed copies: fp32 only
   T* Qnt = reinterpret_cast<T*>(base + 4 * A::ROW_T + A::TR_T);
   T* Gt = reinterpret_cast<T*>(base + 4 * A::ROW_T + 2 * A::TR_T);
-  float* Ls = reinterpret_cast<float*>(base + 4 * A::ROW_T + 3 * A::TR_T);
+  float* Ls = reinterpret_cast<float*>(base + A::BWD_WAVE - A::SMALL);
+  unsigned trK = 0, trQ = 0, trG = 0;
+  if constexpr (A::TRREAD) {
+    trK = tr_base(Kn, lane);
+    trQ = tr_base(Qn, lane);
+    trG = tr_base(Gr, lane);
+  }
   float* Ds = Ls + WT;
   float* Rq = Ds + WT;
   float* Rk = Rq + WT;
@@ -343,12 +427,17 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
       for (int r = 0; r < 16; ++r) dbacc[i][t][r] = 0.f;
 
   RawBwd<T> raw;
-  if (A::PREFETCH && win_lo < win_hi) fetch_bwd<T>(raw, qkv, out, dout, win_lo, h, nw, res, C, shift, lane);
+  WinPos nxt;
+  nxt.set(win_lo, nw);
+  if (A::PREFETCH && win_lo < win_hi) fetch_bwd<T>(raw, qkv, out, dout, lse + (win_lo * heads + h) * WT, nxt, h, res, C, shift, lane);
 #pragma unroll 1
   for (long long win = win_lo; win < win_hi; ++win) {
     const long long unit = win * heads + h;            // (window, head) index of lse / dscale_part (forward's order)
-    const int wx = (int)(win % nw), wy = (int)((win / nw) % nw), b = (int)(win / ((long long)nw * nw));
-    if (!A::PREFETCH) fetch_bwd<T>(raw, qkv, out, dout, win, h, nw, res, C, shift, lane);
+    const int wx = nxt.wx, wy = nxt.wy, b = nxt.b;
+    const bool masked = shift && (wy == nw - 1 || wx == nw - 1);      // only the last row / column of windows mixes regions
+    WPROF(0);
+    if (!A::PREFETCH) fetch_bwd<T>(raw, qkv, out, dout, lse + unit * WT, nxt, h, res, C, shift, lane);
+    nxt.next(nw);
     __builtin_amdgcn_wave_barrier();                   // the previous window's LDS reads are done (same wave, in order)
 #pragma unroll
     for (int n = 0; n < A::NI; ++n) {
@@ -365,9 +454,8 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         nk += k[e] * k[e];
         Dq += gg[e] * oo[e];                           // D_i = sum_j p_ij dP_ij = dO_i . O_i
       }
-      const float rq = fmaxf(sqrtf(token_sum<T>(nq)), 1e-12f), rk = fmaxf(sqrtf(token_sum<T>(nk)), 1e-12f);
+      const float iq = inv_norm(token_sum<T>(nq)), ik = inv_norm(token_sum<T>(nk));
       Dq = token_sum<T>(Dq);
-      const float iq = 1.f / rq, ik = 1.f / rk;
 #pragma unroll
       for (int e = 0; e < A::EP; ++e) {
         q[e] *= iq;
@@ -377,25 +465,29 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
       *reinterpret_cast<u32x4*>(Kn + tk * RP + ch * A::EP) = pack16<T>(k);
       *reinterpret_cast<u32x4*>(Vr + tk * RP + ch * A::EP) = raw.v[n];
       *reinterpret_cast<u32x4*>(Gr + tk * RP + ch * A::EP) = raw.g[n];
+      if constexpr (!A::TRREAD) {
 #pragma unroll
-      for (int e = 0; e < A::EP; ++e) {
-        Qnt[(ch * A::EP + e) * TP + tk] = from_f32<T>(q[e]);
-        Knt[(ch * A::EP + e) * TP + tk] = from_f32<T>(k[e]);
-        Gt[(ch * A::EP + e) * TP + tk] = from_f32<T>(gg[e]);
+        for (int e = 0; e < A::EP; ++e) {
+          Qnt[(ch * A::EP + e) * TP + tk] = from_f32<T>(q[e]);
+          Knt[(ch * A::EP + e) * TP + tk] = from_f32<T>(k[e]);
+          Gt[(ch * A::EP + e) * TP + tk] = from_f32<T>(gg[e]);
+        }
       }
       if (ch == 0) {
         int mid;
         (void)win_token(tk, wy, wx, res, shift, mid);
-        Ls[tk] = lse[unit * WT + tk];
         Ds[tk] = Dq;
-        Rq[tk] = rq;
-        Rk[tk] = rk;
+        Rq[tk] = iq;                                   // 1 / |q|, 1 / |k| for the normalisation backward
+        Rk[tk] = ik;
         Mid[tk] = mid;
       }
     }
-    if (A::PREFETCH && win + 1 < win_hi) fetch_bwd<T>(raw, qkv, out, dout, win + 1, h, nw, res, C, shift, lane);
+    Ls[lane] = raw.lse;
+    WPROF(1);
+    if (A::PREFETCH && win + 1 < win_hi) fetch_bwd<T>(raw, qkv, out, dout, lse + (unit + heads) * WT, nxt, h, res, C, shift, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WPROF(2);
     // ================= phase A: lane = query (two 32-query tiles) -> dq, d(bias), d(scale) =================
     float dsc = 0.f;
 #pragma unroll
@@ -425,24 +517,30 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
           mma(da, rowfrag<T>(Vr, 32 * t + l31, c, g), gf[c]);
         }
         float dss[16];
+        auto softmax_bwd = [&](auto MK) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int k0 = 32 * t + 8 * q4 + 4 * g;
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int k0 = 32 * t + 8 * q4 + 4 * g;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q4 + e;
-            float lg = sa[r] * sc + b4[e];
-            if (shift && Mid[k0 + e] != midq) lg += -100.f;
-            const float p = __expf(lg - lq);
-            const float ds = p * (da[r] - Dq);
-            dbacc[i][t][r] += ds;
-            dsc += ds * sa[r];
-            dss[r] = ds * sc;
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * q4 + e;
+              float lg = sa[r] * sc + b4[e];
+              if constexpr (decltype(MK)::value) {
+                if (Mid[k0 + e] != midq) lg += -100.f;
+              }
+              const float p = __expf(lg - lq);
+              const float ds = p * (da[r] - Dq);
+              dbacc[i][t][r] += ds;
+              dsc += ds * sa[r];
+              dss[r] = ds * sc;
+            }
           }
-        }
+        };
+        if (masked) softmax_bwd(std::true_type{});
+        else softmax_bwd(std::false_type{});
 #pragma unroll
-        for (int fi = 0; fi < A::FPT; ++fi) mma(dq, tfrag<T>(Knt, l31, t, fi, g), pfrag<T>(dss, fi));   // rows = d
+        for (int fi = 0; fi < A::FPT; ++fi) mma(dq, tok_frag<T>(trK, Knt, l31, t, fi, g), pfrag<T>(dss, fi));   // rows = d
       }
       // d(x/|x|) = (I - n n^T) dy / |x| ; dq[r] belongs to d = acc_row(r), the other 16 d live in lane ^ 32
       float qn[16];
@@ -457,7 +555,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         }
       }
       proj += __shfl_xor(proj, 32, 64);
-      const float ir = 1.f / Rq[q];
+      const float ir = Rq[q];
       T* drow = dqkv + ((size_t)b * res * res + tokq) * 3 * C + h * HD;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
@@ -469,6 +567,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
     }
     dsc = wave_sum(dsc);
     if (lane == 0) dscale_part[unit] = dsc;
+    WPROF(3);
     // ================= phase B: lane = key (two 32-key tiles) -> dk, dv =================
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -496,25 +595,31 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
           mma(da, rowfrag<T>(Gr, 32 * i + l31, c, g), vf[c]);
         }
         float pp[16], dss[16];
+        auto softmax_bwd = [&](auto MK) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int q0 = 32 * i + 8 * q4 + 4 * g;
-          const f32x4 b4 = {bcol[q0 * BP], bcol[(q0 + 1) * BP], bcol[(q0 + 2) * BP], bcol[(q0 + 3) * BP]};
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + q0), d4 = *reinterpret_cast<const f32x4*>(Ds + q0);
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int q0 = 32 * i + 8 * q4 + 4 * g;
+            const f32x4 b4 = {bcol[q0 * BP], bcol[(q0 + 1) * BP], bcol[(q0 + 2) * BP], bcol[(q0 + 3) * BP]};
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + q0), d4 = *reinterpret_cast<const f32x4*>(Ds + q0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q4 + e;
-            float lg = sa[r] * sc + b4[e];
-            if (shift && Mid[q0 + e] != midk) lg += -100.f;
-            const float p = __expf(lg - l4[e]);
-            pp[r] = p;
-            dss[r] = p * (da[r] - d4[e]) * sc;
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * q4 + e;
+              float lg = sa[r] * sc + b4[e];
+              if constexpr (decltype(MK)::value) {
+                if (Mid[q0 + e] != midk) lg += -100.f;
+              }
+              const float p = __expf(lg - l4[e]);
+              pp[r] = p;
+              dss[r] = p * (da[r] - d4[e]) * sc;
+            }
           }
-        }
+        };
+        if (masked) softmax_bwd(std::true_type{});
+        else softmax_bwd(std::false_type{});
 #pragma unroll
         for (int fi = 0; fi < A::FPT; ++fi) {
-          mma(dv, tfrag<T>(Gt, l31, i, fi, g), pfrag<T>(pp, fi));
-          mma(dk, tfrag<T>(Qnt, l31, i, fi, g), pfrag<T>(dss, fi));
+          mma(dv, tok_frag<T>(trG, Gt, l31, i, fi, g), pfrag<T>(pp, fi));
+          mma(dk, tok_frag<T>(trQ, Qnt, l31, i, fi, g), pfrag<T>(dss, fi));
         }
       }
       float kn[16];
@@ -529,7 +634,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         }
       }
       proj += __shfl_xor(proj, 32, 64);
-      const float ir = 1.f / Rk[key];
+      const float ir = Rk[key];
       T* drow = dqkv + ((size_t)b * res * res + tokk) * 3 * C + h * HD;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
@@ -543,6 +648,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         store4<T>(drow + 2 * C + rq * 8 + g * 4, o2);
       }
     }
+    WPROF(4);
   }
   // d(bias)[h][query][key] of this wave's windows -> its own partial slice [wave of the head][head][64][64]; summed over waves
   // by the batched deterministic reduction (reduce.hip).  (Global atomics here cost 5 ms of a 20 ms step: every
@@ -657,5 +763,11 @@ int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, cons
     return launch_bwd<float>(qkv, out, dout, bias, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads, shift, st);
   return RGBNM_EINVAL;
 }
+
+#ifdef WIN_PROF
+int rgbnm_debug_win_prof(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_win_prof), sizeof(unsigned long long) * 1024 * 4 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"
