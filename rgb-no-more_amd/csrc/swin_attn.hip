@@ -28,11 +28,19 @@
 
 namespace {
 
-#ifdef WIN_PROF   // experiments only: cycle stamps of every wave's second window (tools/winattn_prof.py)
+#ifdef WIN_PROF   // experiments only: cycle stamps of every wave's second window (tools/winattn_prof.py); 1 = backward, 2 = forward
 __device__ unsigned long long g_win_prof[1024 * 4 * 8];
-#define WPROF(i) do { if (lane == 0 && win == win_lo + 1 && blockIdx.x < 1024) g_win_prof[(blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define WPROF_(i) do { if (lane == 0 && win == win_lo + 1 && blockIdx.x < 1024) g_win_prof[(blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#if WIN_PROF == 2
+#define WPROF(i) do { } while (0)
+#define WPROFF(i) WPROF_(i)
+#else
+#define WPROF(i) WPROF_(i)
+#define WPROFF(i) do { } while (0)
+#endif
 #else
 #define WPROF(i) do { } while (0)
+#define WPROFF(i) do { } while (0)
 #endif
 
 constexpr int WS = 8, WT = 64, HD = 32;
@@ -53,7 +61,9 @@ template <typename T> struct WA {
   // ds_read_b64_tr_b16; fp32 has no transposing read and parks transposed copies
   static constexpr bool TRREAD = sizeof(T) == 2;
   static constexpr int FWD_WAVE = 2 * ROW_T + (TRREAD ? ROW_T : TR_T) + WT * 4;   // Qn, Kn, V (bf16) / V^T (fp32), mask id
-  static constexpr int BWD_WAVE = 4 * ROW_T + (TRREAD ? 0 : 3 * TR_T) + SMALL;
+  // backward: Qn, Kn, V, dO rows (+ bf16: a staging tile for dq; dk / dv are staged in their own dead Kn / V rows)
+  static constexpr bool STAGE_DQ = sizeof(T) == 2;
+  static constexpr int BWD_WAVE = 4 * ROW_T + (TRREAD ? 0 : 3 * TR_T) + (STAGE_DQ ? ROW_T : 0) + SMALL;
   static constexpr int FWD_WAVES = 4;
   static constexpr int BWD_WAVES = sizeof(T) == 2 ? 4 : 2;
   static constexpr int BIAS = WT * BP * 4;                // the workgroup's head: bias[64][BP] fp32
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
     const long long unit = win * heads + h;
     const int wx = nxt.wx, wy = nxt.wy, b = nxt.b;
     const bool masked = shift && (wy == nw - 1 || wx == nw - 1);      // only the last row / column of windows mixes regions
+    WPROFF(0);
     if (!A::PREFETCH) fetch_qkv<T>(raw, qkv, nxt, h, res, C, shift, lane);
     nxt.next(nw);
     __builtin_amdgcn_wave_barrier();                   // the previous window's LDS reads are done (same wave, in order)
@@ -286,14 +297,16 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
         Mid[tk] = mid;
       }
     }
+    WPROFF(1);
     if (A::PREFETCH && win + 1 < win_hi) fetch_qkv<T>(raw, qkv, nxt, h, res, C, shift, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WPROFF(2);
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
       const int q = 32 * i + l31;
       int midq;
-      const int tokq = win_token(q, wy, wx, res, shift, midq);
+      (void)win_token(q, wy, wx, res, shift, midq);
       Frag<T> qf[A::NCH];
 #pragma unroll
       for (int c = 0; c < A::NCH; ++c) qf[c] = rowfrag<T>(Qn, q, c, g);
@@ -348,11 +361,24 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int fi = 0; fi < A::FPT; ++fi) mma(o, tok_frag<T>(trV, Vt, l31, t, fi, g), pfrag<T>(s[t], fi));
       }
-      T* orow = out + ((size_t)b * res * res + tokq) * C + h * HD;       // o[r] = O[q][acc_row(r)]
+      // o[r] = O[q][acc_row(r)] -> the tile's own (now dead) Qn rows; HBM gets whole 64-byte token slices below
+      T* orow = Qn + q * RP;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq)
         store4<T>(orow + rq * 8 + g * 4, (f32x4){o[rq * 4 + 0], o[rq * 4 + 1], o[rq * 4 + 2], o[rq * 4 + 3]});
+      WPROFF(3 + i);
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < A::NI; ++n) {                  // the gather's geometry backwards: 16-byte pieces, LPT lanes per token
+      const int tk = n * A::TPI + lane / A::LPT, ch = lane % A::LPT;
+      int mid;
+      const int tok = win_token(tk, wy, wx, res, shift, mid);
+      *reinterpret_cast<u32x4*>(out + ((size_t)b * res * res + tok) * C + h * HD + ch * A::EP) =
+          *reinterpret_cast<const u32x4*>(Qn + tk * RP + ch * A::EP);
+    }
+    WPROFF(5);
   }
 }
 
@@ -398,6 +424,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
   T* Knt = reinterpret_cast<T*>(base + 4 * A::ROW_T);          // transposed copies: fp32 only
   T* Qnt = reinterpret_cast<T*>(base + 4 * A::ROW_T + A::TR_T);
   T* Gt = reinterpret_cast<T*>(base + 4 * A::ROW_T + 2 * A::TR_T);
+  T* St = reinterpret_cast<T*>(base + A::BWD_WAVE - A::SMALL - A::ROW_T);      // bf16 only
   float* Ls = reinterpret_cast<float*>(base + A::BWD_WAVE - A::SMALL);
   unsigned trK = 0, trQ = 0, trG = 0;
   if constexpr (A::TRREAD) {
@@ -556,7 +583,8 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
       }
       proj += __shfl_xor(proj, 32, 64);
       const float ir = Rq[q];
-      T* drow = dqkv + ((size_t)b * res * res + tokq) * 3 * C + h * HD;
+      // bf16: rows go to the staging tile and leave as whole 64-byte token slices (16 lines per store instruction instead of 64)
+      T* drow = A::STAGE_DQ ? St + q * RP : dqkv + ((size_t)b * res * res + tokq) * 3 * C + h * HD;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         f32x4 o;
@@ -567,6 +595,18 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
     }
     dsc = wave_sum(dsc);
     if (lane == 0) dscale_part[unit] = dsc;
+    if constexpr (A::STAGE_DQ) {
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int n = 0; n < A::NI; ++n) {
+        const int tk = n * A::TPI + lane / A::LPT, ch = lane % A::LPT;
+        int mid;
+        const int tok = win_token(tk, wy, wx, res, shift, mid);
+        *reinterpret_cast<u32x4*>(dqkv + ((size_t)b * res * res + tok) * 3 * C + h * HD + ch * A::EP) =
+            *reinterpret_cast<const u32x4*>(St + tk * RP + ch * A::EP);
+      }
+    }
     WPROF(3);
     // ================= phase B: lane = key (two 32-key tiles) -> dk, dv =================
 #pragma unroll
@@ -635,7 +675,9 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
       }
       proj += __shfl_xor(proj, 32, 64);
       const float ir = Rk[key];
-      T* drow = dqkv + ((size_t)b * res * res + tokk) * 3 * C + h * HD;
+      // dk / dv rows replace the key tile's own Kn / V rows (kf, vf and kn are in registers; nobody else reads these rows in
+      // this phase) and leave as whole token slices after both tiles
+      (void)tokk;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         f32x4 o, o2;
@@ -644,9 +686,20 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
           o[e] = (dk[rq * 4 + e] - kn[rq * 4 + e] * proj) * ir;
           o2[e] = dv[rq * 4 + e];
         }
-        store4<T>(drow + C + rq * 8 + g * 4, o);
-        store4<T>(drow + 2 * C + rq * 8 + g * 4, o2);
+        store4<T>(Kn + key * RP + rq * 8 + g * 4, o);
+        store4<T>(Vr + key * RP + rq * 8 + g * 4, o2);
       }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < A::NI; ++n) {
+      const int tk = n * A::TPI + lane / A::LPT, ch = lane % A::LPT;
+      int mid;
+      const int tok = win_token(tk, wy, wx, res, shift, mid);
+      T* drow = dqkv + ((size_t)b * res * res + tok) * 3 * C + h * HD + ch * A::EP;
+      *reinterpret_cast<u32x4*>(drow + C) = *reinterpret_cast<const u32x4*>(Kn + tk * RP + ch * A::EP);
+      *reinterpret_cast<u32x4*>(drow + 2 * C) = *reinterpret_cast<const u32x4*>(Vr + tk * RP + ch * A::EP);
     }
     WPROF(4);
   }

@@ -10,6 +10,7 @@ import torch
 from rgb_no_more_amd import lib as L
 
 B, res, Cc, heads, shift = 256, 64, 96, 3, int(sys.argv[1]) if len(sys.argv) > 1 else 0
+FWD = len(sys.argv) > 2 and sys.argv[2] == "fwd"         # built with -DWIN_PROF=2
 lib = L.lib()
 M = B * res * res
 dt = torch.bfloat16
@@ -37,9 +38,9 @@ f = lib.rgbnm_debug_win_prof
 f.restype = C.c_int
 f.argtypes = [C.c_void_p]
 assert f(buf.ctypes.data) == 0
-p = buf.reshape(1024, 4, 8).astype(np.int64)[:255]
-names = ["", "park (unpack, norms, LDS writes)", "prefetch issue + LDS drain", "phase A (dq, dbias, dscale) + stores", "phase B (dk, dv) + stores"]
-for i in range(1, 5):
+p = buf.reshape(1024, 4, 8).astype(np.int64)[:255 if not FWD else 510]
+names = ["", "park", "prefetch issue + LDS drain", "query tile 0 (S, softmax, PV, park O)", "query tile 1", "store O"] if FWD else ["", "park (unpack, norms, LDS writes)", "prefetch issue + LDS drain", "phase A (dq, dbias, dscale) + stores", "phase B (dk, dv) + stores"]
+for i in range(1, len(names)):
     d = p[:, :, i] - p[:, :, i - 1]
     print(f"{names[i]:44s} mean {d.mean():8.0f}  min {d.min():8.0f}  max {d.max():8.0f}")
-print("window total", (p[:, :, 4] - p[:, :, 0]).mean())
+print("window total", (p[:, :, len(names) - 1] - p[:, :, 0]).mean())
