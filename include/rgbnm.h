@@ -89,7 +89,9 @@ typedef struct rgbnm_linear_desc {
   int add_identity;    /* shadows hold W + I (residual Linear y = x W^T + x, plainvit.py:345-347) */
   int ldn;             /* row stride of the [K,N] shadow; 0 = N.  > N pads N for 16-byte rows (a class count that is not a
                           multiple of 8: the [N,K] shadow then has ldn rows too, the extra ones left as the caller zeroed them) */
-  int reserved;
+  int pair;            /* != 0: block-diagonal shadows diag(W, W) [2N,2K] and diag(W^T, W^T) [2K,2N] (off-diagonal blocks left as
+                          the caller zeroed them).  x [M,K] read as [M/2,2K] times diag(W,W)^T is y [M,N] read as [M/2,2N]: a
+                          96-wide Linear (SwinV2-T stage 1) then runs on the kernels tuned for 192-wide rows            */
 } rgbnm_linear_desc;
 
 /* master fp32 -> per-step operand shadows for every Linear (descs_dev: device array of ndesc descriptors). */

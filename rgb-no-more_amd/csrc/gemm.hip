@@ -625,7 +625,12 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
       if (r < d.N && c < d.K) {
         const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
         v = master[d.w_off + (size_t)src * d.K + c] + ((d.add_identity && r == c) ? 1.0f : 0.0f);
-        shadow[d.ws_off + (size_t)r * d.K + c] = from_f32<T>(v);
+        if (d.pair) {                                            // diag(W, W): row pitch 2K, second copy at (N, K)
+          shadow[d.ws_off + (size_t)r * (2 * d.K) + c] = from_f32<T>(v);
+          shadow[d.ws_off + (size_t)(d.N + r) * (2 * d.K) + d.K + c] = from_f32<T>(v);
+        } else {
+          shadow[d.ws_off + (size_t)r * d.K + c] = from_f32<T>(v);
+        }
       }
       tile[ty + 8 * k][tx] = v;
     }
@@ -633,7 +638,14 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + ty + 8 * k, r = r0 + tx;
-      if (r < d.N && c < d.K) shadow[d.wst_off + (size_t)c * (d.ldn > 0 ? d.ldn : d.N) + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+      if (r < d.N && c < d.K) {
+        if (d.pair) {
+          shadow[d.wst_off + (size_t)c * (2 * d.N) + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+          shadow[d.wst_off + (size_t)(d.K + c) * (2 * d.N) + d.N + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+        } else {
+          shadow[d.wst_off + (size_t)c * (d.ldn > 0 ? d.ldn : d.N) + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+        }
+      }
     }
     __syncthreads();
   }

@@ -32,6 +32,19 @@
 #undef KP_NSTAGE
 #undef KP_BIAS_LDS
 
+// kp8: 8 waves x 32 rows = 256-row panels, 2-stage ring (112 KB), plain epilogues only.  For row counts that are multiples of
+// 256 but not of 224 -- the SwinV2-T stages at B = 256 (M = 2^20, 2^18, 2^16, 2^14) -- every round of workgroups is full:
+// at M = 16384, N = 768 the 224-row panels made 296 workgroups (two rounds on 256 CUs) where 256 of these make one.
+#define KP_NS kp8
+#define KP_NWAVES 8
+#define KP_NSTAGE 2
+#define KP_BIAS_LDS true
+#include "gemm_nt_kpipe_body.inc"
+#undef KP_NS
+#undef KP_NWAVES
+#undef KP_NSTAGE
+#undef KP_BIAS_LDS
+
 // Geometry choice: option "kp_split" = 1 runs the two-workgroups-per-CU geometry (kp4) for the single-column-tile shapes
 // (N = 192: proj / fc2 with the LayerNorm epilogue, the dX GEMMs with the LayerNorm backward); 0 = one 7-wave workgroup per CU.
 static bool use_split(int N) { return N == 192 && rgbnm_get_option("kp_split") != 0; }
@@ -57,6 +70,7 @@ int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, 
 // returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st) {
+  if (M % 256 == 0 && M % 224 != 0 && rgbnm_get_option("kp8")) return kp8::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
   return use_split(N) ? kp4::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st)
                       : kp7::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
 }

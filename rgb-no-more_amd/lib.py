@@ -16,7 +16,7 @@ _vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
 class LinearDesc(C.Structure):
     _fields_ = [("w_off", _ll), ("b_off", _ll), ("ws_off", _ll), ("wst_off", _ll), ("bperm_off", _ll),
-                ("N", _i), ("K", _i), ("perm_heads", _i), ("add_identity", _i), ("ldn", _i), ("reserved", _i)]
+                ("N", _i), ("K", _i), ("perm_heads", _i), ("add_identity", _i), ("ldn", _i), ("pair", _i)]
 
 
 class VitCfg(C.Structure):

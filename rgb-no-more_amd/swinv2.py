@@ -58,23 +58,55 @@ def _gemm_tn(dY, X, want_bias):
     return dW, db
 
 
+def _paired(sh, W):
+    """Row pairing: the shadow is diag(W, W) (rgbnm_linear_desc.pair).  x [M,K] viewed as [M/2,2K] times diag(W,W)^T IS
+    y [M,N] viewed as [M/2,2N], so the 96-wide Linears of SwinV2-T's first stage (N or K = 96 / 288: no multiple of the 192-column
+    tiles) run on the kernels tuned for 192-wide rows; the zero blocks cost MFMA work these HBM-bound GEMMs have to spare."""
+    return sh[0].shape[0] == 2 * W.shape[0]
+
+
+def _nt(epi, x, Wsh, pair, bias=None, R=None, want_c2=False):
+    if not pair:
+        return _gemm_nt(epi, x, Wsh, bias, R, want_c2)
+    M = x.shape[0]
+    if M % 2:
+        raise ValueError("row pairing needs an even number of rows")
+    N2 = Wsh.shape[0]
+    y, c2 = _gemm_nt(epi, x.view(M // 2, -1), Wsh, None if bias is None else torch.cat((bias, bias)),
+                     None if R is None else R.view(M // 2, N2), want_c2)
+    return y.view(M, N2 // 2), None if c2 is None else c2.view(M, N2 // 2)
+
+
+def _tn(dy, x, want_bias, pair):
+    if not pair:
+        return _gemm_tn(dy, x, want_bias)
+    M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+    dW2, db2 = _gemm_tn(dy.view(M // 2, 2 * N), x.view(M // 2, 2 * K), want_bias)     # [[e.e, e.o], [o.e, o.o]] row parities
+    return dW2[:N, :K] + dW2[N:, K:], None if db2 is None else db2[:N] + db2[N:]
+
+
+def _fbias(b):
+    return None if b is None else b.detach().float().contiguous()
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b  (x [M,K] in the compute dtype, W fp32 master [N,K], b fp32 or None).  sh = (W, W^T) in the
     compute dtype from the per-step shadow buffer (rgbnm_prep_weights): no per-layer cast / transpose kernels."""
 
     @staticmethod
     def forward(ctx, x, W, b, sh):
-        y, _ = _gemm_nt(L.EPI_NONE, x, sh[0], None if b is None else b.detach().float().contiguous())
+        pair = _paired(sh, W)
+        y, _ = _nt(L.EPI_NONE, x, sh[0], pair, _fbias(b))
         ctx.save_for_backward(x)
-        ctx.sh, ctx.has_b = sh, b is not None
+        ctx.sh, ctx.has_b, ctx.pair = sh, b is not None, pair
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = dy.contiguous()
-        dW, db = _gemm_tn(dy, x, ctx.has_b)
-        dx, _ = _gemm_nt(L.EPI_NONE, dy, ctx.sh[1])
+        dW, db = _tn(dy, x, ctx.has_b, ctx.pair)
+        dx, _ = _nt(L.EPI_NONE, dy, ctx.sh[1], ctx.pair)
         return dx, dW, db, None
 
 
@@ -84,20 +116,21 @@ class _MlpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, sh1, sh2):
-        g, gp = _gemm_nt(L.EPI_GELU, x, sh1[0], b1.detach().float().contiguous(), want_c2=True)
-        y, _ = _gemm_nt(L.EPI_NONE, g, sh2[0], b2.detach().float().contiguous())
+        p1, p2 = _paired(sh1, W1), _paired(sh2, W2)
+        g, gp = _nt(L.EPI_GELU, x, sh1[0], p1, _fbias(b1), want_c2=True)
+        y, _ = _nt(L.EPI_NONE, g, sh2[0], p2, _fbias(b2))
         ctx.save_for_backward(x, g, gp)
-        ctx.sh1, ctx.sh2 = sh1, sh2
+        ctx.sh1, ctx.sh2, ctx.p1, ctx.p2 = sh1, sh2, p1, p2
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, gp = ctx.saved_tensors
         dy = dy.contiguous()
-        dW2, db2 = _gemm_tn(dy, g, True)
-        du, _ = _gemm_nt(L.EPI_DGELU, dy, ctx.sh2[1], None, R=gp)
-        dW1, db1 = _gemm_tn(du, x, True)
-        dx, _ = _gemm_nt(L.EPI_NONE, du, ctx.sh1[1])
+        dW2, db2 = _tn(dy, g, True, ctx.p2)
+        du, _ = _nt(L.EPI_DGELU, dy, ctx.sh2[1], ctx.p2, None, R=gp)
+        dW1, db1 = _tn(du, x, True, ctx.p1)
+        dx, _ = _nt(L.EPI_NONE, du, ctx.sh1[1], ctx.p1)
         return dx, dW1, db1, dW2, db2, None, None
 
 
@@ -434,10 +467,13 @@ class SwinTransformerV2(FlatParamModule):
         self._sh_off, so = {}, 0
         for k, name in enumerate(lin):
             Nn, Kk = self._shapes[name + ".weight"]
-            ws, wst = so, so + align(Nn * Kk)
-            so = wst + align(Nn * Kk)
-            descs[k] = L.LinearDesc(self._offs[name + ".weight"], 0, ws, wst, 0, Nn, Kk, 0, 0)
-            self._sh_off[name] = (ws, wst, Nn, Kk)
+            # row pairing (see _paired): widths that are multiples of 96 but not both of 192 -- the first stage of SwinV2-T
+            pair = int(Nn % 96 == 0 and Kk % 96 == 0 and (Nn % 192 != 0 or Kk % 192 != 0) and max(Nn, Kk) <= 384)
+            nel = Nn * Kk * (4 if pair else 1)
+            ws, wst = so, so + align(nel)
+            so = wst + align(nel)
+            descs[k] = L.LinearDesc(self._offs[name + ".weight"], 0, ws, wst, 0, Nn, Kk, 0, 0, 0, pair)
+            self._sh_off[name] = (ws, wst, Nn * (2 if pair else 1), Kk * (2 if pair else 1))
         self._ndesc, self._sh_total = len(lin), so
         self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         self._shadow, self._sh_views = {}, {}

@@ -449,11 +449,13 @@ def test_gemm_nt_bf16_row_panel_path(option, M, K):
     assert torch.equal(gemm_nt(dt, L.EPI_NONE, A, W, b)[0], outs[1][1])
 
 
-@pytest.mark.parametrize("M,N,K", [(224 * 40 + 17, 384, 384), (50176, 1152, 384), (12544, 1536, 384), (9000, 384, 1536)])
+@pytest.mark.parametrize("M,N,K", [(224 * 40 + 17, 384, 384), (50176, 1152, 384), (12544, 1536, 384), (9000, 384, 1536),
+                                   (16384, 768, 768), (16384, 768, 3072), (65536, 384, 1536), (8192, 1152, 384)])
 def test_gemm_nt_bf16_row_panel_column_tiles(option, M, N, K):
     """N a multiple of 192 (JPEG-S: 384 / 1152 / 1536 wide Linears): the row-panel kernel walks 224-row panels x
     192-column tiles, with the residual, GELU (+ GELU') and dGELU epilogues.  Same bits as the tile-per-workgroup kernel
-    (same k order and rounding points), ragged last panel included."""
+    (same k order and rounding points), ragged last panel included.  Row counts that are multiples of 256 and not of 224 (the
+    SwinV2-T stages) take the 8-wave / 256-row geometry (kp8)."""
     dt = torch.bfloat16
     A = dev(detfill.normalish((M, K), 51), dt)
     W = dev(detfill.uniform((N, K), 52, -0.1, 0.1), dt)

@@ -2,7 +2,7 @@
 """The eight activation GEMMs of one JPEG-S encoder block (E = 384, B = 256: M = 50176 rows) through rgbnm_gemm_nt, with the
 library GEMM torch dispatches to (hipBLASLt / rocBLAS) beside each as a yardstick -- what a tuned plain GEMM of that shape takes
 on this GPU.  The yardstick has no fused epilogue: its time is a lower bound for the plain part only.
-usage: python tools/nt384_probe.py [E] [out.json]"""
+usage: python tools/nt384_probe.py [E] [out.json] [M]     (SwinV2-T stages at B = 256: E, M = 96, 1048576 / 192, 262144 / 384, 65536 / 768, 16384)"""
 import json
 import os
 import sys
@@ -28,7 +28,10 @@ def timeit(fn, n=30):
 
 
 def main():
+    global M
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+    if len(sys.argv) > 3:
+        M = int(sys.argv[3])
     lib = L.lib()
     dt = torch.bfloat16
     g = torch.Generator(device=DEV)
@@ -49,8 +52,9 @@ def main():
         lib_t = timeit(lambda: torch.matmul(A, Wt, out=Cc))
         lib_nt = timeit(lambda: torch.nn.functional.linear(A, W))
         gf = 2.0 * M * N * K / 1e9
+        mb = 2.0 * M * (K + N * (1 + int(res) + 2 * int(c2) if epi != 4 else 2 * N + K - N)) / 1e6 if False else 2.0 * M * (K + N + (N if res else 0) + (N if c2 else 0)) / 1e6
         rows.append(dict(name=name, N=N, K=K, epi=epi, ours_us=round(ours, 1), torch_mm_us=round(lib_t, 1),
-                         torch_linear_us=round(lib_nt, 1), gflop=round(gf, 1), ours_tflops=round(gf / ours * 1e3, 1),
+                         torch_linear_us=round(lib_nt, 1), gflop=round(gf, 1), MB=round(mb, 1), ours_TBps=round(mb / ours, 2), ours_tflops=round(gf / ours * 1e3, 1),
                          lib_tflops=round(gf / min(lib_t, lib_nt) * 1e3, 1)))
         print(rows[-1], flush=True)
 
@@ -65,7 +69,7 @@ def main():
     nt("dX of qkv", E, I, 0)
     tot = sum(r["ours_us"] for r in rows)
     print("sum ours %.1f us, library (plain) %.1f us" % (tot, sum(min(r["torch_mm_us"], r["torch_linear_us"]) for r in rows)))
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[2] != "-":
         json.dump(rows, open(sys.argv[2], "w"), indent=1)
 
 
