@@ -52,7 +52,7 @@ def main():
         lib_t = timeit(lambda: torch.matmul(A, Wt, out=Cc))
         lib_nt = timeit(lambda: torch.nn.functional.linear(A, W))
         gf = 2.0 * M * N * K / 1e9
-        mb = 2.0 * M * (K + N * (1 + int(res) + 2 * int(c2) if epi != 4 else 2 * N + K - N)) / 1e6 if False else 2.0 * M * (K + N + (N if res else 0) + (N if c2 else 0)) / 1e6
+        mb = 2.0 * M * (K + N + (N if res else 0) + (N if c2 else 0)) / 1e6      # algorithmic bytes: A in, C (+ R in, + C2) out
         rows.append(dict(name=name, N=N, K=K, epi=epi, ours_us=round(ours, 1), torch_mm_us=round(lib_t, 1),
                          torch_linear_us=round(lib_nt, 1), gflop=round(gf, 1), MB=round(mb, 1), ours_TBps=round(mb / ours, 2), ours_tflops=round(gf / ours * 1e3, 1),
                          lib_tflops=round(gf / min(lib_t, lib_nt) * 1e3, 1)))
