@@ -94,20 +94,25 @@ class _LinearFn(torch.autograd.Function):
     compute dtype from the per-step shadow buffer (rgbnm_prep_weights): no per-layer cast / transpose kernels."""
 
     @staticmethod
-    def forward(ctx, x, W, b, sh):
+    def forward(ctx, x, W, b, sh, fork=False):
+        """fork: also hand x back as a second output for the block's shortcut -- its gradient then arrives HERE and rides the
+        dX GEMM's residual epilogue instead of costing autograd an [M,C] add kernel at the fork (24 per SwinV2-T step)."""
         pair = _paired(sh, W)
         y, _ = _nt(L.EPI_NONE, x, sh[0], pair, _fbias(b))
         ctx.save_for_backward(x)
         ctx.sh, ctx.has_b, ctx.pair = sh, b is not None, pair
-        return y
+        return (y, x) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxs=None):
         (x,) = ctx.saved_tensors
         dy = dy.contiguous()
         dW, db = _tn(dy, x, ctx.has_b, ctx.pair)
-        dx, _ = _nt(L.EPI_NONE, dy, ctx.sh[1], ctx.pair)
-        return dx, dW, db, None
+        if dxs is None:
+            dx, _ = _nt(L.EPI_NONE, dy, ctx.sh[1], ctx.pair)
+        else:
+            dx, _ = _nt(L.EPI_RES, dy, ctx.sh[1], ctx.pair, None, R=dxs.contiguous())
+        return dx, dW, db, None, None
 
 
 class _MlpFn(torch.autograd.Function):
@@ -115,23 +120,26 @@ class _MlpFn(torch.autograd.Function):
     fused into fc2's dX GEMM (swinv2.py:19-35)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, sh1, sh2):
+    def forward(ctx, x, W1, b1, W2, b2, sh1, sh2, fork=False):
         p1, p2 = _paired(sh1, W1), _paired(sh2, W2)
         g, gp = _nt(L.EPI_GELU, x, sh1[0], p1, _fbias(b1), want_c2=True)
         y, _ = _nt(L.EPI_NONE, g, sh2[0], p2, _fbias(b2))
         ctx.save_for_backward(x, g, gp)
         ctx.sh1, ctx.sh2, ctx.p1, ctx.p2 = sh1, sh2, p1, p2
-        return y
+        return (y, x) if fork else y                   # fork: see _LinearFn
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxs=None):
         x, g, gp = ctx.saved_tensors
         dy = dy.contiguous()
         dW2, db2 = _tn(dy, g, True, ctx.p2)
         du, _ = _nt(L.EPI_DGELU, dy, ctx.sh2[1], ctx.p2, None, R=gp)
         dW1, db1 = _tn(du, x, True, ctx.p1)
-        dx, _ = _nt(L.EPI_NONE, du, ctx.sh1[1], ctx.p1)
-        return dx, dW1, db1, dW2, db2, None, None
+        if dxs is None:
+            dx, _ = _nt(L.EPI_NONE, du, ctx.sh1[1], ctx.p1)
+        else:
+            dx, _ = _nt(L.EPI_RES, du, ctx.sh1[1], ctx.p1, None, R=dxs.contiguous())
+        return dx, dW1, db1, dW2, db2, None, None, None
 
 
 class _LNFn(torch.autograd.Function):
@@ -319,13 +327,13 @@ class SwinTransformerBlock(nn.Module):
         a = self.attn
         bias, scale = a.bias_and_scale()
         qb = torch.cat((a.q_bias, torch.zeros_like(a.v_bias, requires_grad=False), a.v_bias))
-        qkv = _LinearFn.apply(x, a.qkv.weight, qb, sh[pre + "attn.qkv"])
+        qkv, xs = _LinearFn.apply(x, a.qkv.weight, qb, sh[pre + "attn.qkv"], True)      # xs = x: the shortcut (fork)
         o = _WinAttnFn.apply(qkv, bias, scale, B, res, C_, self.num_heads, self.shift_size)
         o = _LinearFn.apply(o, a.proj.weight, a.proj.bias, sh[pre + "attn.proj"])
-        x = _LNFn.apply(o, self.norm1.weight, self.norm1.bias, x, self._drop_scale(B, x.device), res * res)
-        h = _MlpFn.apply(x, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
-                         sh[pre + "mlp.fc1"], sh[pre + "mlp.fc2"])
-        return _LNFn.apply(h, self.norm2.weight, self.norm2.bias, x, self._drop_scale(B, x.device), res * res)
+        x = _LNFn.apply(o, self.norm1.weight, self.norm1.bias, xs, self._drop_scale(B, x.device), res * res)
+        h, xs = _MlpFn.apply(x, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
+                             sh[pre + "mlp.fc1"], sh[pre + "mlp.fc2"], True)
+        return _LNFn.apply(h, self.norm2.weight, self.norm2.bias, xs, self._drop_scale(B, x.device), res * res)
 
 
 class PatchMerging(nn.Module):
