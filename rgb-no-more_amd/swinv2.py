@@ -201,9 +201,9 @@ class _WinAttnFn(torch.autograd.Function):
         ws = _ws(qkv.device, wsb)
         nw = (res // WS) ** 2
         dsp = torch.empty(B * nw * heads, device=qkv.device, dtype=torch.float32)
-        bias_t = bias_c.transpose(1, 2).contiguous()
+        # (the bias_t argument is a leftover of the first-generation kernel: the kernel reads columns of its LDS copy of bias)
         L.check(L.lib().rgbnm_window_attention_bwd(L.dt_of(qkv.dtype), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(),
-                                                   bias_c.data_ptr(), bias_t.data_ptr(), scale_c.data_ptr(),
+                                                   bias_c.data_ptr(), bias_c.data_ptr(), scale_c.data_ptr(),
                                                    lse.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), dsp.data_ptr(), B,
                                                    res, C_, heads, shift, ws.data_ptr(), ws.numel(), L.stream()),
                 "window_attention_bwd")
@@ -287,6 +287,24 @@ class WindowAttention(nn.Module):
         return 16 * torch.sigmoid(bias), scale
 
 
+def stage_bias_and_scale(blocks):
+    """WindowAttention.bias_and_scale of every block of one stage (same head count) as batched ops: the continuous-position-
+    bias MLP is parameter-only work of ~20 tiny kernels forward and as many backward PER BLOCK -- 2 ms of launches per SwinV2-T
+    step when run block by block.  Same math (swinv2.py:158-168), fp32."""
+    a0, nb = blocks[0].attn, len(blocks)
+    W1 = torch.stack([b.attn.cpb_mlp[0].weight for b in blocks])                 # [nb,512,2]
+    b1 = torch.stack([b.attn.cpb_mlp[0].bias for b in blocks])                   # [nb,512]
+    W2 = torch.stack([b.attn.cpb_mlp[2].weight for b in blocks])                 # [nb,H,512]
+    ls = torch.stack([b.attn.logit_scale.view(-1) for b in blocks])              # [nb,H]
+    tab = a0.relative_coords_table.view(1, -1, 2).expand(nb, -1, -1)             # [nb,225,2]
+    h = torch.relu(torch.baddbmm(b1.unsqueeze(1), tab, W1.transpose(1, 2)))      # [nb,225,512]
+    t = torch.bmm(W2, h.transpose(1, 2))                                         # [nb,H,225]
+    n = a0.window_size[0] * a0.window_size[1]
+    bias = 16 * torch.sigmoid(t.index_select(2, a0.relative_position_index.view(-1))).view(nb, a0.num_heads, n, n)
+    scale = torch.clamp(ls, max=math.log(1.0 / 0.01)).exp()
+    return bias.unbind(0), scale.unbind(0)
+
+
 class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, window_size, shift_size, drop_path, **kw):
         super().__init__()
@@ -322,18 +340,22 @@ class SwinTransformerBlock(nn.Module):
         keep = 1.0 - self.drop_path_p                   # timm DropPath: per-sample Bernoulli(keep) / keep
         return (torch.rand(B, device=dev) < keep).float() / keep
 
-    def run(self, x, B, sh, pre):
+    def run(self, x, B, sh, pre, bias_scale=None, drop=None):
+        """bias_scale: (bias, scale) of this block from stage_bias_and_scale; drop: the block's two DropPath scale vectors [2,B]
+        (drawn for the whole model at once) or None."""
         res, C_ = self.input_resolution[0], self.dim
         a = self.attn
-        bias, scale = a.bias_and_scale()
+        bias, scale = a.bias_and_scale() if bias_scale is None else bias_scale
+        ds1 = self._drop_scale(B, x.device) if drop is None else drop[0]
+        ds2 = self._drop_scale(B, x.device) if drop is None else drop[1]
         qb = torch.cat((a.q_bias, torch.zeros_like(a.v_bias, requires_grad=False), a.v_bias))
         qkv, xs = _LinearFn.apply(x, a.qkv.weight, qb, sh[pre + "attn.qkv"], True)      # xs = x: the shortcut (fork)
         o = _WinAttnFn.apply(qkv, bias, scale, B, res, C_, self.num_heads, self.shift_size)
         o = _LinearFn.apply(o, a.proj.weight, a.proj.bias, sh[pre + "attn.proj"])
-        x = _LNFn.apply(o, self.norm1.weight, self.norm1.bias, xs, self._drop_scale(B, x.device), res * res)
+        x = _LNFn.apply(o, self.norm1.weight, self.norm1.bias, xs, ds1, res * res)
         h, xs = _MlpFn.apply(x, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
                              sh[pre + "mlp.fc1"], sh[pre + "mlp.fc2"], True)
-        return _LNFn.apply(h, self.norm2.weight, self.norm2.bias, xs, self._drop_scale(B, x.device), res * res)
+        return _LNFn.apply(h, self.norm2.weight, self.norm2.bias, xs, ds2, res * res)
 
 
 class PatchMerging(nn.Module):
@@ -451,15 +473,30 @@ class SwinTransformerV2(FlatParamModule):
         pe = self.patch_embed
         x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias, sh["patch_embed.projection.0"])
         x = _LNFn.apply(x, pe.norm.weight, pe.norm.bias, None, None, 1)
+        drops = self._drop_scales(B, dev)
+        k = 0
         for li, ly in enumerate(self.layers):
+            biases, scales = stage_bias_and_scale(ly.blocks)
             for bi, blk in enumerate(ly.blocks):
-                x = blk.run(x, B, sh, f"layers.{li}.blocks.{bi}.")
+                x = blk.run(x, B, sh, f"layers.{li}.blocks.{bi}.", (biases[bi], scales[bi]), None if drops is None else drops[k])
+                k += 1
             if ly.downsample is not None:
                 x = ly.downsample.run(x, B, sh, f"layers.{li}.downsample.")
                 res //= 2
         x = _LNFn.apply(x, self.norm.weight, self.norm.bias, None, None, 1)
         x = _MeanFn.apply(x, B, res * res, self.num_features)
         return _LinearFn.apply(x, self.head.weight, self.head.bias, sh["head"])
+
+    def _drop_scales(self, B, dev):
+        """timm DropPath (per-sample Bernoulli(keep) / keep) for every residual branch of the model from ONE uniform draw:
+        [blocks][2][B] fp32, rows of ones where a block's rate is 0; None in eval mode or when no block drops."""
+        ps = [blk.drop_path_p for ly in self.layers for blk in ly.blocks]
+        if not self.training or not any(ps):
+            return None
+        key = (tuple(ps), str(dev))
+        if getattr(self, "_keep_key", None) != key:
+            self._keep_key, self._keep = key, torch.tensor([1.0 - p for p in ps], device=dev).view(-1, 1, 1)
+        return (torch.rand(len(ps), 2, B, device=dev) < self._keep).float() / self._keep
 
     # ---------------------------------------------------------------- flat masters + per-step operand shadows
     def _flatten(self):
