@@ -67,6 +67,7 @@ struct RgbnmReduceJob {
   const float* part; long long stride; float* out;
   int n, S, cols, perm_heads, accumulate, epw;      // perm_heads > 0: row i / cols is a de-interleaved qkv row
 };
+bool rgbnm_reduce_defer_active();                    // inside a bracket opened further up the call chain?
 void rgbnm_reduce_defer_begin();                     // queue the following submits ...
 int rgbnm_reduce_defer_flush(hipStream_t st);        // ... and run them as one launch
 int rgbnm_reduce_submit(const RgbnmReduceJob& job, hipStream_t st);

@@ -138,10 +138,18 @@ int submit_ln_reduce(const float* part, float* dgamma, float* dbeta, int nblk, i
   RgbnmReduceJob j;
   j.part = part; j.stride = 2LL * E; j.out = dgamma; j.n = E; j.S = nblk; j.cols = 1; j.perm_heads = 0;
   j.accumulate = accumulate; j.epw = 8;
-  const int rc = rgbnm_reduce_submit(j, st);
-  if (rc != RGBNM_OK) return rc;
-  j.part = part + E; j.out = dbeta;
-  return rgbnm_reduce_submit(j, st);
+  const bool own = !rgbnm_reduce_defer_active();        // stand-alone call: gamma and beta in ONE reduction launch
+  if (own) rgbnm_reduce_defer_begin();
+  int rc = rgbnm_reduce_submit(j, st);
+  if (rc == RGBNM_OK) {
+    j.part = part + E; j.out = dbeta;
+    rc = rgbnm_reduce_submit(j, st);
+  }
+  if (own) {
+    const int rf = rgbnm_reduce_defer_flush(st);
+    if (rc == RGBNM_OK) rc = rf;
+  }
+  return rc;
 }
 
 // ---- head pooling: pooled[b] = mean_t LN(x[b,t,:])  (one workgroup per image) ------------------------

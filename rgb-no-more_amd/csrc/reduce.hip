@@ -156,6 +156,7 @@ int launch(const Jobs& J, int njobs, hipStream_t st) {
 
 }  // namespace
 
+bool rgbnm_reduce_defer_active() { return g_defer; }
 void rgbnm_reduce_defer_begin() {
   g_defer = true;
   g_njobs = 0;

@@ -461,10 +461,18 @@ int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* 
   RgbnmReduceJob j;
   j.part = part; j.stride = 2LL * E; j.out = dgamma; j.n = E; j.S = grid; j.cols = 1; j.perm_heads = 0;
   j.accumulate = accumulate; j.epw = 8;
+  const bool own = !rgbnm_reduce_defer_active();        // dgamma and dbeta in ONE reduction launch
+  if (own) rgbnm_reduce_defer_begin();
   int rc = rgbnm_reduce_submit(j, st);
-  if (rc != RGBNM_OK) return rc;
-  j.part = part + E; j.out = dbeta;
-  return rgbnm_reduce_submit(j, st);
+  if (rc == RGBNM_OK) {
+    j.part = part + E; j.out = dbeta;
+    rc = rgbnm_reduce_submit(j, st);
+  }
+  if (own) {
+    const int rf = rgbnm_reduce_defer_flush(st);
+    if (rc == RGBNM_OK) rc = rf;
+  }
+  return rc;
 }
 
 int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int C, int inverse, void* stream) {
