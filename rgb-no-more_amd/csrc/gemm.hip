@@ -517,10 +517,19 @@ int submit_tn_reduce(const GemmTN& p, float* dW, float* db, int S, int perm_head
   RgbnmReduceJob j;
   j.part = p.part; j.stride = (long long)p.No * p.Ki; j.out = dW; j.n = p.No * p.Ki; j.S = S; j.cols = p.Ki;
   j.perm_heads = perm_heads; j.accumulate = accumulate; j.epw = 64;
-  const int rc = rgbnm_reduce_submit(j, st);
-  if (rc != RGBNM_OK || !db) return rc;
-  j.part = p.bpart; j.stride = p.No; j.out = db; j.n = p.No; j.cols = 1;
-  return rgbnm_reduce_submit(j, st);
+  if (!db) return rgbnm_reduce_submit(j, st);
+  const bool own = !rgbnm_reduce_defer_active();        // stand-alone call: weight and bias partials in ONE reduction launch
+  if (own) rgbnm_reduce_defer_begin();
+  int rc = rgbnm_reduce_submit(j, st);
+  if (rc == RGBNM_OK) {
+    j.part = p.bpart; j.stride = p.No; j.out = db; j.n = p.No; j.cols = 1;
+    rc = rgbnm_reduce_submit(j, st);
+  }
+  if (own) {
+    const int rf = rgbnm_reduce_defer_flush(st);
+    if (rc == RGBNM_OK) rc = rf;
+  }
+  return rc;
 }
 
 // deferred (grouped) weight-gradient launches

@@ -101,9 +101,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       const f32x4 dv = load4<T>(dy + off);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float xh_, gv_, dg_ = dg[v][i], db_ = db[v][i];
-        ln_bwd_acc(dv[i], xv[i], mu, rs, gm[v][i], xh_, gv_, s1, s2, dg_, db_);
-        xh[v][i] = xh_; gv[v][i] = gv_; dg[v][i] = dg_; db[v][i] = db_;
+        if constexpr (E == 192) {      // rounds like the fused epilogues that repeat this arithmetic at E = 192 (ln_bwd_rows.h)
+          float xh_, gv_, dg_ = dg[v][i], db_ = db[v][i];
+          ln_bwd_acc(dv[i], xv[i], mu, rs, gm[v][i], xh_, gv_, s1, s2, dg_, db_);
+          xh[v][i] = xh_; gv[v][i] = gv_; dg[v][i] = dg_; db[v][i] = db_;
+        } else {                       // no fused twin at other widths: leave the compiler free to schedule across rows
+          xh[v][i] = (xv[i] - mu) * rs;
+          gv[v][i] = dv[i] * gm[v][i];
+          s1 += gv[v][i];
+          s2 += gv[v][i] * xh[v][i];
+          dg[v][i] += dv[i] * xh[v][i];
+          db[v][i] += dv[i];
+        }
       }
     }
     const float c1 = row_sum<LPR>(s1) * (1.f / E), c2 = row_sum<LPR>(s2) * (1.f / E);
@@ -112,7 +121,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       const size_t off = (size_t)row * E + (v * LPR + l16) * 4;
       f32x4 o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = ln_bwd_dx(rs, gv[v][i], c1, xh[v][i], c2, rv[v][i]);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (E == 192) o[i] = ln_bwd_dx(rs, gv[v][i], c1, xh[v][i], c2, rv[v][i]);
+        else o[i] = rs * (gv[v][i] - c1 - xh[v][i] * c2) + rv[v][i];
+      }
       store4<T>(dx + off, o);
     }
   }
