@@ -375,8 +375,8 @@ class RandomFlip_DCT(torch.nn.Module):
 
     def __init__(self, p=0.5, direction="horizontal"):
         super().__init__()
-        if direction != "horizontal":
-            raise NotImplementedError("the DCT pipelines flip horizontally (datasets.py:357,374)")
+        if direction not in ("horizontal", "vertical"):
+            raise ValueError("direction must be 'horizontal' or 'vertical' (custom_transforms.py:919)")
         self.p, self.direction = p, direction
 
     def forward(self, coeff, flip=None):
@@ -385,7 +385,15 @@ class RandomFlip_DCT(torch.nn.Module):
         flips = [bool(flip)] * B if flip is not None else [not (torch.rand(1).item() > self.p) for _ in range(B)]
         if Y.shape[2] != Y.shape[3]:
             raise NotImplementedError("RandomFlip_DCT on the HIP path works on the square grids after the crop/resize stage")
-        return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * B, flips, None, 0, torch.int16), single, batched)
+        ops = None
+        if self.direction == "vertical":
+            # dct_ops.py:617-620 (reverse the block rows, negate the odd rows of every block) = the horizontal flip followed by a
+            # half turn; both are exact index / sign work in the kernels (flip in kernel 1, two Rotate90 steps in kernel 2).
+            # Unlike flip_dct, kernel 2 clamps to the coefficient range [-1024, 1016] (RandAugment's per-op clamp): a coefficient
+            # in [-1024, -1017] that the flip negates comes out as 1016, the value RandAugment's entry clamp gives it one stage
+            # later in every reference pipeline; bit exact on [-1016, 1016]
+            ops = [[("Rotate90", 1.0, None), ("Rotate90", 1.0, None)] if f else [] for f in flips]
+        return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * B, flips, ops, 0, torch.int16), single, batched)
 
 
 # ops_list=None: the reference's own default (custom_transforms.py:1060-1062) minus the DFT-domain Rotate / ShearX / ShearY, which

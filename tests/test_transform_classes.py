@@ -37,6 +37,18 @@ def test_flip_crop_torange_are_bit_exact_vs_oracle():
     Yb[0, 0, 3, 6, 1, 1] = -1030
     fy = CT.RandomFlip_DCT(p=1.0)(dev(Yb))
     assert np.array_equal(fy.cpu().numpy()[0], O.flip(Yb[0]))
+    # vertical (custom_transforms.py:919; dct_ops.py:617-620) = horizontal flip + half turn on the kernels.  The half turn runs as
+    # RandAugment ops, whose per-op clamp (custom_transforms.py:1019-1020) bounds what a sign flip can produce: a coefficient in
+    # [-1024, -1017] that the flip negates comes out as 1016 where flip_dct gives up to 1024 -- the value RandAugment's entry
+    # clamp (:1106-1108) makes of it one stage later in every reference pipeline.  Bit exact on [-1016, 1016]; stated, not hidden
+    Ys, Cs = coeffs(3, 28, 28, 31, lo=-1016)
+    for flags in ((True, True, True), (True, False, True)):
+        outs = [CT.RandomFlip_DCT(p=1.0, direction="vertical")((dev(Ys[b:b + 1]), dev(Cs[b:b + 1])), flip=flags[b]) for b in range(3)]
+        for b in range(3):
+            wy, wc = (O.flip(Ys[b], "vertical"), O.flip(Cs[b], "vertical")) if flags[b] else (Ys[b], Cs[b])
+            assert np.array_equal(outs[b][0][0].cpu().numpy(), wy) and np.array_equal(outs[b][1][0].cpu().numpy(), wc)
+    fv = CT.RandomFlip_DCT(p=1.0, direction="vertical")(dev(Yb))
+    assert np.array_equal(fv.cpu().numpy()[0], np.clip(O.flip(np.clip(Yb[0], O.CMIN, O.CMAX), "vertical"), O.CMIN, O.CMAX))
     # crops: 64 -> 28 window, no resize
     Y2, C2 = coeffs(2, 64, 64, 21)
     cy, cc = CT.CenterCrop_DCT(28)((dev(Y2), dev(C2)))
