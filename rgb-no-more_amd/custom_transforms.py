@@ -440,15 +440,23 @@ class ToRange(torch.nn.Module):
                  dtype=torch.float32):
         super().__init__()
         self.val_min, self.val_max, self.orig_min, self.orig_max, self.dtype = val_min, val_max, orig_min, orig_max, dtype
-        if (val_min, val_max, orig_min, orig_max) != (-1, 1, -1024, 1016):
-            raise NotImplementedError("the HIP kernel implements ToRange(val_min=-1, val_max=1, orig_min=-1024, orig_max=1016)")
+        self._fused = (val_min, val_max, orig_min, orig_max) == (-1, 1, -1024, 1016)
         if dtype not in (torch.float32, torch.bfloat16):
             raise NotImplementedError("ToRange output dtype: float32 or bfloat16")
 
     def forward(self, coeff):
         Y, C, single, batched = _unpack(coeff)
-        if Y.shape[2] != Y.shape[3]:
-            raise NotImplementedError("ToRange on the HIP path works on the square grids after the crop/resize stage")
+        if not self._fused or Y.shape[2] != Y.shape[3] or Y.shape[2] not in (28, 32):
+            # any other range (the class default is orig_max = 1024, which no pipeline uses) or grid: the reference's two fp32
+            # statements (custom_transforms.py:450-451) as device tensor ops -- same operations in the same order, same bits
+            L.require_cuda(Y) if C is None else L.require_cuda(Y, C)
+
+            def f(x):
+                # a TENSOR divisor: dividing by a Python scalar is turned into a multiplication by its reciprocal on the device
+                den = torch.full((), float(self.orig_max - self.orig_min), device=x.device, dtype=torch.float32)
+                x = (x.to(torch.float32) - self.orig_min) / den
+                return (self.val_min + x * (self.val_max - self.val_min)).to(self.dtype)
+            return _pack(f(Y), None if C is None else f(C), single, batched)
         return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * Y.shape[0], None, None, 0, self.dtype), single, batched)
 
 

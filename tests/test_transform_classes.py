@@ -63,8 +63,13 @@ def test_flip_crop_torange_are_bit_exact_vs_oracle():
     assert np.array_equal(ty.cpu().numpy(), O.to_range(Y)) and np.array_equal(tc.cpu().numpy(), O.to_range(C))
     by = CT.ToRange(-1, 1, -1024, 1016, torch.bfloat16)(dev(Y))
     assert torch.equal(by.cpu(), torch.from_numpy(O.to_range(Y)).bfloat16())
-    with pytest.raises(NotImplementedError):
-        CT.ToRange(0, 1, -1024, 1024)
+    # any other range -- the class default (orig_max = 1024) included -- and any grid: the reference's two fp32 statements
+    for args in ((), (0.0, 1.0, -1024, 1024), (-2.0, 3.0, -1000, 1000)):
+        gy, gc = CT.ToRange(*args)((dev(Y), dev(C)))
+        kw = dict(zip(("val_min", "val_max", "orig_min", "orig_max"), args)) if args else dict(orig_max=1024)
+        assert np.array_equal(gy.cpu().numpy(), O.to_range(Y, **kw)) and np.array_equal(gc.cpu().numpy(), O.to_range(C, **kw))
+    Yr, _ = coeffs(1, 20, 36, 5)
+    assert np.array_equal(CT.ToRange(-1, 1, -1024, 1016)(dev(Yr)).cpu().numpy(), O.to_range(Yr))      # non-square grid
 
 
 @pytest.mark.parametrize("size,side", [(28, 56), (28, 28), (28, 14), (32, 64), (32, 16)])
