@@ -408,8 +408,6 @@ class RandAugment_dct(torch.nn.Module):
 
     def __init__(self, num_ops: int = 2, magnitude: int = 10, num_magnitude_bins: int = 11, pad=2 ** 0.5, ops_list=None):
         super().__init__()
-        if num_ops > 2:
-            raise NotImplementedError("the HIP kernel chains up to two operations per sample (cfg.TRAIN.NUMOPS default 2)")
         self.num_ops, self.magnitude, self.num_magnitude_bins, self.pad = num_ops, magnitude, num_magnitude_bins, pad
         if ops_list is None:
             ops_list = DEFAULT_OPS
@@ -429,7 +427,12 @@ class RandAugment_dct(torch.nn.Module):
         meta = magnitude_table(self.num_magnitude_bins, (S, S))
         chosen = [list(ops)] * B if ops is not None else \
             [sample_ops(self.ops_list, self.num_ops, self.magnitude, meta, S) for _ in range(B)]
-        return _pack(*_run_chain(Y, C, S, [_whole(Y)] * B, None, chosen, 1, torch.int16), single, batched)
+        # the kernel chains two operations per pass (cfg.TRAIN.NUMOPS default 2); longer chains run as further passes over the int16
+        # result -- the entry clamp of a later pass is the identity on what the previous pass's per-op clamp left
+        n = max([len(c) for c in chosen] + [1])
+        for k in range(0, n, 2):
+            Y, C = _run_chain(Y, C, S, [_whole(Y)] * B, None, [c[k:k + 2] for c in chosen], 1, torch.int16)
+        return _pack(Y, C, single, batched)
 
 
 class ToRange(torch.nn.Module):
@@ -469,6 +472,9 @@ class TrainTransform_DCT(torch.nn.Module):
         if size not in (28, 32):
             raise NotImplementedError("HIP augment path covers 28x28-block (imagenet_dct) and 32x32-block "
                                       "(imagenet_dct_swin) outputs")
+        if num_ops > 2:
+            raise NotImplementedError("the fused transform chains two operations per sample (cfg.TRAIN.NUMOPS default 2); longer "
+                                      "chains: the per-transform classes, RandAugment_dct(num_ops=N)")
         self.size, self.flip_p, self.num_ops, self.magnitude = size, flip_p, num_ops, magnitude
         self.num_magnitude_bins = num_magnitude_bins
         self.ops_list = list(VITTI_OPS if ops_list is None else ops_list)
@@ -511,6 +517,8 @@ class TrainTransform_DCT(torch.nn.Module):
         B = len(params)
         arr = (AugParams * B)()
         nops = max([len(p["ops"]) for p in params] + [0])
+        if nops > 2:
+            raise ValueError("one pass of the augment kernels takes at most two operations per sample")
         for b, p in enumerate(params):
             i, j, h, w = p["box"]
             a = arr[b]

@@ -111,6 +111,17 @@ def test_randaugment_class_vs_oracle_ops():
                 ry, rc = O.apply_op(ry, rc, name, mag, aux)
             assert np.array_equal(oy[b].cpu().numpy(), ry), ops
             assert np.array_equal(oc[b].cpu().numpy(), rc), ops
+    # num_ops > 2 (custom_transforms.py:1024: any count): chained two at a time, every per-op clamp where the reference has it
+    for ops in (cases[:3], cases[2:7], cases[3:7]):
+        oy, oc = CT.RandAugment_dct(num_ops=len(ops), magnitude=3, ops_list=CT.VITTI_OPS)((dev(Y), dev(C)), ops=ops)
+        for b in range(2):
+            ry, rc = np.clip(Y[b], -1024, 1016), np.clip(C[b], -1024, 1016)
+            for name, mag, aux in ops:
+                ry, rc = O.apply_op(ry, rc, name, mag, aux)
+            assert np.array_equal(oy[b].cpu().numpy(), ry) and np.array_equal(oc[b].cpu().numpy(), rc), ops
+    torch.manual_seed(1)
+    s5y, _ = CT.RandAugment_dct(num_ops=5, magnitude=3, ops_list=CT.VITTI_OPS)((dev(Y), dev(C)))
+    assert s5y.dtype == torch.int16 and int(s5y.max()) <= 1016 and int(s5y.min()) >= -1024
     # sampling path: structure, dtype, range
     torch.manual_seed(0)
     sy, sc = ra((dev(Y), dev(C)))
