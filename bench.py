@@ -383,25 +383,10 @@ def main():
             from torch.nn.parallel import DistributedDataParallel as DDP
             # several ~4 MB buckets so the all-reduce of late layers overlaps the backward of early ones
             net = DDP(model, device_ids=[local], output_device=local, bucket_cap_mb=4, gradient_as_bucket_view=False)
-    if swin:
-        # train.py's own objects (pipeline_utils.py:535-537): torch AdamW + the name-filtered WeightDecay + clip_grad_norm_
-        adamw = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0, eps=1e-8)
-        wdec = rg.custom_optims.WeightDecay([p for n, p in model.named_parameters() if (".weight" in n) and ("lrnorm" not in n)],
-                                            lr=1e-3, weight_decay=1e-4)
-
-        class _Opt:
-            @staticmethod
-            def zero_grad(set_to_none=True):
-                adamw.zero_grad(set_to_none=set_to_none)
-
-            @staticmethod
-            def step():
-                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1)
-                adamw.step()
-                wdec.step()
-        opt = _Opt()
-    else:
-        opt = rg.custom_optims.FusedClipAdamWWD(model, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
+    # clip_grad_norm_(1) + AdamW(weight_decay=0) + the name-filtered WeightDecay of train.py (pipeline_utils.py:535-537) as the one
+    # fused launch over the flat parameter buffer, for every arch (SwinV2's per-parameter gradients are gathered into the flat
+    # buffer first; tests/test_swin.py compares it with train.py's own torch objects)
+    opt = rg.custom_optims.FusedClipAdamWWD(model, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
     mix = rg.cls_transforms.RandomMixup_DCT(1000, alpha=0.2)
     mix.out_dtype = cdt
     B = a.batch

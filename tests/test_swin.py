@@ -257,3 +257,38 @@ def test_swinv2t_at_batch_64_vs_reference_golden(golden, dt):
         assert err <= 6e-2
         assert abs(loss.item() - float(g[tag + "_loss"])) < 5e-3
         assert np.median(rel) < 3e-2
+
+
+@pytest.mark.gpu
+def test_fused_optimizer_equals_train_py_objects_on_swin(golden):
+    """pipeline_utils.py:535-537 / train.py:172-176: clip_grad_norm_(1) + torch AdamW(weight_decay=0) + the name-filtered WeightDecay,
+    against the one-launch FusedClipAdamWWD that bench.py --arch swinv2t times (gradients gathered into the flat buffer first:
+    SwinV2's autograd nodes return per-parameter tensors).  Same fp32 gradients in, three steps, parameters compared."""
+    g = golden("g15_swin.npz")
+    runs = []
+    for fused in (False, True):
+        m, *_ = _model("sw3", DEV)
+        names, y, c, tgt = _load(m, "sw3", g)
+        m.train()
+        m.compute_dtype = torch.float32
+        if fused:
+            opt = rg.custom_optims.FusedClipAdamWWD(m, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
+            step = opt.step
+        else:
+            adamw = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0, eps=1e-8)
+            wdec = rg.custom_optims.WeightDecay([p for n, p in m.named_parameters() if (".weight" in n) and ("lrnorm" not in n)],
+                                                lr=1e-3, weight_decay=1e-4)
+
+            def step():
+                torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1)
+                adamw.step()
+                wdec.step()
+        for _ in range(3):
+            for p in m.parameters():
+                p.grad = None
+            rg.cls_transforms.cross_entropy(m(y, c), tgt).backward()
+            step()
+        runs.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    worst = max(((runs[0][n] - runs[1][n]).abs().max() / (runs[0][n].abs().max() + 1e-12)).item() for n in runs[0])
+    print(f"fused vs train.py objects after 3 steps: worst relative parameter difference {worst:.2e}")
+    assert worst < 5e-5
