@@ -77,6 +77,16 @@ size_t rgbnm_gemm_tn_workspace(int M, int No, int Ki);
 int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int No,
                   int Ki, int perm_heads, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Grouped weight gradients.  Between _begin and _end (same host thread) bf16 rgbnm_gemm_tn calls over the SAME row count are
+ * queued -- up to four -- and run as ONE launch at _end (or when the queue fills / the row count changes): with T output tiles
+ * in total every job is split 256 / T ways instead of 256 / its own tiles, so fewer fp32 partial sums are written and re-read,
+ * and one reduction launch serves all jobs.  dW / db hold nothing until _end returns; every queued call needs ITS OWN workspace
+ * (the partial sums live there until _end).  The ViT block backward groups its four dW GEMMs this way internally; this pair is
+ * for callers that drive the Linears one by one (swinv2.py: the two dW GEMMs of an MLP).  Reference: autograd computes each
+ * Linear's weight gradient as its own GEMM (torch.nn.Linear backward). */
+void rgbnm_gemm_tn_group_begin(void);
+int rgbnm_gemm_tn_group_end(void* stream);
+
 /* One nn.Linear in the flat fp32 master buffer and where its shadows go (offsets in elements). */
 typedef struct rgbnm_linear_desc {
   long long w_off;     /* master: weight [N,K] fp32                                   */

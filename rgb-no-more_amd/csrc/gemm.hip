@@ -718,6 +718,20 @@ int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, fl
   return RGBNM_EINVAL;
 }
 
+void rgbnm_gemm_tn_group_begin(void) { rgbnm_tn_defer_begin(); }
+
+int rgbnm_gemm_tn_group_end(void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const bool own = !rgbnm_reduce_defer_active();        // the queued jobs' reductions: one launch
+  if (own) rgbnm_reduce_defer_begin();
+  int rc = rgbnm_tn_defer_flush(st);
+  if (own) {
+    const int rf = rgbnm_reduce_defer_flush(st);
+    if (rc == RGBNM_OK) rc = rf;
+  }
+  return rc;
+}
+
 int rgbnm_prep_weights(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
                        float* bias_perm, void* stream) {
   if (!descs_dev || !master || !shadow || ndesc <= 0) return RGBNM_EINVAL;

@@ -62,6 +62,8 @@ PROTOTYPES = {
     "rgbnm_abi_version": (_i, []),
     "rgbnm_strerror": (C.c_char_p, [_i]),
     "rgbnm_set_option": (_i, [C.c_char_p, _i]),
+    "rgbnm_gemm_tn_group_begin": (None, []),
+    "rgbnm_gemm_tn_group_end": (_i, [_vp]),
     "rgbnm_get_option": (_i, [C.c_char_p]),
     "rgbnm_trace_collect": (_i, [_i, _vp, _vp, _vp, _vp]),
     "rgbnm_gemm_nt": (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -25,11 +25,12 @@ WS = 8
 
 
 # ------------------------------------------------------------------ autograd nodes over the C ABI
-def _ws(dev, nbytes):
-    t = _ws.cache.get(dev)
+def _ws(dev, nbytes, slot=0):
+    """Scratch per (device, slot): calls whose partial sums must coexist (grouped dW GEMMs) take different slots."""
+    t = _ws.cache.get((dev, slot))
     if t is None or t.numel() < nbytes:
         t = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        _ws.cache[dev] = t
+        _ws.cache[(dev, slot)] = t
     return t
 
 
@@ -46,13 +47,13 @@ def _gemm_nt(epi, A, W, bias=None, R=None, want_c2=False):
     return out, c2
 
 
-def _gemm_tn(dY, X, want_bias):
+def _gemm_tn(dY, X, want_bias, slot=0):
     M, No = dY.shape
     Ki = X.shape[1]
     dW = torch.empty(No, Ki, device=dY.device, dtype=torch.float32)
     db = torch.empty(No, device=dY.device, dtype=torch.float32) if want_bias else None
     wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
-    ws = _ws(dY.device, wsb)
+    ws = _ws(dY.device, wsb, slot)
     L.check(L.lib().rgbnm_gemm_tn(L.dt_of(dY.dtype), dY.data_ptr(), No, X.data_ptr(), Ki, dW.data_ptr(), L.ptr(db), M, No,
                                   Ki, 0, 0, ws.data_ptr(), ws.numel(), L.stream()), "gemm_tn")
     return dW, db
@@ -77,12 +78,24 @@ def _nt(epi, x, Wsh, pair, bias=None, R=None, want_c2=False):
     return y.view(M, N2 // 2), None if c2 is None else c2.view(M, N2 // 2)
 
 
-def _tn(dy, x, want_bias, pair):
+def _tn_issue(dy, x, want_bias, pair, slot=0):
+    """Launch (or, inside a rgbnm_gemm_tn_group bracket, queue) one weight-gradient GEMM; _tn_finish turns what it returns into
+    (dW, db) once the results exist."""
     if not pair:
-        return _gemm_tn(dy, x, want_bias)
+        return _gemm_tn(dy, x, want_bias, slot) + (0, 0)
     M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
-    dW2, db2 = _gemm_tn(dy.view(M // 2, 2 * N), x.view(M // 2, 2 * K), want_bias)     # [[e.e, e.o], [o.e, o.o]] row parities
+    return _gemm_tn(dy.view(M // 2, 2 * N), x.view(M // 2, 2 * K), want_bias, slot) + (N, K)   # [[e.e, e.o], [o.e, o.o]] row parities
+
+
+def _tn_finish(t):
+    dW2, db2, N, K = t
+    if N == 0:
+        return dW2, db2
     return dW2[:N, :K] + dW2[N:, K:], None if db2 is None else db2[:N] + db2[N:]
+
+
+def _tn(dy, x, want_bias, pair):
+    return _tn_finish(_tn_issue(dy, x, want_bias, pair))
 
 
 def _fbias(b):
@@ -132,9 +145,18 @@ class _MlpFn(torch.autograd.Function):
     def backward(ctx, dy, dxs=None):
         x, g, gp = ctx.saved_tensors
         dy = dy.contiguous()
-        dW2, db2 = _tn(dy, g, True, ctx.p2)
         du, _ = _nt(L.EPI_DGELU, dy, ctx.sh2[1], ctx.p2, None, R=gp)
-        dW1, db1 = _tn(du, x, True, ctx.p1)
+        # both weight gradients in one launch (rgbnm.h: rgbnm_gemm_tn_group_*): half the split count, one reduction
+        grouped = dy.dtype == torch.bfloat16
+        if grouped:
+            L.lib().rgbnm_gemm_tn_group_begin()
+        try:
+            t2 = _tn_issue(dy, g, True, ctx.p2, 0)
+            t1 = _tn_issue(du, x, True, ctx.p1, 1)
+        finally:
+            if grouped:
+                L.check(L.lib().rgbnm_gemm_tn_group_end(L.stream()), "gemm_tn_group_end")
+        (dW2, db2), (dW1, db1) = _tn_finish(t2), _tn_finish(t1)
         if dxs is None:
             dx, _ = _nt(L.EPI_NONE, du, ctx.sh1[1], ctx.p1)
         else:

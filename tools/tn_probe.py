@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The four weight-gradient GEMMs (dW = dY^T X, fp32 out, + db) of one encoder block through rgbnm_gemm_tn at a given width / row
 count, with the algorithmic bytes (both operands read once) and the rate they correspond to.
-usage: python tools/tn_probe.py E M      (SwinV2-T stages at B = 256: 192 524288 (stage 1, row-paired) / 192 262144 / 384 65536 / 768 16384)"""
+usage: python tools/tn_probe.py E M [option=value ...]      (SwinV2-T stages at B = 256: 192 524288 (stage 1, row-paired) / 192 262144 / 384 65536 / 768 16384)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,6 +27,9 @@ def timeit(fn, n=20):
 def main():
     E, M = int(sys.argv[1]), int(sys.argv[2])
     lib = L.lib()
+    for kv in sys.argv[3:]:                      # library options, e.g. tn_square=1
+        k, v = kv.split("=")
+        L.check(lib.rgbnm_set_option(k.encode(), int(v)))
     dt = torch.bfloat16
     tot = 0.0
     for name, No, Ki in (("dW qkv", 3 * E, E), ("dW proj", E, E), ("dW fc1", 4 * E, E), ("dW fc2", E, 4 * E)):
