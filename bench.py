@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-augment", action="store_true", help="model-only step on S-randn inputs (benchmark.py:146-148)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden-vector check of the timed kernel mix")
-    ap.add_argument("--cpu-baseline-images", type=int, default=64)
+    ap.add_argument("--cpu-baseline-images", type=int, default=512)     # ~10 s of CPU work at JPEG-Ti (17.7 ms / image on 16 threads)
     ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel HIP-event trace of the timed region")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B experiments)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step from the host (no HIP graph replay)")
