@@ -107,10 +107,13 @@ template <typename T> __device__ __forceinline__ float token_sum(float v) {
   if constexpr (WA<T>::LPT == 8) v += lane_xor4(v);
   return v;
 }
-// the workgroup's head bias [64][64] -> LDS [64][BP]
+// Softmax in base 2: logits are kept as log2(e) * (scale cos + bias) -- the bias is scaled once when it is staged, the scale and
+// lse once per wave / window -- so a probability is ONE v_exp_f32 of a difference (exp(x) costs a multiply more per element).
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+// the workgroup's head bias [64][64] -> LDS [64][BP], times log2(e)
 __device__ __forceinline__ void stage_bias(float* Bs, const float* __restrict__ bias_h) {
   for (int i = threadIdx.x; i < WT * WT / 4; i += blockDim.x)
-    *reinterpret_cast<f32x4*>(Bs + (i >> 4) * BP + (i & 15) * 4) = *reinterpret_cast<const f32x4*>(bias_h + i * 4);
+    *reinterpret_cast<f32x4*>(Bs + (i >> 4) * BP + (i & 15) * 4) = *reinterpret_cast<const f32x4*>(bias_h + i * 4) * LOG2E;
 }
 
 __device__ __forceinline__ int region(int s, int res, int shift) { return s < res - WS ? 0 : (s < res - shift ? 1 : 2); }
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
   const int wph = bph * A::FWD_WAVES, wih = (blockIdx.x % bph) * A::FWD_WAVES + w;      // waves of this head, index among them
   const long long win_lo = nwin * wih / wph, win_hi = nwin * (wih + 1) / wph;
   const int l31 = lane & 31, g = lane >> 5;
-  const float sc = scale[h];
+  const float sc = scale[h] * LOG2E;                 // logits in base-2 units (stage_bias)
   RawQKV<T> raw;
   WinPos nxt;
   nxt.set(win_lo, nw);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
             for (int e = 0; e < 4; ++e) {
               float v = acc[4 * q4 + e] * sc + b4[e];
               if constexpr (decltype(MK)::value) {
-                if (Mid[k0 + e] != midq) v += -100.f;
+                if (Mid[k0 + e] != midq) v += -100.f * LOG2E;
               }
               s[t][4 * q4 + e] = v;
               m = fmaxf(m, v);
@@ -345,12 +348,12 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s[t][r] = __expf(s[t][r] - m);
+          s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m);
           sum += s[t][r];
         }
       sum += __shfl_xor(sum, 32, 64);
       const float inv = 1.f / sum;
-      if (g == 0) lse[unit * WT + q] = m + __logf(sum);
+      if (g == 0) lse[unit * WT + q] = (m + __log2f(sum)) * LN2;      // stored in natural units
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
   const int wph = bph * A::BWD_WAVES, wih = (blockIdx.x % bph) * A::BWD_WAVES + w;      // waves of this head, index among them
   const long long win_lo = nwin * wih / wph, win_hi = nwin * (wih + 1) / wph;
   const int l31 = lane & 31, g = lane >> 5;
-  const float sc = scale[h];
+  const float sc = scale[h], sc2 = sc * LOG2E;       // sc2: logits in base-2 units (stage_bias); sc: the chain rule's factor
   float dbacc[2][2][16];                    // this head's d(bias) in accumulator layout: [query tile][key tile][r]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -509,14 +512,14 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         Mid[tk] = mid;
       }
     }
-    Ls[lane] = raw.lse;
+    Ls[lane] = raw.lse * LOG2E;
     WPROF(1);
     if (A::PREFETCH && win + 1 < win_hi) fetch_bwd<T>(raw, qkv, out, dout, lse + (unit + heads) * WT, nxt, h, res, C, shift, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WPROF(2);
     // ================= phase A: lane = query (two 32-query tiles) -> dq, d(bias), d(scale) =================
-    float dsc = 0.f;
+    f32x2 dsc2 = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = 32 * i + l31;
@@ -544,23 +547,29 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
           mma(da, rowfrag<T>(Vr, 32 * t + l31, c, g), gf[c]);
         }
         float dss[16];
-        auto softmax_bwd = [&](auto MK) {
+        auto softmax_bwd = [&](auto MK) {          // element pairs: packed fp32 VALU (v_pk_fma / v_pk_mul / v_pk_add)
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const int k0 = 32 * t + 8 * q4 + 4 * g;
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + k0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * q4 + e;
-              float lg = sa[r] * sc + b4[e];
+            for (int hp = 0; hp < 2; ++hp) {
+              const int r = 4 * q4 + 2 * hp;
+              const f32x2 s2 = {sa[r], sa[r + 1]};
+              f32x2 lg = s2 * sc2 + (f32x2){b4[2 * hp], b4[2 * hp + 1]};
               if constexpr (decltype(MK)::value) {
-                if (Mid[k0 + e] != midq) lg += -100.f;
+                if (Mid[k0 + 2 * hp] != midq) lg[0] += -100.f * LOG2E;
+                if (Mid[k0 + 2 * hp + 1] != midq) lg[1] += -100.f * LOG2E;
               }
-              const float p = __expf(lg - lq);
-              const float ds = p * (da[r] - Dq);
-              dbacc[i][t][r] += ds;
-              dsc += ds * sa[r];
-              dss[r] = ds * sc;
+              const f32x2 x = lg - lq;
+              const f32x2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+              const f32x2 ds = p * ((f32x2){da[r], da[r + 1]} - Dq);
+              dbacc[i][t][r] += ds[0];
+              dbacc[i][t][r + 1] += ds[1];
+              dsc2 = ds * s2 + dsc2;
+              const f32x2 o = ds * sc;
+              dss[r] = o[0];
+              dss[r + 1] = o[1];
             }
           }
         };
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         store4<T>(drow + rq * 8 + g * 4, o);
       }
     }
-    dsc = wave_sum(dsc);
+    const float dsc = wave_sum(dsc2[0] + dsc2[1]);
     if (lane == 0) dscale_part[unit] = dsc;
     if constexpr (A::STAGE_DQ) {
       __builtin_amdgcn_wave_barrier();
@@ -642,15 +651,20 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
             const f32x4 b4 = {bcol[q0 * BP], bcol[(q0 + 1) * BP], bcol[(q0 + 2) * BP], bcol[(q0 + 3) * BP]};
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + q0), d4 = *reinterpret_cast<const f32x4*>(Ds + q0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * q4 + e;
-              float lg = sa[r] * sc + b4[e];
+            for (int hp = 0; hp < 2; ++hp) {
+              const int r = 4 * q4 + 2 * hp;
+              f32x2 lg = (f32x2){sa[r], sa[r + 1]} * sc2 + (f32x2){b4[2 * hp], b4[2 * hp + 1]};
               if constexpr (decltype(MK)::value) {
-                if (Mid[q0 + e] != midk) lg += -100.f;
+                if (Mid[q0 + 2 * hp] != midk) lg[0] += -100.f * LOG2E;
+                if (Mid[q0 + 2 * hp + 1] != midk) lg[1] += -100.f * LOG2E;
               }
-              const float p = __expf(lg - l4[e]);
-              pp[r] = p;
-              dss[r] = p * (da[r] - d4[e]) * sc;
+              const f32x2 x = lg - (f32x2){l4[2 * hp], l4[2 * hp + 1]};
+              const f32x2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+              const f32x2 o = p * ((f32x2){da[r], da[r + 1]} - (f32x2){d4[2 * hp], d4[2 * hp + 1]}) * sc;
+              pp[r] = p[0];
+              pp[r + 1] = p[1];
+              dss[r] = o[0];
+              dss[r + 1] = o[1];
             }
           }
         };
