@@ -110,6 +110,25 @@ template <typename T> __device__ __forceinline__ float token_sum(float v) {
 // Softmax in base 2: logits are kept as log2(e) * (scale cos + bias) -- the bias is scaled once when it is staged, the scale and
 // lse once per wave / window -- so a probability is ONE v_exp_f32 of a difference (exp(x) costs a multiply more per element).
 constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+// Workgroup -> (head, slot among the head's workgroups).  gpx = 0: head-major (bph workgroups per head).  gpx > 0: XCD-aware --
+// workgroup b runs on XCD b % 8, whose L2 it shares; the heads of one window range sit on ONE XCD (slot s of the XCD: head
+// s % heads, group s / heads, gpx groups per XCD), so the half of a 128-byte line that belongs to the neighbouring head is an
+// L2 hit for that head's workgroup instead of a second HBM fetch (a head's slice of a token is 64 bytes).  Returns false for the
+// few workgroups of an XCD that are left over when its slots do not divide by the head count.
+__device__ __forceinline__ bool head_slot(int bph, int gpx, int heads, int& h, int& slot, int& nslots) {
+  if (gpx == 0) {
+    h = blockIdx.x / bph;
+    slot = blockIdx.x % bph;
+    nslots = bph;
+    return true;
+  }
+  const int c = blockIdx.x & 7, s = blockIdx.x >> 3;
+  if (s >= gpx * heads) return false;
+  h = s % heads;
+  slot = c * gpx + s / heads;
+  nslots = 8 * gpx;
+  return true;
+}
 // the workgroup's head bias [64][64] -> LDS [64][BP], times log2(e)
 __device__ __forceinline__ void stage_bias(float* Bs, const float* __restrict__ bias_h) {
   for (int i = threadIdx.x; i < WT * WT / 4; i += blockDim.x)
@@ -233,7 +252,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
                                                            const float* __restrict__ scale, T* __restrict__ out,
                                                            float* __restrict__ lse, int B, int res, int C, int heads,
-                                                           int shift, int bph) {
+                                                           int shift, int bph, int gpx) {
   using A = WA<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -245,12 +264,13 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
   int* Mid = reinterpret_cast<int*>(base + A::FWD_WAVE - WT * 4);
   unsigned trV = 0;
   if constexpr (A::TRREAD) trV = tr_base(Vt, lane);
-  const int h = blockIdx.x / bph;
+  int h, slot, nslots;
+  if (!head_slot(bph, gpx, heads, h, slot, nslots)) return;
   stage_bias(Bs, bias + (size_t)h * WT * WT);
   __syncthreads();
   const int nw = res / WS;
   const long long nwin = (long long)B * nw * nw;
-  const int wph = bph * A::FWD_WAVES, wih = (blockIdx.x % bph) * A::FWD_WAVES + w;      // waves of this head, index among them
+  const int wph = nslots * A::FWD_WAVES, wih = slot * A::FWD_WAVES + w;      // waves of this head, index among them
   const long long win_lo = nwin * wih / wph, win_hi = nwin * (wih + 1) / wph;
   const int l31 = lane & 31, g = lane >> 5;
   const float sc = scale[h] * LOG2E;                 // logits in base-2 units (stage_bias)
@@ -414,7 +434,7 @@ template <typename T>
 __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ lse, T* __restrict__ dqkv, float* __restrict__ dpart,
-    float* __restrict__ dscale_part, int B, int res, int C, int heads, int shift, int bph) {
+    float* __restrict__ dscale_part, int B, int res, int C, int heads, int shift, int bph, int gpx) {
   using A = WA<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -439,12 +459,13 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
   float* Rq = Ds + WT;
   float* Rk = Rq + WT;
   int* Mid = reinterpret_cast<int*>(Rk + WT);
-  const int h = blockIdx.x / bph;
+  int h, slot, nslots;
+  if (!head_slot(bph, gpx, heads, h, slot, nslots)) return;
   stage_bias(Bs, bias + (size_t)h * WT * WT);
   __syncthreads();
   const int nw = res / WS;
   const long long nwin = (long long)B * nw * nw;
-  const int wph = bph * A::BWD_WAVES, wih = (blockIdx.x % bph) * A::BWD_WAVES + w;      // waves of this head, index among them
+  const int wph = nslots * A::BWD_WAVES, wih = slot * A::BWD_WAVES + w;      // waves of this head, index among them
   const long long win_lo = nwin * wih / wph, win_hi = nwin * (wih + 1) / wph;
   const int l31 = lane & 31, g = lane >> 5;
   const float sc = scale[h], sc2 = sc * LOG2E;       // sc2: logits in base-2 units (stage_bias); sc: the chain rule's factor
@@ -752,11 +773,22 @@ int num_cus() {
 }
 // workgroups per head: one resident round of the chip split evenly between the heads (a workgroup holds ONE head's bias);
 // `per_cu` = workgroups of this kernel that fit a CU (LDS).  Never more waves than windows.
-int blocks_per_head(long long nwin, int heads, int per_cu, int waves) {
-  long long bph = (long long)num_cus() * per_cu / heads;
+struct HeadGrid { int bph, gpx, grid, slots; };     // slots = workgroups per head that do work (= partial d(bias) slices / waves)
+HeadGrid head_grid(long long nwin, int heads, int per_cu, int waves) {
+  HeadGrid g;
+  const int cus = num_cus();
+  long long bph = (long long)cus * per_cu / heads;
   const long long cap = (nwin + waves - 1) / waves;
-  if (bph > cap) bph = cap;
-  return bph < 1 ? 1 : (int)bph;
+  const bool capped = bph > cap;
+  if (capped) bph = cap;
+  if (bph < 1) bph = 1;
+  g.bph = (int)bph; g.gpx = 0; g.grid = g.bph * heads; g.slots = g.bph;
+  // XCD-aware mapping (head_slot) when the slots of an XCD divide (nearly) evenly by the head count
+  const int spx = cus / 8 * per_cu, gpx = spx / heads;
+  if (!capped && cus % 8 == 0 && gpx >= 1 && rgbnm_get_option("win_xcd") && (spx - gpx * heads) * 100 <= 7 * spx) {
+    g.gpx = gpx; g.grid = 8 * spx; g.slots = 8 * gpx;
+  }
+  return g;
 }
 
 template <typename T>
@@ -764,15 +796,15 @@ int launch_fwd(const void* qkv, const float* bias, const float* scale, void* out
                int heads, int shift, hipStream_t st) {
   if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
   const long long nwin = (long long)B * (res / WS) * (res / WS);
-  const int bph = blocks_per_head(nwin, heads, 160 * 1024 / WA<T>::FWD_LDS, WA<T>::FWD_WAVES);
-  hipLaunchKernelGGL(win_attn_fwd_kernel<T>, dim3(bph * heads), dim3(64 * WA<T>::FWD_WAVES), WA<T>::FWD_LDS, st,
-                     (const T*)qkv, bias, scale, (T*)out, lse, B, res, C, heads, shift, bph);
+  const HeadGrid g = head_grid(nwin, heads, 160 * 1024 / WA<T>::FWD_LDS, WA<T>::FWD_WAVES);
+  hipLaunchKernelGGL(win_attn_fwd_kernel<T>, dim3(g.grid), dim3(64 * WA<T>::FWD_WAVES), WA<T>::FWD_LDS, st,
+                     (const T*)qkv, bias, scale, (T*)out, lse, B, res, C, heads, shift, g.bph, g.gpx);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
 
-template <typename T> int bwd_bph(long long nwin, int heads) {
-  return blocks_per_head(nwin, heads, 160 * 1024 / WA<T>::BWD_LDS, WA<T>::BWD_WAVES);
+template <typename T> HeadGrid bwd_grid(long long nwin, int heads) {
+  return head_grid(nwin, heads, 160 * 1024 / WA<T>::BWD_LDS, WA<T>::BWD_WAVES);
 }
 
 template <typename T>
@@ -781,13 +813,13 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
                hipStream_t st) {
   if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
   const long long nwin = (long long)B * (res / WS) * (res / WS);
-  const int bph = bwd_bph<T>(nwin, heads);
-  hipLaunchKernelGGL(win_attn_bwd_kernel<T>, dim3(bph * heads), dim3(64 * WA<T>::BWD_WAVES), WA<T>::BWD_LDS, st,
+  const HeadGrid g = bwd_grid<T>(nwin, heads);
+  hipLaunchKernelGGL(win_attn_bwd_kernel<T>, dim3(g.grid), dim3(64 * WA<T>::BWD_WAVES), WA<T>::BWD_LDS, st,
                      (const T*)qkv, (const T*)out, (const T*)dout, bias, scale, lse, (T*)dqkv, dpart, dscale_part, B, res, C,
-                     heads, shift, bph);
+                     heads, shift, g.bph, g.gpx);
   LAUNCH_CHECK();
   RgbnmReduceJob j;
-  j.part = dpart; j.stride = (long long)heads * WT * WT; j.out = dbias; j.n = heads * WT * WT; j.S = bph * WA<T>::BWD_WAVES;
+  j.part = dpart; j.stride = (long long)heads * WT * WT; j.out = dbias; j.n = heads * WT * WT; j.S = g.slots * WA<T>::BWD_WAVES;
   j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
   return rgbnm_reduce_submit(j, st);
 }
@@ -809,8 +841,9 @@ int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, co
 size_t rgbnm_window_attention_bwd_workspace(int B, int res, int heads) {
   // one d(bias) slice per wave: the fp32 geometry (2 waves per workgroup, as many workgroups) bounds both dtypes
   const long long nwin = (long long)B * (res / WS) * (res / WS);
-  const long long waves_bf = (long long)bwd_bph<bf16>(nwin, heads) * WA<bf16>::BWD_WAVES;
-  const long long waves_f = (long long)bwd_bph<float>(nwin, heads) * WA<float>::BWD_WAVES;
+  // (head-major slots >= XCD-aware slots, so the head-major count bounds both mappings)
+  const long long waves_bf = (long long)bwd_grid<bf16>(nwin, heads).bph * WA<bf16>::BWD_WAVES;
+  const long long waves_f = (long long)bwd_grid<float>(nwin, heads).bph * WA<float>::BWD_WAVES;
   return (size_t)(waves_bf > waves_f ? waves_bf : waves_f) * heads * WT * WT * sizeof(float);
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Window attention forward / backward at the four SwinV2-T stage shapes of BASELINE config 5 (B = 256, 256 x 256 input, window 8):
 time per launch, algorithmic bytes (qkv in, out / d(out) in, d(qkv) out) and the HBM rate they correspond to.
-usage: python tools/winattn_probe.py [B] [out.json]"""
+usage: python tools/winattn_probe.py [B] [out.json | -] [option=value ...]"""
 import json
 import os
 import sys
@@ -28,6 +28,9 @@ def timeit(fn, n=10):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     lib = L.lib()
+    for kv in sys.argv[3:]:                      # library options, e.g. win_xcd=0
+        k, v = kv.split("=")
+        L.check(lib.rgbnm_set_option(k.encode(), int(v)))
     dt = torch.bfloat16
     rows = []
     tot_f = tot_b = 0.0
@@ -64,7 +67,7 @@ def main():
             tot_f += tf * n
             tot_b += tb * n
     print("per step (12 blocks): forward %.2f ms, backward %.2f ms" % (tot_f / 1e3, tot_b / 1e3))
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[2] != "-":
         json.dump(dict(B=B, rows=rows, fwd_ms_per_step=tot_f / 1e3, bwd_ms_per_step=tot_b / 1e3), open(sys.argv[2], "w"), indent=1)
 
 
