@@ -2,7 +2,7 @@
 """The eight activation GEMMs of one JPEG-S encoder block (E = 384, B = 256: M = 50176 rows) through rgbnm_gemm_nt, with the
 library GEMM torch dispatches to (hipBLASLt / rocBLAS) beside each as a yardstick -- what a tuned plain GEMM of that shape takes
 on this GPU.  The yardstick has no fused epilogue: its time is a lower bound for the plain part only.
-usage: python tools/nt384_probe.py [E] [out.json] [M]     (SwinV2-T stages at B = 256: E, M = 96, 1048576 / 192, 262144 / 384, 65536 / 768, 16384)"""
+usage: python tools/nt384_probe.py [E] [out.json | -] [M] [option=value ...]     (SwinV2-T stages at B = 256: E, M = 96, 1048576 / 192, 262144 / 384, 65536 / 768, 16384)"""
 import json
 import os
 import sys
@@ -33,6 +33,9 @@ def main():
     if len(sys.argv) > 3:
         M = int(sys.argv[3])
     lib = L.lib()
+    for kv in sys.argv[4:]:                      # library options, e.g. kp_split=2
+        k, v = kv.split("=")
+        L.check(lib.rgbnm_set_option(k.encode(), int(v)))
     dt = torch.bfloat16
     g = torch.Generator(device=DEV)
     g.manual_seed(0)
