@@ -322,7 +322,9 @@ def stage_bias_and_scale(blocks):
     h = torch.relu(torch.baddbmm(b1.unsqueeze(1), tab, W1.transpose(1, 2)))      # [nb,225,512]
     t = torch.bmm(W2, h.transpose(1, 2))                                         # [nb,H,225]
     n = a0.window_size[0] * a0.window_size[1]
-    bias = 16 * torch.sigmoid(t.index_select(2, a0.relative_position_index.view(-1))).view(nb, a0.num_heads, n, n)
+    # advanced indexing, not index_select: its backward is the sort-based index_put (run-to-run identical bits); index_select's is
+    # an atomicAdd scatter (tests/test_swin.py::test_swin_step_is_bit_reproducible)
+    bias = 16 * torch.sigmoid(t[:, :, a0.relative_position_index.view(-1)]).view(nb, a0.num_heads, n, n)
     scale = torch.clamp(ls, max=math.log(1.0 / 0.01)).exp()
     return bias.unbind(0), scale.unbind(0)
 

@@ -291,4 +291,29 @@ def test_fused_optimizer_equals_train_py_objects_on_swin(golden):
         runs.append({n: p.detach().clone() for n, p in m.named_parameters()})
     worst = max(((runs[0][n] - runs[1][n]).abs().max() / (runs[0][n].abs().max() + 1e-12)).item() for n in runs[0])
     print(f"fused vs train.py objects after 3 steps: worst relative parameter difference {worst:.2e}")
-    assert worst < 5e-5
+    assert worst < 1e-4        # Adam normalises by sqrt(v): a last-bit difference in the clip norm moves small-gradient entries by ~1e-5 of the largest weight
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_swin_step_is_bit_reproducible(golden, dt):
+    """No atomics anywhere (window-attention d(bias), LayerNorm and weight-gradient partial sums go through the ordered reduction):
+    the same inputs give the same bits, run after run -- a race in the wave-private LDS staging of the attention kernels or in a
+    persistent launch's work split would show here."""
+    g = golden("g15_swin.npz")
+    m, *_ = _model("swt", DEV)
+    names, y, c, tgt = _load(m, "swt", g)
+    m.train()
+    m.compute_dtype = dt
+    runs = []
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad = None
+        logits = m(y, c)
+        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=dt).backward()
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    for k in (1, 2):
+        assert torch.equal(runs[0][0], runs[k][0])
+        bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[k][1][n])]
+        assert not bad, bad[:5]
