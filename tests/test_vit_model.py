@@ -488,3 +488,30 @@ def test_wide_embeddings_vitb_vitl(emb, heads):
     projection Linears are rectangular, and the softmax scale stays 1/sqrt(emb), plainvit.py:459).  These widths run the
     generic kernels (one wave per LayerNorm row); no launch is tuned for them -- the test is that the model is usable."""
     _fp32_and_bf16_vs_oracle(emb, heads, 2, 3, 1000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("emb,heads,B", [(192, 3, 64), (384, 6, 8), (768, 12, 3)])
+def test_vit_step_is_bit_reproducible(emb, heads, B):
+    """Every reduction of the backward runs in a fixed order (split partial sums + the ordered reduction kernels, no atomics): the
+    same inputs give the same bits, run after run, on the fused E = 192 path (B = 64 takes the large-batch kernels), the E = 384
+    path and the generic widths.  A race in a persistent kernel's ring / staging reuse would show here."""
+    m = rg.ViT(3, 16, emb, depth=2, n_classes=1000, drop_p=0.0, device=DEV, num_heads=heads, head_size=64,
+               pixel_space="DCT", ver=1, use_subblock=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in detfill.fill_state_dict(shapes, base_seed=1).items()})
+    m.compute_dtype = torch.bfloat16
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    lab = torch.from_numpy(detfill.integers((B,), 74, 0, 998, np.int64)).to(DEV)
+    runs = []
+    for _ in range(3):
+        m.zero_grad()
+        logits = m(y, c)
+        rg.cls_transforms.cross_entropy(logits, lab, grad_dtype=torch.bfloat16).backward()
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    for k in (1, 2):
+        assert torch.equal(runs[0][0], runs[k][0])
+        bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[k][1][n])]
+        assert not bad, bad[:5]
