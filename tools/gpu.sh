@@ -14,6 +14,10 @@
 #   variants <file.hip> <kernel-pattern> <-DFLAG ...>   rebuild ONE csrc file per flag on the box and print that kernel's time
 #   stalls <tag> [bench args]       SQ activity / wait / LDS-conflict counters per kernel (three --pmc passes)
 #   stress [n]                      bit-identity loop of the fused kernels + a 3000-step run (races show as a differing bit / NaN)
+#
+# Stand-alone probes (run them directly on the box):  tools/nt384_probe.py E [out|-] M [opt=val]   activation GEMMs of a block vs the library GEMM
+#   tools/tn_probe.py E M [opt=val]          weight-gradient GEMMs of a block      tools/winattn_probe.py [B] [out|-] [opt=val]   window attention per stage
+#   tools/winattn_prof.py [shift] [fwd]      cycle stamps inside the window-attention kernels (build with RGBNM_HIPCC_FLAGS=-DWIN_PROF[=2])
 export TMPDIR=/tmp
 CMD=$1; shift
 line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('$1', d['value'], d['ms_per_step'], r.get('avg_launch_us'), (d.get('parity_check') or {}).get('max_abs_dlogit'))"; }
