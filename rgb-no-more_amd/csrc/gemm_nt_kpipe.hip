@@ -83,3 +83,9 @@ int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ld
   return use_split(N) ? kp4::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st)
                       : kp7::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
 }
+
+#ifdef KP_PROF
+extern "C" int rgbnm_debug_kp_prof(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kp7::g_kp_prof), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+#endif

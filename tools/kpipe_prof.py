@@ -13,6 +13,7 @@ N, K = int(sys.argv[1]), int(sys.argv[2])
 epi = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 M = int(sys.argv[4]) if len(sys.argv) > 4 else 50176
 lib = L.lib()
+L.check(lib.rgbnm_set_option(b"kp_persist", 0))        # the stamps sit in the one-tile-per-workgroup kernel
 dt = torch.bfloat16
 A = torch.randn(M, K, device="cuda").to(dt)
 W = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
