@@ -47,8 +47,12 @@
 
 // kp8 when its rounds of workgroups cost less than kp7's: rounds x rows per panel, kp8 charged 5 % for its shallower ring
 // (measured: equal at M = 2^18 where both geometries fill their rounds, 17 % / 28 % faster at M = 2^16 / 2^14).
-static bool use_kp8(int M, int N) {
-  if (M % 256 || M % 224 == 0 || N % 192 || !rgbnm_get_option("kp8")) return false;
+static bool use_kp8(int M, int N, int epi) {
+  if (M % 256 || N % 192 || !rgbnm_get_option("kp8")) return false;
+  // row counts that suit both geometries (M = 50176 = 224 x 224 = 196 x 256, the ViT batch): measured per epilogue at E = 384 -- the
+  // plain GEMMs gain from the 2-D wave tiles (qkv 79 -> 71 us, the dX GEMMs 2 - 5 %), the residual / GELU / dGELU ones are level
+  // or lose the persistent form's prefetch (dGELU 128 -> 135 us)
+  if (M % 224 == 0) return epi == 0;
   const long long nt = N / 192, cus = 256;
   const long long r7 = ((long long)((M + 223) / 224) * nt + cus - 1) / cus * 224, r8 = ((long long)(M / 256) * nt + cus - 1) / cus * 256;
   return r8 * 105 < r7 * 100;
@@ -79,7 +83,7 @@ int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, 
 // returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st) {
-  if (use_kp8(M, N)) return kp8::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
+  if (use_kp8(M, N, epi)) return kp8::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
   return use_split(N) ? kp4::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st)
                       : kp7::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
 }
