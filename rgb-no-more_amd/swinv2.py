@@ -309,6 +309,36 @@ class WindowAttention(nn.Module):
         return 16 * torch.sigmoid(bias), scale
 
 
+class _TableGatherFn(torch.autograd.Function):
+    """out[..., i] = tab[..., idx[i]] with a backward that is neither an atomicAdd scatter (index_select: bits change run to run) nor
+    the sort-based index_put (advanced indexing: deterministic but 27 us per call): every table entry sums the <= 64 positions that
+    read it, listed once in a padded [entries, 64] matrix `inv` (inverse_index) -- a gather and a row sum, fixed order."""
+
+    @staticmethod
+    def forward(ctx, tab, idx, inv):
+        ctx.inv = inv
+        return tab[..., idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        gp = torch.cat((g, g.new_zeros(g.shape[:-1] + (1,))), -1)        # column idx.numel(): the padding of `inv` reads zeros
+        return gp[..., ctx.inv].sum(-1), None, None
+
+
+def inverse_index(idx, n_entries):
+    """[n_entries, max count] positions i with idx[i] == entry (ascending), padded with idx.numel()."""
+    i = idx.detach().cpu().view(-1)
+    cnt = torch.bincount(i, minlength=n_entries)
+    inv = torch.full((n_entries, int(cnt.max())), i.numel(), dtype=torch.long)
+    order = torch.argsort(i, stable=True)
+    pos = 0
+    for e in range(n_entries):
+        c = int(cnt[e])
+        inv[e, :c] = order[pos:pos + c]
+        pos += c
+    return inv.to(idx.device)
+
+
 def stage_bias_and_scale(blocks):
     """WindowAttention.bias_and_scale of every block of one stage (same head count) as batched ops: the continuous-position-
     bias MLP is parameter-only work of ~20 tiny kernels forward and as many backward PER BLOCK -- 2 ms of launches per SwinV2-T
@@ -322,9 +352,12 @@ def stage_bias_and_scale(blocks):
     h = torch.relu(torch.baddbmm(b1.unsqueeze(1), tab, W1.transpose(1, 2)))      # [nb,225,512]
     t = torch.bmm(W2, h.transpose(1, 2))                                         # [nb,H,225]
     n = a0.window_size[0] * a0.window_size[1]
-    # advanced indexing, not index_select: its backward is the sort-based index_put (run-to-run identical bits); index_select's is
-    # an atomicAdd scatter (tests/test_swin.py::test_swin_step_is_bit_reproducible)
-    bias = 16 * torch.sigmoid(t[:, :, a0.relative_position_index.view(-1)]).view(nb, a0.num_heads, n, n)
+    # (run-to-run identical bits: tests/test_swin.py::test_swin_step_is_bit_reproducible)
+    idx = a0.relative_position_index.view(-1)
+    inv = a0.__dict__.get("_inv_index")
+    if inv is None or inv.device != idx.device:
+        inv = a0.__dict__["_inv_index"] = inverse_index(idx, t.shape[-1])      # plain attribute: not a buffer, not in the state_dict
+    bias = 16 * torch.sigmoid(_TableGatherFn.apply(t, idx, inv)).view(nb, a0.num_heads, n, n)
     scale = torch.clamp(ls, max=math.log(1.0 / 0.01)).exp()
     return bias.unbind(0), scale.unbind(0)
 
