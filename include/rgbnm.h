@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RGBNM_ABI_VERSION 1
+#define RGBNM_ABI_VERSION 2
 #define RGBNM_DT_F32 0
 #define RGBNM_DT_BF16 1
 #define RGBNM_DT_I16 2   /* only as out_dtype of rgbnm_dct_augment[_ex] */
@@ -295,6 +295,29 @@ int rgbnm_vit_block_fwd_chain(const rgbnm_vit_cfg* cfg, const rgbnm_block_params
 int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, const rgbnm_block_acts* a,
                         const rgbnm_block_grads* g, const rgbnm_block_scratch* s, const void* dy, void* dx,
                         void* stream);
+
+/* ---- The whole encoder forward as ONE launch, one workgroup per image (csrc/vit_chain.hip) --------------------------------
+ * Reference: the `depth` TransformerEncoderBlocks of models/plainvit.py:493-529 applied in sequence (:601-611).  bf16, E = 192,
+ * 3 heads, 196 tokens (JPEG-Ti); needs rgbnm_gelu_table_init on the device.  The residual stream, LayerNorm outputs, q and the
+ * attention output stay in registers, K / V of one head in LDS; every tensor the backward reads (rgbnm_block_acts) is written
+ * exactly as rgbnm_vit_block_fwd writes it, so rgbnm_vit_block_bwd runs unchanged behind it.
+ * rgbnm_chain_block: one block's parameters and outputs (device pointers); the caller keeps an array of `depth` of them in
+ *   DEVICE memory.  x_in of block 0 is the x0 argument; block i's x_out is block i + 1's input.
+ * wimg: the block's "chain image" -- its four weight matrices as they lie in LDS (rows permuted, 16-byte chunks swizzled,
+ *   consumption order), rgbnm_chain_image_elems() bf16 elements, written per step by rgbnm_chain_gather(src = operand shadows,
+ *   idx = constant int32 table built on the host: rgb-no-more_amd/chain.py documents the layout).
+ * Returns RGBNM_OK, 1 when the configuration is not eligible (the caller runs the blocks one by one), or a negative error. */
+typedef struct rgbnm_chain_block {
+  const void* wimg;
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv_perm, *bproj, *b1, *b2;
+  void* xn1; float *mean1, *rstd1;
+  void* qkv; float* lse; void* attn; void* x_mid; void* xn2; float *mean2, *rstd2;
+  void* u; void* gl; void* x_out;
+} rgbnm_chain_block;
+size_t rgbnm_chain_block_bytes(void);          /* sizeof(rgbnm_chain_block) as the library was built */
+long long rgbnm_chain_image_elems(void);       /* bf16 elements of one block's chain image */
+int rgbnm_chain_gather(const void* src, const int* idx, void* dst, long long n, void* stream);   /* dst[i] = src[idx[i]], bf16, n % 8 == 0 */
+int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* cfg, const void* blocks_dev, int depth, const void* x0, void* stream);
 
 /* Table GELU of the bf16 path (csrc/mlp_fused.hip): in bf16 mode the pre-activation is rounded to bf16 before the GELU
  * (models/plainvit.py:487-488 under autocast), so gelu / gelu' are functions of 16 bits.  _init is a SET-UP call (it

@@ -864,6 +864,19 @@ extern "C" int rgbnm_gelu_table_init(void* stream) {
   T.state.store(ok ? 1 : -1, std::memory_order_release);
   return RGBNM_OK;
 }
+// Other translation units (vit_chain.hip): the device image and its window on the current device; returns the table state
+// (1 = usable, 0 = rgbnm_gelu_table_init not called, -1 = built but unusable)
+int rgbnm_gelu_table_query(const unsigned** img, int* A0, int* P1, int* N1, int* ndw) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const GeluTabHost& T = g_tab_host[dev & 63];
+  const int state = T.state.load(std::memory_order_acquire);
+  if (state == 1) {
+    *img = T.img; *A0 = T.A0; *P1 = T.P1; *N1 = T.N1;
+    *ndw = (T.P1 - T.A0 + 2) + (T.N1 - T.A0 + 2);
+  }
+  return state;
+}
 // Test / diagnostics: the window descriptor (16 ints) and, optionally, the full table (65536 dwords) on the host.  Synchronises.
 extern "C" int rgbnm_gelu_table_info(int* win16, unsigned* full65536) {
   if (hipDeviceSynchronize() != hipSuccess) return RGBNM_ELAUNCH;

@@ -1,0 +1,782 @@
+// The whole encoder of JPEG-Ti as ONE persistent launch, one workgroup per image (reference: the twelve
+// TransformerEncoderBlocks of models/plainvit.py:493-529 applied in sequence, :601-611).
+//
+// Why: nothing in the encoder forward couples two images -- LayerNorm, the Linears, attention and the residual adds are all
+// row- or image-local -- so an image can stay on one CU for all twelve blocks.  The per-operation launches (qkv GEMM, attention,
+// projection + LN2, fused MLP: 48 per forward) each pay a start (DMA ring fill), a memory-bound epilogue and a tail in which
+// the slowest workgroup holds the next launch back, and every activation makes a round trip through L2 / HBM between them
+// (463 MB per block read + written).  Here the residual stream, the LayerNorm outputs, q and the attention output never leave
+// the registers of the wave that owns the 32 tokens; K and V of one head live in LDS; what goes to HBM is exactly what the
+// backward needs (307 MB per block), written by the wave that produced it while the next phase already runs.  Workgroups drift
+// apart over the twelve blocks, so the store bursts of different CUs no longer coincide.
+//
+// Structure: 512 threads = 7 compute waves (32 tokens each, 196 = 6 x 32 + 4) + 1 DMA wave that streams the weights of the
+// whole forward, in consumption order, from a per-step "chain image" (written by rgbnm_chain_gather: rows and swizzles exactly
+// as they lie in LDS, so every transfer is a linear 1 KB LDS-DMA) into three 24 KB slots (attention part: q, k, v and output
+// projection chunks of one head each) / two 48 KB stages (MLP part: hidden chunks of 64, as mlp_fused.hip).  One workgroup
+// barrier per step, 28 steps per block; the DMA wave runs a static schedule two short steps (one long step) ahead.
+//
+// Register convention ("D layout"): every [tokens, features] activation is held as the accumulator of a swapped MFMA
+// (D rows = features, D cols = tokens): lane (l31, g) owns token 32 w + l31 and, of every 16 features, the 8 with bit 3 == g.
+// All weight matrices are stored with their OUTPUT rows permuted by swapping index bits 2 and 3, so that accumulator registers
+// 8 hs .. 8 hs + 7 of tile b are the 8 CONSECUTIVE features 32 b + 16 hs + 8 g + (0..7): one bf16x8 that is at the same time
+// (i) a B-operand fragment of the next GEMM (reduction index in natural order), (ii) a 16-byte piece of the row in memory.
+// The attention output leaves the PV MFMAs in plain accumulator order; the projection weights' reduction index is permuted to
+// match (rgbnm_chain_gather).  LayerNorm runs on these registers: a token's 192 features sit in two lanes (l31, l31 + 32).
+//
+// Arithmetic vs the per-operation path: same operand rounding points (q, k, v, attention output, LayerNorm outputs, gelu, the
+// residual stream are rounded to bf16 where that path stores them), fp32 accumulation; the two residual adds are done in fp32
+// on the accumulator (one rounding instead of two) and the LayerNorm sums run in a different order -- results agree to bf16
+// rounding, not bit for bit (tests/test_chain_fwd.py compares with the per-operation kernels and with the reference golden).
+#include "common.h"
+#include <type_traits>
+#include "internal.h"
+#include "../../include/rgbnm.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+constexpr int E = 192, HID = 768, HD = 64, HEADS = 3, NTOK = 196, NTILE = 7, NPAD = 224, INNER = HEADS * HD;
+constexpr int NCW = 7, NTHREADS = 64 * (NCW + 1);
+constexpr int ROWB = 128;
+constexpr int SLOT = 24576;                       // one 64 x 192 (or 192 x 64) bf16 weight chunk
+// ---- LDS, attention part of a block
+constexpr int A_SLOT0 = 0;                        // three chunk slots
+constexpr int K_OFF = 3 * SLOT;                   // 73728: K[224][64] (rows 196.. hold the LN1 parameters: masked keys)
+constexpr int ARR = NPAD * ROWB;                  // 28672
+constexpr int V_OFF = K_OFF + ARR;                // 102400
+constexpr int STGA_OFF = V_OFF + ARR;             // 131072: private 32 x 128 B tiles of the compute waves
+constexpr int STG_TILE = 32 * ROWB;               // 4096
+constexpr int MISC_OFF = STGA_OFF + NCW * STG_TILE;   // 159744: LN2 gamma, beta, projection bias (fp32)
+constexpr int LN1P_OFF = K_OFF + NTOK * ROWB;     // 98816: LN1 gamma | beta (fp32), inside the K pad rows
+// ---- LDS, MLP part
+constexpr int TAB_LIMIT = 12816;                  // the GELU table image must end here ...
+constexpr int B1R_OFF = TAB_LIMIT;                // ... the fc1-bias ring (2 x 64 floats) follows
+constexpr int ST1_OFF = 13440;                    // odd hidden chunks: W1 chunk | W2 chunk (128-byte aligned)
+constexpr int STAGE = 2 * SLOT;
+constexpr int TA_OFF = ST1_OFF + STAGE;           // 62592: gelu tiles of wave 5, then wave 6's
+constexpr int ST0_OFF = K_OFF;                    // even hidden chunks (over K, V: dead by then)
+constexpr int TB_OFF = ST0_OFF + STAGE;           // 122880: gelu | gelu' tiles of waves 0..4
+constexpr int SMEM = 163840;
+static_assert(MISC_OFF + 3 * E * 4 <= SMEM, "LDS");
+static_assert(TB_OFF + 10 * STG_TILE <= SMEM, "LDS");
+static_assert(TA_OFF + 2 * STG_TILE + 2 * 4 * ROWB <= ST0_OFF, "LDS");
+static_assert(LN1P_OFF + 2 * E * 4 <= V_OFF, "LDS");
+static_assert(B1R_OFF + 512 <= ST1_OFF && ST1_OFF % 128 == 0 && TA_OFF % 128 == 0, "LDS");
+
+struct ChainBlk {            // = rgbnm_chain_block (rgbnm.h) with typed pointers
+  const bf16* wimg;          // 12 attention chunks (q0 k0 v0 q1 k1 v1 q2 k2 v2 p0 p1 p2) | 12 x (W1 chunk | W2 chunk)
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bproj, *b1, *b2;
+  bf16* xn1; float *mean1, *rstd1;
+  bf16* qkv; float* lse; bf16* attn; bf16* x_mid; bf16* xn2; float *mean2, *rstd2;
+  bf16* gp; bf16* gl; bf16* x_out;       // gp = gelu'(u) (rgbnm_block_acts.u), gl = gelu(u)
+};
+static_assert(sizeof(ChainBlk) == sizeof(rgbnm_chain_block), "rgbnm_chain_block layout");
+struct ChainArgs {
+  const ChainBlk* blk; const bf16* x0;
+  int depth, nimg;
+  float eps, scale;
+  const unsigned* tab_img; int tab_pieces;
+  unsigned kneg, kpos, klo, koff, ksgn;
+};
+
+__device__ __forceinline__ int fswz(int row) {
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+}
+
+struct Geo {
+  int lane, l31, g, fl;
+  unsigned tr0;    // byte offset inside a [token][64] array of the (t=0, fi=0, dt=0, rd=0) transpose read (attention_v2.hip)
+};
+__device__ __forceinline__ Geo make_geo() {
+  Geo L;
+  L.lane = threadIdx.x & 63;
+  L.l31 = L.lane & 31;
+  L.g = L.lane >> 5;
+  L.fl = fswz(L.l31);
+  const int k = (L.lane >> 2) & 3, G1 = (L.lane >> 4) & 1, l3 = L.lane & 3;
+  const int pc = (2 * G1 + (l3 >> 1)) ^ (((k >> 1) << 2) | L.g);
+  L.tr0 = (unsigned)((4 * L.g + k) * ROWB + pc * 16 + 8 * (l3 & 1));
+  return L;
+}
+
+template <int T> struct TileLoop {
+  template <typename F> static __device__ __forceinline__ void run(F&& f) {
+    TileLoop<T - 1>::run(f);
+    f(std::integral_constant<int, T - 1>{});
+  }
+};
+template <> struct TileLoop<0> {
+  template <typename F> static __device__ __forceinline__ void run(F&&) {}
+};
+
+__device__ __forceinline__ bf16x8 pack8(u32x2 lo, u32x2 hi) {
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// Both fragments (FI = 0, 1) x both d tiles of key tile T of the V array (tokens as reduction axis): 8 transpose reads, one wait
+template <int T>
+__device__ __forceinline__ void tfrag4(unsigned a0, Frag<bf16> (&f)[4]) {
+  u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+  const unsigned a00 = a0, a01 = (a0 ^ 32u) + 1024u, a10 = a0 ^ 64u, a11 = (a0 ^ 96u) + 1024u;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "i"(T * 4096), "i"(T * 4096 + 2048)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  f[0].v = pack8(r0, r1);   // fi=0, dt=0
+  f[1].v = pack8(r2, r3);   // fi=0, dt=1
+  f[2].v = pack8(r4, r5);   // fi=1, dt=0
+  f[3].v = pack8(r6, r7);   // fi=1, dt=1
+}
+__device__ __forceinline__ Frag<bf16> pfrag(const float (&p)[16], int fi) {
+  Frag<bf16> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (bf16)p[fi * 8 + j];
+  return f;
+}
+
+// A per-lane value the optimiser must treat as new: addresses derived from it are re-derived where they are used (one XOR / add
+// each) instead of being hoisted out of the block loop as invariants and spilled (common.h, lane_id_here)
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// workgroup barrier that the compiler may not move LDS / global accesses across (the builtin alone is "no memory")
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// ---- DMA wave helpers: linear 1 KB pieces
+template <int NKB>
+__device__ __forceinline__ void dma_linear(const unsigned char* src, unsigned char* dst, int lane) {
+#pragma unroll
+  for (int i = 0; i < NKB; ++i)
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + i * 1024 + lane * 16), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+}
+__device__ __forceinline__ void dma_f32x192(const float* src, unsigned char* dst, int lane) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + 64 * i + lane), (lds_ptr)(dst + 256 * i), 4, 0, 0);
+}
+
+// ---- D-layout rows: 12 pieces (index c = 2 b + hs) of 8 bf16 = features 16 c + 8 g + (0..7) of the lane's token
+struct Rows { bf16x8 v[12]; };
+
+__device__ __forceinline__ void ln_stats(const Rows& x, float& mu, float& rs, float eps) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 12; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      s0 += (float)x.v[c][j];
+      s1 += (float)x.v[c][j + 1];
+    }
+  float s = s0 + s1;
+  s += __shfl_xor(s, 32, 64);
+  mu = s * (1.f / E);
+  float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 12; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const float d0 = (float)x.v[c][j] - mu, d1 = (float)x.v[c][j + 1] - mu;
+      q0 = __builtin_fmaf(d0, d0, q0);
+      q1 = __builtin_fmaf(d1, d1, q1);
+    }
+  float q = q0 + q1;
+  q += __shfl_xor(q, 32, 64);
+  rs = rsqrtf(__builtin_fmaf(q, 1.f / E, eps));
+}
+// y = (x - mu) * rs * gamma + beta, gamma | beta = 2 x 192 floats in LDS
+__device__ __forceinline__ void ln_apply(const Rows& x, float mu, float rs, const float* gb, int g, Rows& y) {
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const float* gp = gb + 16 * c + 8 * g;
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(gp + E), b1 = *reinterpret_cast<const f32x4*>(gp + E + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gm = j < 4 ? g0[j & 3] : g1[j & 3], bt = j < 4 ? b0[j & 3] : b1[j & 3];
+      y.v[c][j] = (bf16)__builtin_fmaf(((float)x.v[c][j] - mu) * rs, gm, bt);
+    }
+    if (c & 1) __builtin_amdgcn_sched_barrier(0);     // (else all 48 parameter reads are issued up front: 192 registers)
+  }
+}
+
+// One 64-feature third (pieces c0 .. c0 + 3) of the wave's 32 rows -> private tile -> whole 128-byte row pieces -> global
+// (row r of the wave at dst + r * ld).  The tile is swizzled by 16-byte chunk: chunk q of row r at q ^ (r & 7).
+__device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, const bf16x8& p0, const bf16x8& p1, const bf16x8& p2,
+                                         const bf16x8& p3, bf16* dst, int ld, int live) {
+  const int ln = lane_id_here();
+  // own row ln & 31, chunk 2 q + g at (2 q + g) ^ (row & 7): one base offset, q selected by XOR (the tile is 128-byte aligned)
+  const unsigned wo = stg + (unsigned)((ln & 31) * ROWB + (((ln >> 5) ^ (ln & 7)) << 4));
+  *reinterpret_cast<bf16x8*>(smem + wo) = p0;
+  *reinterpret_cast<bf16x8*>(smem + (wo ^ 32u)) = p1;
+  *reinterpret_cast<bf16x8*>(smem + (wo ^ 64u)) = p2;
+  *reinterpret_cast<bf16x8*>(smem + (wo ^ 96u)) = p3;
+  wait_lds();
+  const int rl = ln >> 3, seg = ln & 7;
+  const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));      // row i * 8 + rl: (row & 7) == rl
+  bf16* gp = dst + (size_t)rl * ld + seg * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+    if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v;
+  }
+  wait_lds();
+}
+__device__ __forceinline__ void rows_out(unsigned char* smem, unsigned stg, const Rows& x, bf16* dst, int live) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) tile_out(smem, stg, x.v[4 * t], x.v[4 * t + 1], x.v[4 * t + 2], x.v[4 * t + 3], dst + 64 * t, E, live);
+}
+
+// acc (32 output features x 32 tokens, swapped) += W chunk rows [32 ht .. +31] . x : 12 k-steps; chunk rows are 384 B, 16-byte
+// chunks swizzled by pchunk (as the W1 stage of mlp_fused.hip)
+__device__ __forceinline__ void gemm_k192(f32x16& acc, const unsigned char* sW, int ht, const Rows& x, const Geo& L) {
+  int wbase = L.l31 * (E * 2) + ((L.g ^ L.fl) << 4) + ht * 32 * (E * 2);
+  asm volatile("" : "+v"(wbase));
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    Frag<bf16> fb, fx;
+    fb.v = *reinterpret_cast<const bf16x8*>(sW + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+    fx.v = x.v[c];
+    mma(acc, fb, fx);
+  }
+}
+
+__global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int img = blockIdx.x;
+  if (img >= p.nimg) return;
+  const Geo L = make_geo();
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int depth = p.depth;
+
+  if (w == NCW) {
+    // ================================================================ DMA wave: the static weight schedule
+    const int lane = L.lane;
+    auto chunkA = [&](const ChainBlk& b, int idx, int slot) {
+      dma_linear<24>(reinterpret_cast<const unsigned char*>(b.wimg) + (size_t)idx * SLOT, smem + A_SLOT0 + slot * SLOT, lane);
+    };
+    auto chunkM = [&](const ChainBlk& b, int c) {
+      unsigned char* st = smem + ((c & 1) ? ST1_OFF : ST0_OFF);
+      dma_linear<48>(reinterpret_cast<const unsigned char*>(b.wimg) + (size_t)12 * SLOT + (size_t)c * STAGE, st, lane);
+    };
+    auto bias1 = [&](const ChainBlk& b, int c) {
+      __builtin_amdgcn_global_load_lds((glb_ptr)(b.b1 + c * 64 + lane), (lds_ptr)(smem + B1R_OFF + (c & 1) * 256), 4, 0, 0);
+    };
+    auto ln1p = [&](const ChainBlk& b) {
+      dma_f32x192(b.ln1_g, smem + LN1P_OFF, lane);
+      dma_f32x192(b.ln1_b, smem + LN1P_OFF + E * 4, lane);
+    };
+    auto misc = [&](const ChainBlk& b) {
+      dma_f32x192(b.ln2_g, smem + MISC_OFF, lane);
+      dma_f32x192(b.ln2_b, smem + MISC_OFF + E * 4, lane);
+      dma_f32x192(b.bproj, smem + MISC_OFF + 2 * E * 4, lane);
+    };
+    {
+      const ChainBlk& b0 = p.blk[0];
+      ln1p(b0);
+      misc(b0);
+      chunkA(b0, 0, 0);
+      chunkA(b0, 1, 1);
+      chunkA(b0, 2, 2);
+      wait_vm<63>();                        // the parameter vectors have landed (they are older than the 72 chunk pieces)
+      wait_vm<48>();
+      wg_barrier();         // init
+    }
+    for (int ib = 0; ib < depth; ++ib) {
+      const ChainBlk& b = p.blk[ib];
+      wait_vm<48>(); wg_barrier();                       // 0: q0
+      wait_vm<24>(); wg_barrier();                       // 1: k0
+      chunkA(b, 3, 0); wait_vm<24>(); wg_barrier();      // 2: v0
+      chunkA(b, 4, 1); wg_barrier();                     // 3: attention 0
+      chunkA(b, 5, 2); wait_vm<48>(); wg_barrier();      // 4: q1
+      wait_vm<24>(); wg_barrier();                       // 5: k1
+      chunkA(b, 6, 0); wait_vm<24>(); wg_barrier();      // 6: v1
+      chunkA(b, 7, 1); wg_barrier();                     // 7: attention 1
+      chunkA(b, 8, 2); wait_vm<48>(); wg_barrier();      // 8: q2
+      wait_vm<24>(); wg_barrier();                       // 9: k2
+      chunkA(b, 9, 0); wait_vm<24>(); wg_barrier();      // 10: v2
+      chunkA(b, 10, 1); wg_barrier();                    // 11: attention 2
+      chunkA(b, 11, 2); wait_vm<48>(); wg_barrier();     // 12: p0
+      chunkM(b, 0); wait_vm<63>(); wg_barrier();         // 13: p1 (older than p2 and the 48 pieces behind it)
+      {                                                                   // GELU table image + first fc1-bias piece
+        for (int i = 0; i * 64 < p.tab_pieces; ++i)
+          if (i * 64 + lane < p.tab_pieces)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(p.tab_img + (i * 64 + lane) * 4), (lds_ptr)(smem + i * 1024), 16, 0, 0);
+        bias1(b, 0);
+      }
+      wait_vm<49>(); wg_barrier();                       // 14: p2 (at least the 48 + 1 pieces of chunk 0 are younger)
+      wait_vm<0>(); wg_barrier();                        // 15: hidden chunk 0, table, bias
+      for (int c = 0; c < 11; ++c) {
+        chunkM(b, c + 1);
+        bias1(b, c + 1);
+        wait_vm<0>(); wg_barrier();                      // 16 + c
+      }
+      if (ib + 1 < depth) ln1p(p.blk[ib + 1]);                           // stage 0 (over the K pad rows) is dead since barrier 26
+      wait_vm<0>(); wg_barrier();                        // 27: every wave has left the last hidden chunk
+      if (ib + 1 < depth) {
+        const ChainBlk& nb = p.blk[ib + 1];
+        misc(nb);
+        chunkA(nb, 0, 0);
+        chunkA(nb, 1, 1);
+        chunkA(nb, 2, 2);
+      }
+    }
+    return;
+  }
+
+  // ==================================================================== compute waves
+  const int row0 = 32 * w;
+  const int live = NTOK - row0 < 32 ? NTOK - row0 : 32;          // 32, or 4 for the seventh wave
+  const int tok = row0 + L.l31 < NTOK ? row0 + L.l31 : NTOK - 1; // this lane's token (clamped: finite data in the pad rows)
+  const size_t grow0 = (size_t)img * NTOK + row0;                // first global row of the wave
+  const unsigned stg = (unsigned)(STGA_OFF + w * STG_TILE);      // LDS offset of the private tile
+  const float c2 = p.scale * 1.4426950408889634f;
+  const float* ln1p = reinterpret_cast<const float*>(smem + LN1P_OFF);
+  const float* ln2p = reinterpret_cast<const float*>(smem + MISC_OFF);
+  const float* bprj = reinterpret_cast<const float*>(smem + MISC_OFF + 2 * E * 4);
+
+  Rows xr;                                                        // the residual stream of this lane's token
+  {
+    const bf16* xrow = p.x0 + ((size_t)img * NTOK + tok) * E + 8 * L.g;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) xr.v[c] = *reinterpret_cast<const bf16x8*>(xrow + 16 * c);
+  }
+  float mu1, rs1;
+  ln_stats(xr, mu1, rs1, p.eps);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wg_barrier();                                   // init: LN parameters of block 0 are in LDS
+  {
+    const ChainBlk& b0 = p.blk[0];
+    Rows xn;
+    ln_apply(xr, mu1, rs1, ln1p, L.g, xn);
+    rows_out(smem, stg, xn, b0.xn1 + grow0 * E, live);
+    if (L.g == 0 && L.l31 < live) {
+      b0.mean1[grow0 + L.l31] = mu1;
+      b0.rstd1[grow0 + L.l31] = rs1;
+    }
+  }
+
+  for (int ib = 0; ib < depth; ++ib) {
+    const ChainBlk& b = p.blk[ib];
+    Frag<bf16> of[HEADS][4];                                      // attention output of the three heads as projection operands
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      Rows xn;
+      ln_apply(xr, mu1, rs1, ln1p, L.g, xn);                      // LN1 output, recomputed per head (48 registers not held)
+      Frag<bf16> qf[4];
+      // ---------------- q, k, v of head h: three steps of 24 MFMAs
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const float* bias = b.bqkv + m * INNER + h * HD + 8 * L.g;
+        f32x4 bv[2][2][2];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+          for (int hs = 0; hs < 2; ++hs) {
+            bv[ht][hs][0] = *reinterpret_cast<const f32x4*>(bias + 32 * ht + 16 * hs);
+            bv[ht][hs][1] = *reinterpret_cast<const f32x4*>(bias + 32 * ht + 16 * hs + 4);
+          }
+        wg_barrier();                             // step 4 h + m: the chunk has landed
+        const unsigned char* sW = smem + A_SLOT0 + m * SLOT;
+        f32x16 acc[2];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ht][r] = 0.f;
+          gemm_k192(acc[ht], sW, ht, xn, L);
+        }
+        bf16x8 pc[4];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+          for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              pc[2 * ht + hs][j] = (bf16)(acc[ht][8 * hs + j] + (j < 4 ? bv[ht][hs][0][j & 3] : bv[ht][hs][1][j & 3]));
+        if (m == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) qf[c].v = pc[c];
+        } else {
+          // K / V array row of this lane's token: 16-byte chunk q at q ^ fswz(row).  The seventh wave leaves the K pad rows
+          // alone (LN1 parameters) and fills the V pad rows with its clamped (finite) rows.
+          const unsigned ao = opaque((unsigned)((m == 1 ? K_OFF : V_OFF) + (row0 + L.l31) * ROWB + ((L.g ^ L.fl) << 4)));
+          if (m == 2 || L.l31 < live) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<bf16x8*>(smem + (ao ^ (unsigned)(c << 5))) = pc[c];
+          }
+        }
+        tile_out(smem, stg, pc[0], pc[1], pc[2], pc[3], b.qkv + grow0 * (3 * INNER) + m * INNER + h * HD, 3 * INNER, live);
+      }
+      // ---------------- attention of head h (the forward of attention_v2.hip: scores recomputed in the second pass)
+      wg_barrier();                               // step 4 h + 3: every K, V row is written
+      {
+        const unsigned char* Ks = smem + K_OFF;
+        unsigned rb = (unsigned)(L.l31 * ROWB + ((L.g ^ L.fl) << 4)), tr = L.tr0;
+        asm volatile("" : "+v"(rb), "+v"(tr));
+        float mx = -INFINITY;
+        TileLoop<NTILE>::run([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            Frag<bf16> kf;
+            kf.v = *reinterpret_cast<const bf16x8*>(Ks + (rb ^ (unsigned)(c << 5)) + t * 32 * ROWB);
+            mma(acc, kf, qf[c]);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            if (t * 32 + 32 > NTOK && t * 32 + acc_row(r, L.lane) >= NTOK) v = -INFINITY;
+            mx = fmaxf(mx, v);
+          }
+        });
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc2 = mx * c2;
+        float sum = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        const unsigned vt = (unsigned)V_OFF + tr;
+        TileLoop<NTILE>::run([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            Frag<bf16> kf;
+            kf.v = *reinterpret_cast<const bf16x8*>(Ks + (rb ^ (unsigned)(c << 5)) + t * 32 * ROWB);
+            mma(acc, kf, qf[c]);
+          }
+          float pr[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            pr[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mc2));
+            if (t * 32 + 32 > NTOK && t * 32 + acc_row(r, L.lane) >= NTOK) pr[r] = 0.f;
+            sum += pr[r];
+          }
+          Frag<bf16> vv[4];
+          tfrag4<t>(vt, vv);
+          Frag<bf16> pf = pfrag(pr, 0);
+          mma(o[0], vv[0], pf);
+          mma(o[1], vv[1], pf);
+          pf = pfrag(pr, 1);
+          mma(o[0], vv[2], pf);
+          mma(o[1], vv[3], pf);
+        });
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (L.g == 0 && L.l31 < live) b.lse[((size_t)img * HEADS + h) * NTOK + row0 + L.l31] = mx * p.scale + __logf(sum);
+        // o: register r of tile dt = head dim 32 dt + 8 (r >> 2) + 4 g + (r & 3).  As projection operand (k order permuted in the
+        // chain image): registers 8 hs .. 8 hs + 7.  As memory rows: 8-byte pieces through the private tile.
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) of[h][2 * dt + hs].v[j] = (bf16)(o[dt][8 * hs + j] * inv);
+        {
+          const int ln = lane_id_here();
+          // 8-byte pieces: head dims 8 q + 4 g + (0..3) of the own row, chunk q at q ^ (row & 7)
+          const unsigned wo = stg + (unsigned)((ln & 31) * ROWB + ((ln & 7) << 4) + (ln >> 5) * 8);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              const bf16x8 src = of[h][2 * dt + (rq >> 1)].v;
+              bf16x4 q4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) q4[e] = src[4 * (rq & 1) + e];
+              *reinterpret_cast<bf16x4*>(smem + (wo ^ (unsigned)((dt * 4 + rq) << 4))) = q4;
+            }
+          wait_lds();
+          const int rl = ln >> 3, seg = ln & 7;
+          const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));
+          bf16* dst = b.attn + (grow0 + rl) * INNER + h * HD + seg * 8;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+            if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v;
+          }
+          wait_lds();
+        }
+      }
+    }
+    // ---------------- output projection: 3 steps of 24 MFMAs (k = the 64 dims of head h), then residual + LN2
+    f32x16 accp[6];
+#pragma unroll
+    for (int bt = 0; bt < 6; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[bt][r] = 0.f;
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      wg_barrier();                               // steps 12, 13, 14
+      // chunk image: [192 rows][128 B], chunk q at q ^ fswz(row)
+      const unsigned wo = opaque((unsigned)(A_SLOT0 + h * SLOT + L.l31 * ROWB + ((L.g ^ L.fl) << 4)));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<bf16> fw[6];
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt)
+          fw[bt].v = *reinterpret_cast<const bf16x8*>(smem + (wo ^ (unsigned)(s << 5)) + bt * 32 * ROWB);
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt) mma(accp[bt], fw[bt], of[h][s]);
+      }
+    }
+    float mu2, rs2;
+    {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        const float* bp = bprj + 16 * c + 8 * L.g;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          xr.v[c][j] = (bf16)(accp[c >> 1][8 * (c & 1) + j] + (j < 4 ? b0[j & 3] : b1[j & 3]) + (float)xr.v[c][j]);
+        if (c & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      ln_stats(xr, mu2, rs2, p.eps);
+      rows_out(smem, stg, xr, b.x_mid + grow0 * E, live);
+      if (L.g == 0 && L.l31 < live) {
+        b.mean2[grow0 + L.l31] = mu2;
+        b.rstd2[grow0 + L.l31] = rs2;
+      }
+    }
+    Rows fa;
+    ln_apply(xr, mu2, rs2, ln2p, L.g, fa);
+    rows_out(smem, stg, fa, b.xn2 + grow0 * E, live);
+
+    // ---------------- MLP: 12 hidden chunks of 64 (mlp_fused.hip), accumulator initialised with the residual
+    f32x16 acc2[6];
+#pragma unroll
+    for (int c = 0; c < 12; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc2[c >> 1][8 * (c & 1) + j] = (float)xr.v[c][j];
+    const unsigned tg = (unsigned)(w < 5 ? TB_OFF + 2 * w * STG_TILE
+                                         : (w == 5 ? TA_OFF : TA_OFF + 2 * STG_TILE));       // gelu tile (LDS offset); gelu' follows
+    const unsigned tpoff = (unsigned)(live * ROWB);                // (32 or 4 rows per tile)
+    const bool lane_live = L.l31 < live;
+    const unsigned kneg = p.kneg, kpos = p.kpos, klo = p.klo, koff = p.koff, ksgn = p.ksgn;
+    unsigned k4v = 0x00040004u;
+    asm volatile("" : "+v"(k4v));
+    const int woff0 = L.l31 * (E * 2) + ((L.g ^ L.fl) << 4);
+#ifdef X_NOMLP
+    for (int chunk = 0; chunk < HID / 64; ++chunk) wg_barrier();
+    for (int chunk = 0; chunk < 0; ++chunk) {
+#else
+    for (int chunk = 0; chunk < HID / 64; ++chunk) {
+#endif
+      wg_barrier();                               // steps 15 .. 26
+      const unsigned st_off = (unsigned)((chunk & 1) ? ST1_OFF : ST0_OFF);
+      const unsigned char* sW1 = smem + st_off;
+      const float* bch = reinterpret_cast<const float*>(smem + B1R_OFF) + (chunk & 1) * 64;
+      // per-lane bases of this chunk, made new here so that nothing derived from them is a block-loop invariant
+      const unsigned w2o = opaque(st_off + (unsigned)(SLOT + L.l31 * ROWB + ((L.g ^ L.fl) << 4)));       // W2 chunk, fragment s at ^ (s << 5)
+      const unsigned two = opaque(tg + (unsigned)(L.l31 * ROWB + ((L.g ^ (L.l31 & 7)) << 4)));          // own tile row, piece q at ^ (q << 5)
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht) {
+        f32x16 a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+        int wbase = woff0 + ht * 32 * (E * 2);
+        asm volatile("" : "+v"(wbase));
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+          Frag<bf16> fb, fx;
+          fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+          fx.v = fa.v[c];
+          mma(a1, fb, fx);
+        }
+        Frag<bf16> pg[2];
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+          const float* bp = bch + 32 * ht + 16 * hs + 8 * L.g;
+          const f32x4 bl = *reinterpret_cast<const f32x4*>(bp), bh = *reinterpret_cast<const f32x4*>(bp + 4);
+          bf16x8 gv, dv;
+          // table GELU of eight elements (see mlp_fused.hip: gelu_full_kernel / mlp_fwd_kernel<true>)
+          unsigned pb[4], agv[4], alo[4], ahi[4], e0[4], e1[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = 2 * jj;
+            const f32x2 uu = f32x2{a1[8 * hs + j], a1[8 * hs + j + 1]} + (j < 4 ? f32x2{bl[j], bl[j + 1]} : f32x2{bh[j - 4], bh[j - 3]});
+            const bf16x2v pbv = {(bf16)uu[0], (bf16)uu[1]};
+            pb[jj] = __builtin_bit_cast(unsigned, pbv);
+            unsigned p1, p2, ak, i4, sg;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(p1) : "v"(pb[jj]), "s"(kneg));
+            asm("v_pk_min_i16 %0, %1, %2" : "=v"(p2) : "v"(p1), "s"(kpos));
+            p1 &= 0x7FFF7FFFu;
+            p2 &= 0x7FFF7FFFu;
+            asm("v_pk_max_u16 %0, %1, %2" : "=v"(agv[jj]) : "v"(p1), "s"(0x00800080u));
+            asm("v_pk_max_u16 %0, %1, %2" : "=v"(ak) : "v"(p2), "s"(klo));
+            asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(i4) : "v"(ak), "v"(k4v), "s"(koff));
+            asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(sg) : "s"(0x000F000Fu), "v"(pb[jj]));
+            asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(i4) : "v"(sg), "s"(ksgn), "v"(i4));
+            alo[jj] = i4 & 0xffffu;
+            ahi[jj] = i4 >> 16;
+          }
+          asm volatile(
+              "ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+              "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(e0[0]), "=&v"(e1[0]), "=&v"(e0[1]), "=&v"(e1[1]), "=&v"(e0[2]), "=&v"(e1[2]), "=&v"(e0[3]), "=&v"(e1[3])
+              : "v"(alo[0]), "v"(ahi[0]), "v"(alo[1]), "v"(ahi[1]), "v"(alo[2]), "v"(ahi[2]), "v"(alo[3]), "v"(ahi[3])
+              : "memory");
+          u32x4 gq, dq;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const unsigned dpair = __builtin_amdgcn_perm(e1[jj], e0[jj], 0x05040100u);
+            unsigned gm;
+            asm("v_pk_sub_u16 %0, %1, %2" : "=v"(gm) : "v"(agv[jj]), "v"(dpair));
+            gq[jj] = (pb[jj] & 0x80008000u) | gm;
+            dq[jj] = __builtin_amdgcn_perm(e1[jj], e0[jj], 0x07060302u);
+          }
+          gv = __builtin_bit_cast(bf16x8, gq);
+          dv = __builtin_bit_cast(bf16x8, dq);
+          pg[hs].v = gv;
+          if (lane_live) {
+            const unsigned to = two ^ (unsigned)((2 * ht + hs) << 5);
+            *reinterpret_cast<bf16x8*>(smem + to) = gv;
+            *reinterpret_cast<bf16x8*>(smem + to + tpoff) = dv;
+          }
+        }
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+          const int s = 2 * ht + hs;
+          Frag<bf16> fw[6];
+#pragma unroll
+          for (int bt = 0; bt < 6; ++bt)
+            fw[bt].v = *reinterpret_cast<const bf16x8*>(smem + (w2o ^ (unsigned)(s << 5)) + bt * 32 * ROWB);
+#pragma unroll
+          for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw[bt], pg[hs]);
+        }
+      }
+      // the chunk's gelu / gelu' tiles out as whole 128-byte row pieces
+      wait_lds();
+      {
+        const int ln = lane_id_here();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+          if (row < live) {
+            const unsigned so = tg + (unsigned)(row * ROWB + ((vec ^ (row & 7)) << 4));
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(smem + so);
+            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(smem + so + tpoff);
+            const size_t go = (grow0 + row) * HID + chunk * 64 + vec * 8;
+            *reinterpret_cast<bf16x8*>(b.gl + go) = v0;
+            *reinterpret_cast<bf16x8*>(b.gp + go) = v1;
+          }
+        }
+        wait_lds();
+      }
+    }
+    wg_barrier();                                 // step 27: the MLP tiles and stages are dead
+    // ---------------- x_out = x_mid + fc2(...) + b2 ; next block's LN1
+    {
+      const float* b2p = b.b2 + 8 * L.g;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b2p + 16 * c), b1 = *reinterpret_cast<const f32x4*>(b2p + 16 * c + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr.v[c][j] = (bf16)(acc2[c >> 1][8 * (c & 1) + j] + (j < 4 ? b0[j & 3] : b1[j & 3]));
+        if (c & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      rows_out(smem, stg, xr, b.x_out + grow0 * E, live);
+      if (ib + 1 < depth) {
+        const ChainBlk& nb = p.blk[ib + 1];
+        ln_stats(xr, mu1, rs1, p.eps);
+        Rows xn;
+        ln_apply(xr, mu1, rs1, ln1p, L.g, xn);
+        rows_out(smem, stg, xn, nb.xn1 + grow0 * E, live);
+        if (L.g == 0 && L.l31 < live) {
+          nb.mean1[grow0 + L.l31] = mu1;
+          nb.rstd1[grow0 + L.l31] = rs1;
+        }
+      }
+    }
+  }
+}
+
+// dst[i] = src[idx[i]]: the chain image from the [N,K] operand shadows (the index table is built once on the host)
+__global__ __launch_bounds__(256) void chain_gather_kernel(const bf16* __restrict__ src, const int* __restrict__ idx,
+                                                           bf16* __restrict__ dst, long long n8) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const int4 a = *reinterpret_cast<const int4*>(idx + 8 * i), c = *reinterpret_cast<const int4*>(idx + 8 * i + 4);
+    bf16x8 v;
+    v[0] = src[a.x]; v[1] = src[a.y]; v[2] = src[a.z]; v[3] = src[a.w];
+    v[4] = src[c.x]; v[5] = src[c.y]; v[6] = src[c.z]; v[7] = src[c.w];
+    *reinterpret_cast<bf16x8*>(dst + 8 * i) = v;
+  }
+}
+
+}  // namespace
+
+int rgbnm_gelu_table_query(const unsigned** img, int* A0, int* P1, int* N1, int* ndw);   // mlp_fused.hip
+
+extern "C" {
+
+size_t rgbnm_chain_block_bytes(void) { return sizeof(ChainBlk); }
+long long rgbnm_chain_image_elems(void) { return 12ll * (SLOT / 2) + 12ll * (STAGE / 2); }
+
+int rgbnm_chain_gather(const void* src, const int* idx, void* dst, long long n, void* stream) {
+  if (!src || !idx || !dst || n <= 0 || n % 8) return RGBNM_EINVAL;
+  const long long n8 = n / 8;
+  int grid = (int)((n8 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(chain_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, n8);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+// 1 = not eligible (the caller runs the blocks one by one)
+int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* c, const void* blk_table_dev, int depth, const void* x0, void* stream) {
+  if (!c || !blk_table_dev || !x0 || depth <= 0) return RGBNM_EINVAL;
+  if (c->dtype != RGBNM_DT_BF16 || c->E != E || c->heads != HEADS || c->N != NTOK || c->B < 1) return 1;
+  const unsigned* img = nullptr;
+  int A0 = 0, P1 = 0, N1 = 0, ndw = 0;
+  if (rgbnm_gelu_table_query(&img, &A0, &P1, &N1, &ndw) != 1 || ndw * 4 > TAB_LIMIT) return 1;
+  ChainArgs p;
+  p.blk = (const ChainBlk*)blk_table_dev; p.x0 = (const bf16*)x0; p.depth = depth; p.nimg = c->B;
+  p.eps = c->ln_eps; p.scale = c->attn_scale;
+  p.tab_img = img; p.tab_pieces = (ndw * 4 + 15) / 16;
+  p.kneg = 0x00010001u * (unsigned)(0x8000 | N1);
+  p.kpos = 0x00010001u * (unsigned)P1;
+  p.klo = 0x00010001u * (unsigned)(A0 - 1);
+  p.koff = 0x00010001u * (unsigned)((0x10000 - 4 * (A0 - 1)) & 0xffff);
+  p.ksgn = 0x00010001u * (unsigned)(4 * (P1 - A0 + 2));
+  static DevOnce attr;
+  if (attr.need()) {
+    if (hipFuncSetAttribute((const void*)vit_chain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr.done();
+  }
+  hipLaunchKernelGGL(vit_chain_fwd_kernel, dim3(c->B), dim3(NTHREADS), SMEM, (hipStream_t)stream, p);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // extern "C"

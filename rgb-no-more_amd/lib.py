@@ -56,6 +56,13 @@ class HeadGrads(C.Structure):
     _fields_ = [(n, _vp) for n in ("dln_g", "dln_b", "dw1", "db1", "dw2", "db2")]
 
 
+class ChainBlock(C.Structure):
+    _fields_ = [(n, _vp) for n in ("wimg", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "bqkv_perm", "bproj", "b1", "b2", "xn1", "mean1",
+                                   "rstd1", "qkv", "lse", "attn", "x_mid", "xn2", "mean2", "rstd2", "u", "gl", "x_out")]
+
+
+ABI_VERSION = 2      # include/rgbnm.h RGBNM_ABI_VERSION this binding was written against
+
 _P = C.POINTER
 # name -> (restype, argtypes); every symbol include/rgbnm.h declares
 PROTOTYPES = {
@@ -116,6 +123,10 @@ PROTOTYPES = {
     "rgbnm_calib_vmem_issue": (_i, [_i, _i, _i, _vp, _sz, _i, _vp, _vp]),
     "rgbnm_calib_l2": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _vp]),
     "rgbnm_calib_pipes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "rgbnm_chain_block_bytes": (_sz, []),
+    "rgbnm_chain_image_elems": (_ll, []),
+    "rgbnm_chain_gather": (_i, [_vp, _vp, _vp, _ll, _vp]),
+    "rgbnm_vit_chain_fwd": (_i, [_P(VitCfg), _vp, _i, _vp, _vp]),
     "rgbnm_vit_block_fwd_chain": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _i, _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
                                  _vp, _vp]),
@@ -145,6 +156,11 @@ def lib():
             fn = getattr(L, name)       # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.rgbnm_abi_version() != ABI_VERSION:
+            raise RgbnmError(f"{LIB_PATH} has ABI version {L.rgbnm_abi_version()}, this binding expects {ABI_VERSION}: rebuild "
+                             "(python rgb-no-more_amd/build.py)")
+        if L.rgbnm_chain_block_bytes() != C.sizeof(ChainBlock):
+            raise RgbnmError("rgbnm_chain_block layout mismatch between librgbnm.so and lib.py")
         _lib = L
     return _lib
 

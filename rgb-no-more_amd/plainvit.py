@@ -12,6 +12,7 @@
 There is no fallback path: without librgbnm.so / a HIP device `forward` raises.
 """
 import ctypes as C
+import numpy as np
 import math
 import threading
 import warnings
@@ -173,6 +174,7 @@ class _Arena:
                                           self.dattn.data_ptr(), self.dqkv.data_ptr(), self.ws.data_ptr(), ws_bytes)
         self.ws_bytes = ws_bytes
         self.ws_blk = self.ws_head = self.hold_table = self.hold_table_host = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
+        self.chain_table = None      # device array of rgbnm_chain_block, built by the first one-launch forward (ViT._chain_forward)
         self.acts = []
         for i in range(D):
             b = self.blk[i if need_grad else 0]
@@ -465,6 +467,13 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, st, idx, *params):
         m, a = st.model, st.arena
         assert x.data_ptr() == a.xbuf(idx).data_ptr()
+        # the whole encoder forward as ONE launch (rgbnm.h rgbnm_vit_chain_fwd): block 0's node runs it, the nodes of the other
+        # blocks only hand their output buffer on -- the autograd graph (one backward node per block) stays what it was
+        if idx == 0:
+            st.chain_fwd = m._chain_forward(a)
+        if st.chain_fwd:
+            ctx.st, ctx.idx = st, idx
+            return a.xbuf(idx + 1).detach()
         # consecutive blocks are chained: fc2 of block i also emits LN1 of block i+1 (rgbnm.h, rgbnm_vit_block_fwd_chain)
         chain = st.ln_chain
         last = idx + 1 >= m.depth
@@ -674,6 +683,16 @@ class ViT(FlatParamModule):
             self._sep_cache = {}
         else:
             self._conv16 = self.patchembed.conv_Y.to(dev).contiguous()
+        # one-launch encoder forward (chain.py): constant gather table for the per-step chain image
+        self._chain_idx = None
+        if self.emb_size == 192 and self.num_heads == 3 and self.n_tokens == 196:
+            from . import chain as _chain
+            idx = np.concatenate([_chain.block_index(self._sh_off[f"qkv{i}"][0], self._sh_off[f"proj{i}"][0],
+                                                     self._sh_off[f"fc1{i}"][0], self._sh_off[f"fc2{i}"][0])
+                                  for i in range(self.depth)])
+            assert idx.max() < 2 ** 31 and _chain.BLOCK_ELEMS == L.lib().rgbnm_chain_image_elems()
+            self._chain_idx = torch.from_numpy(idx.astype(np.int32)).to(dev)
+            self._chain_img = torch.zeros(idx.size, device=dev, dtype=torch.bfloat16)
         self._pos = sincos_table(14, 14, self.emb_size, dev)
         self._pos7 = sincos_table(7, 7, self.emb_size, dev) if self.embed_kind == "concat" else None
         self._zc = {}
@@ -746,6 +765,9 @@ class ViT(FlatParamModule):
         L.check(L.lib().rgbnm_prep_weights(L.dt_of(cdtype), self._descs_dev.data_ptr(), self._ndesc,
                                            self._flat.data_ptr(), self._shadow[cdtype].data_ptr(),
                                            self._bias_perm.data_ptr(), L.stream()), "prep_weights")
+        if cdtype == torch.bfloat16 and self._chain_idx is not None and L.lib().rgbnm_get_option(b"fwd_chain"):
+            L.check(L.lib().rgbnm_chain_gather(self._shadow[cdtype].data_ptr(), self._chain_idx.data_ptr(),
+                                               self._chain_img.data_ptr(), self._chain_idx.numel(), L.stream()), "chain_gather")
         if cdtype not in self._bparams_by_dtype:
             bps = []
             for i in range(self.depth):
@@ -771,6 +793,26 @@ class ViT(FlatParamModule):
         self._bparams, self._hparams = self._bparams_by_dtype[cdtype]
         if self._ncls_pad != self.n_classes:
             self._b2pad[:self.n_classes].copy_(self._named["classhead.ch_linear2.bias"].detach())
+
+    def _chain_forward(self, a):
+        """Run all encoder blocks as one launch into arena `a` (rgbnm_vit_chain_fwd); False = not eligible (per-block path)."""
+        if a.cdtype != torch.bfloat16 or self._chain_idx is None or not L.lib().rgbnm_get_option(b"fwd_chain"):
+            return False
+        if a.chain_table is None:
+            from . import chain as _chain
+            blocks = (L.ChainBlock * self.depth)()
+            for i in range(self.depth):
+                bp, ac = self._bparams[i], a.acts[i]
+                blocks[i] = L.ChainBlock(self._chain_img.data_ptr() + i * _chain.BLOCK_ELEMS * 2,
+                                         bp.ln1_g, bp.ln1_b, bp.ln2_g, bp.ln2_b, bp.bqkv_perm, bp.bproj, bp.b1, bp.b2,
+                                         ac.xn1, ac.mean1, ac.rstd1, ac.qkv, ac.lse, ac.attn, ac.x_mid, ac.xn2, ac.mean2, ac.rstd2,
+                                         ac.u, ac.gl, ac.x_out)
+            a.chain_table = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(self._flat.device)
+        rc = L.lib().rgbnm_vit_chain_fwd(C.byref(a.cfg), a.chain_table.data_ptr(), self.depth, a.xbuf(0).data_ptr(), L.stream())
+        if rc == 1:
+            return False
+        L.check(rc, "vit_chain_fwd")
+        return True
 
     # ---------------------------------------------------------------- arenas
     def _acquire_arena(self, B, cdtype, need_grad):
