@@ -14,7 +14,7 @@
 // whole forward, in consumption order, from a per-step "chain image" (written by rgbnm_chain_gather: rows and swizzles exactly
 // as they lie in LDS, so every transfer is a linear 1 KB LDS-DMA) into three 24 KB slots (attention part: q, k, v and output
 // projection chunks of one head each) / two 48 KB stages (MLP part: hidden chunks of 64, as mlp_fused.hip).  One workgroup
-// barrier per step, 28 steps per block; the DMA wave runs a static schedule two short steps (one long step) ahead.
+// barrier per step, 29 per block; the DMA wave runs a static schedule two short steps (one long step) ahead.
 //
 // Register convention ("D layout"): every [tokens, features] activation is held as the accumulator of a swapped MFMA
 // (D rows = features, D cols = tokens): lane (l31, g) owns token 32 w + l31 and, of every 16 features, the 8 with bit 3 == g.
@@ -55,19 +55,20 @@ constexpr int STG_TILE = 32 * ROWB;               // 4096
 constexpr int MISC_OFF = STGA_OFF + NCW * STG_TILE;   // 159744: LN2 gamma, beta, projection bias (fp32)
 constexpr int LN1P_OFF = K_OFF + NTOK * ROWB;     // 98816: LN1 gamma | beta (fp32), inside the K pad rows
 // ---- LDS, MLP part
-constexpr int TAB_LIMIT = 12816;                  // the GELU table image must end here ...
-constexpr int B1R_OFF = TAB_LIMIT;                // ... the fc1-bias ring (2 x 64 floats) follows
+constexpr int TAB_LIMIT = 13328;                  // the GELU table image (mlp_fused.hip F_TAB_BYTES) at offset 0
 constexpr int ST1_OFF = 13440;                    // odd hidden chunks: W1 chunk | W2 chunk (128-byte aligned)
 constexpr int STAGE = 2 * SLOT;
 constexpr int TA_OFF = ST1_OFF + STAGE;           // 62592: gelu tiles of wave 5, then wave 6's
+constexpr int B1R_OFF = TA_OFF + 2 * STG_TILE + 2 * 4 * ROWB;   // 71808: fc1-bias ring, 2 x 64 floats (inside slot 2 of the attention part:
+                                                                //        the first piece is fetched after the last projection step)
 constexpr int ST0_OFF = K_OFF;                    // even hidden chunks (over K, V: dead by then)
 constexpr int TB_OFF = ST0_OFF + STAGE;           // 122880: gelu | gelu' tiles of waves 0..4
 constexpr int SMEM = 163840;
 static_assert(MISC_OFF + 3 * E * 4 <= SMEM, "LDS");
 static_assert(TB_OFF + 10 * STG_TILE <= SMEM, "LDS");
-static_assert(TA_OFF + 2 * STG_TILE + 2 * 4 * ROWB <= ST0_OFF, "LDS");
+static_assert(B1R_OFF + 512 <= ST0_OFF, "LDS");
 static_assert(LN1P_OFF + 2 * E * 4 <= V_OFF, "LDS");
-static_assert(B1R_OFF + 512 <= ST1_OFF && ST1_OFF % 128 == 0 && TA_OFF % 128 == 0, "LDS");
+static_assert(TAB_LIMIT <= ST1_OFF && ST1_OFF % 128 == 0 && TA_OFF % 128 == 0, "LDS");
 
 struct ChainBlk {            // = rgbnm_chain_block (rgbnm.h) with typed pointers
   const bf16* wimg;          // 12 attention chunks (q0 k0 v0 q1 k1 v1 q2 k2 v2 p0 p1 p2) | 12 x (W1 chunk | W2 chunk)
@@ -324,9 +325,10 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         for (int i = 0; i * 64 < p.tab_pieces; ++i)
           if (i * 64 + lane < p.tab_pieces)
             __builtin_amdgcn_global_load_lds((glb_ptr)(p.tab_img + (i * 64 + lane) * 4), (lds_ptr)(smem + i * 1024), 16, 0, 0);
-        bias1(b, 0);
       }
-      wait_vm<49>(); wg_barrier();                       // 14: p2 (at least the 48 + 1 pieces of chunk 0 are younger)
+      wait_vm<48>(); wg_barrier();                       // 14: p2 (at least the 48 pieces of chunk 0 are younger)
+      wg_barrier();                                      // 14b: the projection MFMAs are done: slot 2 is free
+      bias1(b, 0);
       wait_vm<0>(); wg_barrier();                        // 15: hidden chunk 0, table, bias
       for (int c = 0; c < 11; ++c) {
         chunkM(b, c + 1);
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         for (int bt = 0; bt < 6; ++bt) mma(accp[bt], fw[bt], of[h][s]);
       }
     }
+    wg_barrier();                                                 // step 14b: the chunk slots are free (fc1-bias ring lives there)
     float mu2, rs2;
     {
 #pragma unroll

@@ -3,6 +3,9 @@ import sys
 import time
 import numpy as np
 import torch
+import os
+import sys as _s
+_s.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rgb_no_more_amd as rg
 from rgb_no_more_amd import detfill, lib as L
 
