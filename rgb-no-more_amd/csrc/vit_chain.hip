@@ -52,7 +52,9 @@ constexpr int ARR = NPAD * ROWB;                  // 28672
 constexpr int V_OFF = K_OFF + ARR;                // 102400
 constexpr int STGA_OFF = V_OFF + ARR;             // 131072: private 32 x 128 B tiles of the compute waves
 constexpr int STG_TILE = 32 * ROWB;               // 4096
-constexpr int MISC_OFF = STGA_OFF + NCW * STG_TILE;   // 159744: LN2 gamma, beta, projection bias (fp32)
+// the seventh wave's tile needs 4 rows: the parameter vectors start behind them (fp32): LN2 gamma | beta | projection bias | qkv bias
+constexpr int MISC_OFF = STGA_OFF + 6 * STG_TILE + 4 * ROWB;      // 156160
+constexpr int BPROJ_OFF = MISC_OFF + 2 * E * 4, BQKV_OFF = BPROJ_OFF + E * 4;
 constexpr int LN1P_OFF = K_OFF + NTOK * ROWB;     // 98816: LN1 gamma | beta (fp32), inside the K pad rows
 // ---- LDS, MLP part
 constexpr int TAB_LIMIT = 13328;                  // the GELU table image (mlp_fused.hip F_TAB_BYTES) at offset 0
@@ -61,12 +63,13 @@ constexpr int STAGE = 2 * SLOT;
 constexpr int TA_OFF = ST1_OFF + STAGE;           // 62592: gelu tiles of wave 5, then wave 6's
 constexpr int B1R_OFF = TA_OFF + 2 * STG_TILE + 2 * 4 * ROWB;   // 71808: fc1-bias ring, 2 x 64 floats (inside slot 2 of the attention part:
                                                                 //        the first piece is fetched after the last projection step)
+constexpr int B2_OFF = B1R_OFF + 512;             // 72320: fc2 bias (fetched with the first fc1-bias piece)
 constexpr int ST0_OFF = K_OFF;                    // even hidden chunks (over K, V: dead by then)
 constexpr int TB_OFF = ST0_OFF + STAGE;           // 122880: gelu | gelu' tiles of waves 0..4
 constexpr int SMEM = 163840;
-static_assert(MISC_OFF + 3 * E * 4 <= SMEM, "LDS");
+static_assert(BQKV_OFF + 3 * INNER * 4 <= SMEM, "LDS");
 static_assert(TB_OFF + 10 * STG_TILE <= SMEM, "LDS");
-static_assert(B1R_OFF + 512 <= ST0_OFF, "LDS");
+static_assert(B2_OFF + E * 4 <= ST0_OFF, "LDS");
 static_assert(LN1P_OFF + 2 * E * 4 <= V_OFF, "LDS");
 static_assert(TAB_LIMIT <= ST1_OFF && ST1_OFF % 128 == 0 && TA_OFF % 128 == 0, "LDS");
 
@@ -179,17 +182,29 @@ __device__ __forceinline__ void dma_f32x192(const float* src, unsigned char* dst
     __builtin_amdgcn_global_load_lds((glb_ptr)(src + 64 * i + lane), (lds_ptr)(dst + 256 * i), 4, 0, 0);
 }
 
-// ---- D-layout rows: 12 pieces (index c = 2 b + hs) of 8 bf16 = features 16 c + 8 g + (0..7) of the lane's token
-struct Rows { bf16x8 v[12]; };
+// ---- D-layout rows: 12 pieces (index c = 2 b + hs) of 8 bf16 = features 16 c + 8 g + (0..7) of the lane's token, held as PACKED
+// dwords (element j of a piece = half j & 1 of dword j >> 1): as bf16 vectors built element by element the compiler kept the
+// 96 values of a row set in 96 registers and spilled them
+struct Rows { u32x4 v[12]; };
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack2(float a, float b) {       // two fp32 -> bf16 pair (round to nearest even), a in the low half
+  const bf16x2v v = {(bf16)a, (bf16)b};
+  unsigned r = __builtin_bit_cast(unsigned, v);
+  asm volatile("" : "+v"(r));     // packed HERE: the optimiser otherwise sinks the conversion to the (conditional) use and keeps the fp32 pair
+  return r;
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 __device__ __forceinline__ void ln_stats(const Rows& x, float& mu, float& rs, float eps) {
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int c = 0; c < 12; ++c)
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      s0 += (float)x.v[c][j];
-      s1 += (float)x.v[c][j + 1];
+    for (int d = 0; d < 4; ++d) {
+      const unsigned u = opaque(x.v[c][d]);
+      s0 += bf_lo(u);
+      s1 += bf_hi(u);
     }
   float s = s0 + s1;
   s += __shfl_xor(s, 32, 64);
@@ -198,8 +213,9 @@ __device__ __forceinline__ void ln_stats(const Rows& x, float& mu, float& rs, fl
 #pragma unroll
   for (int c = 0; c < 12; ++c)
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const float d0 = (float)x.v[c][j] - mu, d1 = (float)x.v[c][j + 1] - mu;
+    for (int d = 0; d < 4; ++d) {
+      const unsigned u = opaque(x.v[c][d]);
+      const float d0 = bf_lo(u) - mu, d1 = bf_hi(u) - mu;
       q0 = __builtin_fmaf(d0, d0, q0);
       q1 = __builtin_fmaf(d1, d1, q1);
     }
@@ -215,9 +231,13 @@ __device__ __forceinline__ void ln_apply(const Rows& x, float mu, float rs, cons
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(gp + E), b1 = *reinterpret_cast<const f32x4*>(gp + E + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float gm = j < 4 ? g0[j & 3] : g1[j & 3], bt = j < 4 ? b0[j & 3] : b1[j & 3];
-      y.v[c][j] = (bf16)__builtin_fmaf(((float)x.v[c][j] - mu) * rs, gm, bt);
+    for (int d = 0; d < 4; ++d) {
+      const float gm0 = d < 2 ? g0[2 * d] : g1[2 * d - 4], gm1 = d < 2 ? g0[2 * d + 1] : g1[2 * d - 3];
+      const float bt0 = d < 2 ? b0[2 * d] : b1[2 * d - 4], bt1 = d < 2 ? b0[2 * d + 1] : b1[2 * d - 3];
+      // (the packed dword is read through an opaque copy: otherwise the unpacked fp32 values of the residual stream are computed
+      // once per block, shared by every use -- three LN1 recomputations and the residual add -- and held / spilled in between)
+      const unsigned u = opaque(x.v[c][d]);
+      y.v[c][d] = pack2(__builtin_fmaf((bf_lo(u) - mu) * rs, gm0, bt0), __builtin_fmaf((bf_hi(u) - mu) * rs, gm1, bt1));
     }
     if (c & 1) __builtin_amdgcn_sched_barrier(0);     // (else all 48 parameter reads are issued up front: 192 registers)
   }
@@ -225,15 +245,17 @@ __device__ __forceinline__ void ln_apply(const Rows& x, float mu, float rs, cons
 
 // One 64-feature third (pieces c0 .. c0 + 3) of the wave's 32 rows -> private tile -> whole 128-byte row pieces -> global
 // (row r of the wave at dst + r * ld).  The tile is swizzled by 16-byte chunk: chunk q of row r at q ^ (r & 7).
-__device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, const bf16x8& p0, const bf16x8& p1, const bf16x8& p2,
-                                         const bf16x8& p3, bf16* dst, int ld, int live) {
+__device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, const u32x4& p0, const u32x4& p1, const u32x4& p2,
+                                         const u32x4& p3, bf16* dst, int ld, int live) {
   const int ln = lane_id_here();
   // own row ln & 31, chunk 2 q + g at (2 q + g) ^ (row & 7): one base offset, q selected by XOR (the tile is 128-byte aligned)
   const unsigned wo = stg + (unsigned)((ln & 31) * ROWB + (((ln >> 5) ^ (ln & 7)) << 4));
-  *reinterpret_cast<bf16x8*>(smem + wo) = p0;
-  *reinterpret_cast<bf16x8*>(smem + (wo ^ 32u)) = p1;
-  *reinterpret_cast<bf16x8*>(smem + (wo ^ 64u)) = p2;
-  *reinterpret_cast<bf16x8*>(smem + (wo ^ 96u)) = p3;
+  if ((ln & 31) < live) {       // (the seventh wave's tile has 4 rows; the parameter vectors lie behind them)
+    *reinterpret_cast<u32x4*>(smem + wo) = p0;
+    *reinterpret_cast<u32x4*>(smem + (wo ^ 32u)) = p1;
+    *reinterpret_cast<u32x4*>(smem + (wo ^ 64u)) = p2;
+    *reinterpret_cast<u32x4*>(smem + (wo ^ 96u)) = p3;
+  }
   wait_lds();
   const int rl = ln >> 3, seg = ln & 7;
   const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));      // row i * 8 + rl: (row & 7) == rl
@@ -247,7 +269,10 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
 }
 __device__ __forceinline__ void rows_out(unsigned char* smem, unsigned stg, const Rows& x, bf16* dst, int live) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) tile_out(smem, stg, x.v[4 * t], x.v[4 * t + 1], x.v[4 * t + 2], x.v[4 * t + 3], dst + 64 * t, E, live);
+  for (int t = 0; t < 3; ++t) {
+    tile_out(smem, stg, x.v[4 * t], x.v[4 * t + 1], x.v[4 * t + 2], x.v[4 * t + 3], dst + 64 * t, E, live);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // acc (32 output features x 32 tokens, swapped) += W chunk rows [32 ht .. +31] . x : 12 k-steps; chunk rows are 384 B, 16-byte
@@ -259,10 +284,35 @@ __device__ __forceinline__ void gemm_k192(f32x16& acc, const unsigned char* sW, 
   for (int c = 0; c < 12; ++c) {
     Frag<bf16> fb, fx;
     fb.v = *reinterpret_cast<const bf16x8*>(sW + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
-    fx.v = x.v[c];
+    fx.v = as_bf16x8(x.v[c]);
     mma(acc, fb, fx);
   }
 }
+
+#ifdef CHAIN_PROF
+// experiments only (RGBNM_HIPCC_FLAGS=-DCHAIN_PROF): cycle stamps of block CHAIN_PROF_BLK of the first 8 workgroups, slot 2 s = in
+// front of the barrier of step s, 2 s + 1 = behind it, [126] / [127] = s_memrealtime at kernel start / end; tools/chain_prof.py
+#ifndef CHAIN_PROF_BLK
+#define CHAIN_PROF_BLK 1
+#endif
+__device__ unsigned long long g_chain_prof[8 * 8 * 128];
+#define CP(i)                                                                                          \
+  do {                                                                                                 \
+    if (ib == CHAIN_PROF_BLK && blockIdx.x < 8) {                                                      \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                      \
+      if ((threadIdx.x & 63) == 0) g_chain_prof[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 128 + (i)] = t_; \
+    }                                                                                                  \
+  } while (0)
+#define CP_RT(i)                                                                                       \
+  do {                                                                                                 \
+    if (blockIdx.x < 8 && (threadIdx.x & 63) == 0)                                                     \
+      g_chain_prof[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 128 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CP(i) do {} while (0)
+#define CP_RT(i) do {} while (0)
+#endif
+#define BAR(s) do { CP(2 * (s)); wg_barrier(); CP(2 * (s) + 1); } while (0)
 
 __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -271,6 +321,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
   const Geo L = make_geo();
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int depth = p.depth;
+  CP_RT(126);
 
   if (w == NCW) {
     // ================================================================ DMA wave: the static weight schedule
@@ -292,7 +343,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
     auto misc = [&](const ChainBlk& b) {
       dma_f32x192(b.ln2_g, smem + MISC_OFF, lane);
       dma_f32x192(b.ln2_b, smem + MISC_OFF + E * 4, lane);
-      dma_f32x192(b.bproj, smem + MISC_OFF + 2 * E * 4, lane);
+      dma_f32x192(b.bproj, smem + BPROJ_OFF, lane);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dma_f32x192(b.bqkv + i * INNER, smem + BQKV_OFF + i * INNER * 4, lane);
     };
     {
       const ChainBlk& b0 = p.blk[0];
@@ -307,36 +360,37 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
     }
     for (int ib = 0; ib < depth; ++ib) {
       const ChainBlk& b = p.blk[ib];
-      wait_vm<48>(); wg_barrier();                       // 0: q0
-      wait_vm<24>(); wg_barrier();                       // 1: k0
-      chunkA(b, 3, 0); wait_vm<24>(); wg_barrier();      // 2: v0
-      chunkA(b, 4, 1); wg_barrier();                     // 3: attention 0
-      chunkA(b, 5, 2); wait_vm<48>(); wg_barrier();      // 4: q1
-      wait_vm<24>(); wg_barrier();                       // 5: k1
-      chunkA(b, 6, 0); wait_vm<24>(); wg_barrier();      // 6: v1
-      chunkA(b, 7, 1); wg_barrier();                     // 7: attention 1
-      chunkA(b, 8, 2); wait_vm<48>(); wg_barrier();      // 8: q2
-      wait_vm<24>(); wg_barrier();                       // 9: k2
-      chunkA(b, 9, 0); wait_vm<24>(); wg_barrier();      // 10: v2
-      chunkA(b, 10, 1); wg_barrier();                    // 11: attention 2
-      chunkA(b, 11, 2); wait_vm<48>(); wg_barrier();     // 12: p0
-      chunkM(b, 0); wait_vm<63>(); wg_barrier();         // 13: p1 (older than p2 and the 48 pieces behind it)
+      wait_vm<48>(); BAR(0);                             // 0: q0
+      wait_vm<24>(); BAR(1);                             // 1: k0
+      chunkA(b, 3, 0); wait_vm<24>(); BAR(2);            // 2: v0
+      chunkA(b, 4, 1); BAR(3);                           // 3: attention 0
+      chunkA(b, 5, 2); wait_vm<48>(); BAR(4);            // 4: q1
+      wait_vm<24>(); BAR(5);                             // 5: k1
+      chunkA(b, 6, 0); wait_vm<24>(); BAR(6);            // 6: v1
+      chunkA(b, 7, 1); BAR(7);                           // 7: attention 1
+      chunkA(b, 8, 2); wait_vm<48>(); BAR(8);            // 8: q2
+      wait_vm<24>(); BAR(9);                             // 9: k2
+      chunkA(b, 9, 0); wait_vm<24>(); BAR(10);           // 10: v2
+      chunkA(b, 10, 1); BAR(11);                         // 11: attention 2
+      chunkA(b, 11, 2); wait_vm<48>(); BAR(12);          // 12: p0
+      chunkM(b, 0); wait_vm<63>(); BAR(13);              // 13: p1 (older than p2 and the 48 pieces behind it)
       {                                                                   // GELU table image + first fc1-bias piece
         for (int i = 0; i * 64 < p.tab_pieces; ++i)
           if (i * 64 + lane < p.tab_pieces)
             __builtin_amdgcn_global_load_lds((glb_ptr)(p.tab_img + (i * 64 + lane) * 4), (lds_ptr)(smem + i * 1024), 16, 0, 0);
       }
-      wait_vm<48>(); wg_barrier();                       // 14: p2 (at least the 48 pieces of chunk 0 are younger)
-      wg_barrier();                                      // 14b: the projection MFMAs are done: slot 2 is free
+      wait_vm<48>(); BAR(14);                            // 14: p2 (at least the 48 pieces of chunk 0 are younger)
+      BAR(15);                                           // 14b: the projection MFMAs are done: slot 2 is free
       bias1(b, 0);
-      wait_vm<0>(); wg_barrier();                        // 15: hidden chunk 0, table, bias
+      dma_f32x192(b.b2, smem + B2_OFF, lane);
+      wait_vm<0>(); BAR(16);                             // 15: hidden chunk 0, table, bias
       for (int c = 0; c < 11; ++c) {
         chunkM(b, c + 1);
         bias1(b, c + 1);
-        wait_vm<0>(); wg_barrier();                      // 16 + c
+        wait_vm<0>(); BAR(17 + c);                       // 16 + c
       }
       if (ib + 1 < depth) ln1p(p.blk[ib + 1]);                           // stage 0 (over the K pad rows) is dead since barrier 26
-      wait_vm<0>(); wg_barrier();                        // 27: every wave has left the last hidden chunk
+      wait_vm<0>(); BAR(28);                             // 27: every wave has left the last hidden chunk
       if (ib + 1 < depth) {
         const ChainBlk& nb = p.blk[ib + 1];
         misc(nb);
@@ -357,13 +411,13 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
   const float c2 = p.scale * 1.4426950408889634f;
   const float* ln1p = reinterpret_cast<const float*>(smem + LN1P_OFF);
   const float* ln2p = reinterpret_cast<const float*>(smem + MISC_OFF);
-  const float* bprj = reinterpret_cast<const float*>(smem + MISC_OFF + 2 * E * 4);
+  const float* bprj = reinterpret_cast<const float*>(smem + BPROJ_OFF);
 
   Rows xr;                                                        // the residual stream of this lane's token
   {
     const bf16* xrow = p.x0 + ((size_t)img * NTOK + tok) * E + 8 * L.g;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) xr.v[c] = *reinterpret_cast<const bf16x8*>(xrow + 16 * c);
+    for (int c = 0; c < 12; ++c) xr.v[c] = *reinterpret_cast<const u32x4*>(xrow + 16 * c);
   }
   float mu1, rs1;
   ln_stats(xr, mu1, rs1, p.eps);
@@ -386,21 +440,15 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) {
       Rows xn;
+      __builtin_amdgcn_sched_barrier(0);
       ln_apply(xr, mu1, rs1, ln1p, L.g, xn);                      // LN1 output, recomputed per head (48 registers not held)
+      __builtin_amdgcn_sched_barrier(0);
       Frag<bf16> qf[4];
       // ---------------- q, k, v of head h: three steps of 24 MFMAs
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        const float* bias = b.bqkv + m * INNER + h * HD + 8 * L.g;
-        f32x4 bv[2][2][2];
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-          for (int hs = 0; hs < 2; ++hs) {
-            bv[ht][hs][0] = *reinterpret_cast<const f32x4*>(bias + 32 * ht + 16 * hs);
-            bv[ht][hs][1] = *reinterpret_cast<const f32x4*>(bias + 32 * ht + 16 * hs + 4);
-          }
-        wg_barrier();                             // step 4 h + m: the chunk has landed
+        const float* bias = reinterpret_cast<const float*>(smem + BQKV_OFF) + m * INNER + h * HD + 8 * L.g;
+        BAR(4 * h + m);                           // step 4 h + m: the chunk has landed
         const unsigned char* sW = smem + A_SLOT0 + m * SLOT;
         f32x16 acc[2];
 #pragma unroll
@@ -409,36 +457,44 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
           for (int r = 0; r < 16; ++r) acc[ht][r] = 0.f;
           gemm_k192(acc[ht], sW, ht, xn, L);
         }
-        bf16x8 pc[4];
+        u32x4 pc[4];
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-          for (int hs = 0; hs < 2; ++hs)
+          for (int hs = 0; hs < 2; ++hs) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 32 * ht + 16 * hs);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 32 * ht + 16 * hs + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              pc[2 * ht + hs][j] = (bf16)(acc[ht][8 * hs + j] + (j < 4 ? bv[ht][hs][0][j & 3] : bv[ht][hs][1][j & 3]));
+            for (int d = 0; d < 4; ++d)
+              pc[2 * ht + hs][d] = pack2(acc[ht][8 * hs + 2 * d] + (d < 2 ? b0[2 * d] : b1[2 * d - 4]),
+                                         acc[ht][8 * hs + 2 * d + 1] + (d < 2 ? b0[2 * d + 1] : b1[2 * d - 3]));
+          }
         if (m == 0) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) qf[c].v = pc[c];
+          for (int c = 0; c < 4; ++c) qf[c].v = as_bf16x8(pc[c]);
         } else {
           // K / V array row of this lane's token: 16-byte chunk q at q ^ fswz(row).  The seventh wave leaves the K pad rows
           // alone (LN1 parameters) and fills the V pad rows with its clamped (finite) rows.
           const unsigned ao = opaque((unsigned)((m == 1 ? K_OFF : V_OFF) + (row0 + L.l31) * ROWB + ((L.g ^ L.fl) << 4)));
           if (m == 2 || L.l31 < live) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) *reinterpret_cast<bf16x8*>(smem + (ao ^ (unsigned)(c << 5))) = pc[c];
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(smem + (ao ^ (unsigned)(c << 5))) = pc[c];
           }
         }
         tile_out(smem, stg, pc[0], pc[1], pc[2], pc[3], b.qkv + grow0 * (3 * INNER) + m * INNER + h * HD, 3 * INNER, live);
       }
       // ---------------- attention of head h (the forward of attention_v2.hip: scores recomputed in the second pass)
-      wg_barrier();                               // step 4 h + 3: every K, V row is written
+      BAR(4 * h + 3);                             // step 4 h + 3: every K, V row is written
       {
         const unsigned char* Ks = smem + K_OFF;
         unsigned rb = (unsigned)(L.l31 * ROWB + ((L.g ^ L.fl) << 4)), tr = L.tr0;
         asm volatile("" : "+v"(rb), "+v"(tr));
         float mx = -INFINITY;
+#ifdef X_NOATTN
+        TileLoop<0>::run([&](auto tc) {
+#else
         TileLoop<NTILE>::run([&](auto tc) {
+#endif
           constexpr int t = decltype(tc)::value;
           f32x16 acc;
 #pragma unroll
@@ -465,7 +521,11 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
         const unsigned vt = (unsigned)V_OFF + tr;
+#ifdef X_NOATTN
+        TileLoop<0>::run([&](auto tc) {
+#else
         TileLoop<NTILE>::run([&](auto tc) {
+#endif
           constexpr int t = decltype(tc)::value;
           f32x16 acc;
 #pragma unroll
@@ -497,25 +557,27 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         if (L.g == 0 && L.l31 < live) b.lse[((size_t)img * HEADS + h) * NTOK + row0 + L.l31] = mx * p.scale + __logf(sum);
         // o: register r of tile dt = head dim 32 dt + 8 (r >> 2) + 4 g + (r & 3).  As projection operand (k order permuted in the
         // chain image): registers 8 hs .. 8 hs + 7.  As memory rows: 8-byte pieces through the private tile.
+        u32x4 op[4];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-          for (int hs = 0; hs < 2; ++hs)
+          for (int hs = 0; hs < 2; ++hs) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) of[h][2 * dt + hs].v[j] = (bf16)(o[dt][8 * hs + j] * inv);
+            for (int d = 0; d < 4; ++d) op[2 * dt + hs][d] = pack2(o[dt][8 * hs + 2 * d] * inv, o[dt][8 * hs + 2 * d + 1] * inv);
+            of[h][2 * dt + hs].v = as_bf16x8(op[2 * dt + hs]);
+          }
         {
           const int ln = lane_id_here();
           // 8-byte pieces: head dims 8 q + 4 g + (0..3) of the own row, chunk q at q ^ (row & 7)
           const unsigned wo = stg + (unsigned)((ln & 31) * ROWB + ((ln & 7) << 4) + (ln >> 5) * 8);
+          if ((ln & 31) < live)
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-              const bf16x8 src = of[h][2 * dt + (rq >> 1)].v;
-              bf16x4 q4;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) q4[e] = src[4 * (rq & 1) + e];
-              *reinterpret_cast<bf16x4*>(smem + (wo ^ (unsigned)((dt * 4 + rq) << 4))) = q4;
+              const u32x4 src = op[2 * dt + (rq >> 1)];
+              const u32x2 q2 = {src[2 * (rq & 1)], src[2 * (rq & 1) + 1]};
+              *reinterpret_cast<u32x2*>(smem + (wo ^ (unsigned)((dt * 4 + rq) << 4))) = q2;
             }
           wait_lds();
           const int rl = ln >> 3, seg = ln & 7;
@@ -538,7 +600,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
       for (int r = 0; r < 16; ++r) accp[bt][r] = 0.f;
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) {
-      wg_barrier();                               // steps 12, 13, 14
+      BAR(12 + h);                                // steps 12, 13, 14
       // chunk image: [192 rows][128 B], chunk q at q ^ fswz(row)
       const unsigned wo = opaque((unsigned)(A_SLOT0 + h * SLOT + L.l31 * ROWB + ((L.g ^ L.fl) << 4)));
 #pragma unroll
@@ -551,7 +613,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         for (int bt = 0; bt < 6; ++bt) mma(accp[bt], fw[bt], of[h][s]);
       }
     }
-    wg_barrier();                                                 // step 14b: the chunk slots are free (fc1-bias ring lives there)
+    BAR(15);                                                      // step 14b: the chunk slots are free (fc1-bias ring lives there)
     float mu2, rs2;
     {
 #pragma unroll
@@ -559,27 +621,41 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         const float* bp = bprj + 16 * c + 8 * L.g;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          xr.v[c][j] = (bf16)(accp[c >> 1][8 * (c & 1) + j] + (j < 4 ? b0[j & 3] : b1[j & 3]) + (float)xr.v[c][j]);
+        for (int d = 0; d < 4; ++d) {
+          const unsigned u = opaque(xr.v[c][d]);
+          xr.v[c][d] = pack2(accp[c >> 1][8 * (c & 1) + 2 * d] + (d < 2 ? b0[2 * d] : b1[2 * d - 4]) + bf_lo(u),
+                             accp[c >> 1][8 * (c & 1) + 2 * d + 1] + (d < 2 ? b0[2 * d + 1] : b1[2 * d - 3]) + bf_hi(u));
+        }
         if (c & 1) __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       ln_stats(xr, mu2, rs2, p.eps);
+      __builtin_amdgcn_sched_barrier(0);
       rows_out(smem, stg, xr, b.x_mid + grow0 * E, live);
+      __builtin_amdgcn_sched_barrier(0);
       if (L.g == 0 && L.l31 < live) {
         b.mean2[grow0 + L.l31] = mu2;
         b.rstd2[grow0 + L.l31] = rs2;
       }
     }
     Rows fa;
+    __builtin_amdgcn_sched_barrier(0);
     ln_apply(xr, mu2, rs2, ln2p, L.g, fa);
+    __builtin_amdgcn_sched_barrier(0);
     rows_out(smem, stg, fa, b.xn2 + grow0 * E, live);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- MLP: 12 hidden chunks of 64 (mlp_fused.hip), accumulator initialised with the residual
     f32x16 acc2[6];
 #pragma unroll
     for (int c = 0; c < 12; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc2[c >> 1][8 * (c & 1) + j] = (float)xr.v[c][j];
+      for (int d = 0; d < 4; ++d) {
+        const unsigned u = opaque(xr.v[c][d]);
+        acc2[c >> 1][8 * (c & 1) + 2 * d] = bf_lo(u);
+        acc2[c >> 1][8 * (c & 1) + 2 * d + 1] = bf_hi(u);
+      }
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned tg = (unsigned)(w < 5 ? TB_OFF + 2 * w * STG_TILE
                                          : (w == 5 ? TA_OFF : TA_OFF + 2 * STG_TILE));       // gelu tile (LDS offset); gelu' follows
     const unsigned tpoff = (unsigned)(live * ROWB);                // (32 or 4 rows per tile)
@@ -589,12 +665,12 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
     asm volatile("" : "+v"(k4v));
     const int woff0 = L.l31 * (E * 2) + ((L.g ^ L.fl) << 4);
 #ifdef X_NOMLP
-    for (int chunk = 0; chunk < HID / 64; ++chunk) wg_barrier();
+    for (int chunk = 0; chunk < HID / 64; ++chunk) BAR(16 + chunk);
     for (int chunk = 0; chunk < 0; ++chunk) {
 #else
     for (int chunk = 0; chunk < HID / 64; ++chunk) {
 #endif
-      wg_barrier();                               // steps 15 .. 26
+      BAR(16 + chunk);                            // steps 15 .. 26
       const unsigned st_off = (unsigned)((chunk & 1) ? ST1_OFF : ST0_OFF);
       const unsigned char* sW1 = smem + st_off;
       const float* bch = reinterpret_cast<const float*>(smem + B1R_OFF) + (chunk & 1) * 64;
@@ -612,7 +688,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         for (int c = 0; c < 12; ++c) {
           Frag<bf16> fb, fx;
           fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
-          fx.v = fa.v[c];
+          fx.v = as_bf16x8(fa.v[c]);
           mma(a1, fb, fx);
         }
         Frag<bf16> pg[2];
@@ -697,31 +773,40 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         wait_lds();
       }
     }
-    wg_barrier();                                 // step 27: the MLP tiles and stages are dead
+    BAR(28);                                      // step 27: the MLP tiles and stages are dead
     // ---------------- x_out = x_mid + fc2(...) + b2 ; next block's LN1
     {
-      const float* b2p = b.b2 + 8 * L.g;
+      const float* b2p = reinterpret_cast<const float*>(smem + B2_OFF) + 8 * L.g;
 #pragma unroll
       for (int c = 0; c < 12; ++c) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(b2p + 16 * c), b1 = *reinterpret_cast<const f32x4*>(b2p + 16 * c + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xr.v[c][j] = (bf16)(acc2[c >> 1][8 * (c & 1) + j] + (j < 4 ? b0[j & 3] : b1[j & 3]));
+        for (int d = 0; d < 4; ++d)
+          xr.v[c][d] = pack2(acc2[c >> 1][8 * (c & 1) + 2 * d] + (d < 2 ? b0[2 * d] : b1[2 * d - 4]),
+                             acc2[c >> 1][8 * (c & 1) + 2 * d + 1] + (d < 2 ? b0[2 * d + 1] : b1[2 * d - 3]));
         if (c & 1) __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       rows_out(smem, stg, xr, b.x_out + grow0 * E, live);
+      __builtin_amdgcn_sched_barrier(0);
       if (ib + 1 < depth) {
         const ChainBlk& nb = p.blk[ib + 1];
         ln_stats(xr, mu1, rs1, p.eps);
+        __builtin_amdgcn_sched_barrier(0);
         Rows xn;
         ln_apply(xr, mu1, rs1, ln1p, L.g, xn);
+        __builtin_amdgcn_sched_barrier(0);
         rows_out(smem, stg, xn, nb.xn1 + grow0 * E, live);
+        __builtin_amdgcn_sched_barrier(0);
         if (L.g == 0 && L.l31 < live) {
           nb.mean1[grow0 + L.l31] = mu1;
           nb.rstd1[grow0 + L.l31] = rs1;
         }
       }
     }
+    CP(58);
   }
+  CP_RT(127);
 }
 
 // dst[i] = src[idx[i]]: the chain image from the [N,K] operand shadows (the index table is built once on the host)
@@ -739,6 +824,12 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(const bf16* __restric
 }  // namespace
 
 int rgbnm_gelu_table_query(const unsigned** img, int* A0, int* P1, int* N1, int* ndw);   // mlp_fused.hip
+
+#ifdef CHAIN_PROF
+extern "C" int rgbnm_chain_prof_read(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_prof), sizeof(unsigned long long) * 8 * 8 * 128) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" {
 
