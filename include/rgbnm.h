@@ -319,6 +319,32 @@ long long rgbnm_chain_image_elems(void);       /* bf16 elements of one block's c
 int rgbnm_chain_gather(const void* src, const int* idx, void* dst, long long n, void* stream);   /* dst[i] = src[idx[i]], bf16, n % 8 == 0 */
 int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* cfg, const void* blocks_dev, int depth, const void* x0, void* stream);
 
+/* ---- The data path of the whole encoder BACKWARD as ONE launch, one workgroup per image (csrc/vit_chain_bwd.hip) -----------
+ * Reference: the backward of the same `depth` blocks as autograd runs it (models/plainvit.py:493-529).  For every block, last to
+ * first: du = (dy . W2) * gelu'(u), d(x_mid) = dy + LN2'(du . W1), d(attention output) = d(x_mid) . Wproj, attention backward,
+ * dx = d(x_mid) + LN1'(d(qkv) . Wqkv) -- the kernels rgbnm_vit_block_bwd launches one by one, same arithmetic, same bits.  It
+ * leaves du / dx_mid / dqkv / dx of EVERY block in the caller's buffers (operands of the weight-gradient GEMMs) and the
+ * per-image partial sums of the LayerNorm parameter gradients in part2 / part1 ([B][2][192] each: d(gamma) | d(beta)); the caller
+ * then runs rgbnm_vit_block_bwd_dw per block (any order), which launches the four weight-gradient GEMMs and submits the
+ * reductions exactly as rgbnm_vit_block_bwd does.  blocks_dev: DEVICE array of `depth` rgbnm_chain_bwd_block; blk[i].dy must be
+ * blk[i + 1].dx for i < depth - 1.  wimg: the backward chain image (rgb-no-more_amd/chain.py, from the TRANSPOSED operand
+ * shadows by rgbnm_chain_gather).  dattn: [B * 196, 192] scratch.  Returns RGBNM_OK, 1 = not eligible, negative = error. */
+typedef struct rgbnm_chain_bwd_block {
+  const void* wimg;
+  const float *ln1_g, *ln2_g;
+  const void* x_in; const float *mean1, *rstd1;
+  const void* qkv; const float* lse; const void* attn; const void* x_mid; const float *mean2, *rstd2; const void* u;
+  const void* dy;
+  void* du; void* dx_mid; void* dqkv; void* dx;
+  float *part2, *part1;
+} rgbnm_chain_bwd_block;
+size_t rgbnm_chain_bwd_block_bytes(void);
+int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* cfg, const void* blocks_dev, int depth, void* dattn, void* stream);
+/* The weight / bias / LayerNorm-parameter gradients of one block from what rgbnm_vit_chain_bwd left behind: the dW part of
+ * rgbnm_vit_block_bwd (scratch->du / dx_mid / dqkv as filled by the chain kernel; dy = the block's output gradient). */
+int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* cfg, const rgbnm_block_acts* a, const rgbnm_block_grads* g,
+                           const rgbnm_block_scratch* s, const void* dy, const float* part2, const float* part1, void* stream);
+
 /* Table GELU of the bf16 path (csrc/mlp_fused.hip): in bf16 mode the pre-activation is rounded to bf16 before the GELU
  * (models/plainvit.py:487-488 under autocast), so gelu / gelu' are functions of 16 bits.  _init is a SET-UP call (it
  * synchronises `stream`; not capturable; idempotent per device): it builds the table of the library's own GELU arithmetic for

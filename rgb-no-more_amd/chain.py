@@ -66,3 +66,25 @@ def block_index(ws_qkv, ws_proj, ws_fc1, ws_fc2, heads=3, E=192):
     idx = np.concatenate(out)
     assert idx.size == BLOCK_ELEMS
     return idx
+
+
+def block_index_bwd(wst_qkv, wst_proj, wst_fc1, wst_fc2, heads=3, E=192):
+    """Index table of one block's BACKWARD chain image (csrc/vit_chain_bwd.hip), over the TRANSPOSED operand shadows
+    (wst_*: offsets of the [K, N] shadows; the qkv one has its 576 columns de-interleaved).  Consumption order:
+      12 x ( W2^T chunk: LDS row r (384 B) <- row 64 c + swap23(r) of fc2's [768, 192] shadow, pchunk swizzle
+           | W1^T chunk: LDS row r (128 B) <- row r of fc1's [192, 768] shadow, columns 64 c .., chunk q at q ^ fswz(r) )
+      3 projection chunks (head h): LDS row r (384 B) <- row 64 h + swap23(r) of the projection's [192, 192] transposed shadow
+      9 qkv chunks j: LDS row r (128 B) <- row r of the qkv [192, 576] transposed shadow, columns 64 j .."""
+    assert heads == 3 and E == 192
+    inner, hid = heads * 64, 4 * E
+    out = []
+    for c in range(hid // 64):
+        out.append(_rows384(lambda r, c=c: c * 64 + _swap23(r), wst_fc2, E))
+        out.append(_rows128(lambda r: r, lambda k, c=c: c * 64 + k, wst_fc1, hid))
+    for h in range(heads):
+        out.append(_rows384(lambda r, h=h: h * 64 + _swap23(r), wst_proj, E))
+    for j in range(3 * inner // 64):
+        out.append(_rows128(lambda r: r, lambda k, j=j: j * 64 + k, wst_qkv, 3 * inner))
+    idx = np.concatenate(out)
+    assert idx.size == BLOCK_ELEMS
+    return idx

@@ -56,6 +56,15 @@ struct LnBwdRows {
   // barrier that completes the tile.  red: RED_BYTES of LDS scratch that does not overlap Cs.  Contains two __syncthreads.
   __device__ __forceinline__ void run(const bf16* Cs, int cp, bf16* __restrict__ C, int ldc, const float* __restrict__ gamma,
                                       bool has_res, float* __restrict__ part, int panel, float* red, int m0, int rows, int tid) {
+    run(Cs, cp, C, ldc, gamma, has_res, part, panel, red, m0, rows, tid, nullptr, [](int) { __syncthreads(); });
+  }
+  // The same with (i) wb != null: every dx row is also written back into the staging tile (pitch cp, same pieces), from which a
+  // persistent caller takes its rows as operand fragments; (ii) the four workgroup barriers of the column sums supplied by the
+  // caller (bar(0) .. bar(3)): a workgroup with a non-participating wave must let that wave mirror them (vit_chain_bwd.hip).
+  template <typename BarF>
+  __device__ __forceinline__ void run(const bf16* Cs, int cp, bf16* __restrict__ C, int ldc, const float* __restrict__ gamma,
+                                      bool has_res, float* __restrict__ part, int panel, float* red, int m0, int rows, int tid,
+                                      bf16* wb, BarF&& bar) {
     const int l8 = tid & 7, grp = tid >> 3;
     f32x4 gm[3][2];
 #pragma unroll
@@ -93,12 +102,17 @@ struct LnBwdRows {
           for (int i = 0; i < 8; ++i)
             ob[i] = (bf16)ln_bwd_dx(rs[it], gv[v][i], c1, xh[v][i], c2, has_res ? (float)lr[it][v][i] : 0.f);
           *reinterpret_cast<bf16x8*>(C + (size_t)(m0 + row) * ldc + v * 64 + l8 * 8) = ob;
+          if (wb) {
+            bf16* wp = wb + row * cp + v * 64 + l8 * 8;                 // 8-byte aligned pieces, as they were read
+            *reinterpret_cast<bf16x4*>(wp) = bf16x4{ob[0], ob[1], ob[2], ob[3]};
+            *reinterpret_cast<bf16x4*>(wp + 4) = bf16x4{ob[4], ob[5], ob[6], ob[7]};
+          }
         }
       }
     }
     // panel-level column sums of dgamma / dbeta (fixed order => deterministic)
     for (int pass = 0; pass < 2; ++pass) {
-      __syncthreads();
+      bar(2 * pass);
 #pragma unroll
       for (int v = 0; v < 3; ++v)
 #pragma unroll
@@ -107,7 +121,7 @@ struct LnBwdRows {
                                     : (f32x4){db[v][4 * hf], db[v][4 * hf + 1], db[v][4 * hf + 2], db[v][4 * hf + 3]};
           *reinterpret_cast<f32x4*>(red + grp * (E + 4) + v * 64 + l8 * 8 + hf * 4) = q;
         }
-      __syncthreads();
+      bar(2 * pass + 1);
       for (int e = tid; e < E; e += NT) {
         float a = 0.f;
 #pragma unroll 8

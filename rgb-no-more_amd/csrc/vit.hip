@@ -32,7 +32,7 @@ hipEvent_t take_event() {
 // process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
 // they select between parity-tested kernels and are meant to be set before work is enqueued
 struct Opt { const char* name; std::atomic<int> value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"attn_proj", 0}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"attn_proj", 0}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}, {"bwd_chain", 1}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -282,6 +282,45 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   }();
 #undef WS
   const int rt = rgbnm_tn_defer_flush((hipStream_t)st);      // no-op unless an error left the queue open
+  const int rf = rgbnm_reduce_defer_flush((hipStream_t)st);
+  return rc != RGBNM_OK ? rc : (rt != RGBNM_OK ? rt : rf);
+}
+
+// The weight / bias / LayerNorm-parameter gradients of one block after rgbnm_vit_chain_bwd (vit_chain_bwd.hip) has run its data
+// path: the four weight-gradient GEMMs as ONE grouped launch and the batched reduction, as rgbnm_vit_block_bwd issues them.
+int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* c, const rgbnm_block_acts* a, const rgbnm_block_grads* g,
+                           const rgbnm_block_scratch* s, const void* dy, const float* part2, const float* part1, void* st) {
+  if (!c || !a || !g || !s || !dy || !part2 || !part1) return RGBNM_EINVAL;
+  const int dt = c->dtype, M = c->B * c->N, E = c->E, I = c->heads * 64;
+  size_t off[7];
+  if (s->ws_bytes < block_ws_offsets(M, E, I, off)) return RGBNM_EWORKSPACE;
+  char* wsb = (char*)s->ws;
+#define WS(i) (wsb + off[i]), (off[(i) + 1] - off[i])
+  rgbnm_reduce_defer_begin();
+  const int rc = [&]() -> int {
+    const int group = rgbnm_get_option("tn_group");
+    if (group) rgbnm_tn_defer_begin();
+    TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
+    TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, WS(1), st));
+    if (group == 1) { TRY(rgbnm_tn_defer_flush((hipStream_t)st)); rgbnm_tn_defer_begin(); }
+    TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, WS(2), st));
+    TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
+    if (group) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
+    // per-image partial sums of the LayerNorm parameter gradients (one panel per image)
+    RgbnmReduceJob j;
+    j.stride = 2LL * E; j.n = E; j.S = c->B; j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
+    j.part = part2; j.out = g->dln2_g;
+    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+    j.part = part2 + E; j.out = g->dln2_b;
+    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+    j.part = part1; j.out = g->dln1_g;
+    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+    j.part = part1 + E; j.out = g->dln1_b;
+    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+    return RGBNM_OK;
+  }();
+#undef WS
+  const int rt = rgbnm_tn_defer_flush((hipStream_t)st);
   const int rf = rgbnm_reduce_defer_flush((hipStream_t)st);
   return rc != RGBNM_OK ? rc : (rt != RGBNM_OK ? rt : rf);
 }

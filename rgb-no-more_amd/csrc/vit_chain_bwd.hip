@@ -1,0 +1,806 @@
+// The data path of the whole encoder BACKWARD of JPEG-Ti as ONE persistent launch, one workgroup per image (reference: the
+// twelve TransformerEncoderBlocks of models/plainvit.py:493-529 run backwards by autograd).
+//
+// What couples images in the backward are only the weight / bias / LayerNorm-parameter gradients (sums over all tokens); the
+// chain dy -> d(x_mid) -> d(attention output) -> d(q, k, v) -> dx of a block is image-local exactly like the forward.  This
+// kernel runs that chain for all blocks of one image on one CU and leaves behind, per block, the operands of the four
+// weight-gradient GEMMs (du, d(x_mid), d(qkv), dy: gemm_tn_pipe.hip runs them afterwards, one grouped launch per block as
+// before) and the image's partial sums of the LayerNorm parameter gradients.  It replaces 4 launches per block -- fused MLP
+// backward, the attention-output dX GEMM, attention backward, the qkv dX GEMM with the LayerNorm backward -- and their starts,
+// memory-bound epilogues and tails; the hand-offs between them stay inside the CU's L2 (d(attention output), d(qkv)) or LDS
+// (d(x_mid), the next block's dy).
+//
+// The phases are the bodies of those kernels, same arithmetic and summation order, so the results are the SAME BITS as the
+// per-operation path (tests/test_chain_bwd.py):
+//   M   mlp_fused.hip mlp_bwd_kernel: du = (dy . W2) * gelu'(u) chunk by chunk, dxn2 += du . W1; LayerNorm backward through a
+//       row-major staging tile (ln_bwd_rows.h), which also hands d(x_mid) back to the waves as operand fragments
+//   P   d(attention output) = d(x_mid) . Wproj: three steps of 24 MFMAs per wave (as the q / k / v steps of vit_chain.hip)
+//   A   attention_v2.hip attn3_bwd_kernel for the three heads of the image (K,V / Q,dO arrays by LDS-DMA, gradient tiles out
+//       through the DMA wave)
+//   X   dxn1 = d(qkv) . Wqkv: nine steps of 24 MFMAs, the wave's own d(qkv) rows coming back from L2 by LDS-DMA; LayerNorm
+//       backward as in M, whose staging tile hands the next block its dy
+// Weights come from a second chain image (transposed shadows, consumption order, LDS layout: rgb-no-more_amd/chain.py).
+#include "common.h"
+#include <type_traits>
+#include "internal.h"
+#include "ln_bwd_rows.h"
+#include "../../include/rgbnm.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+constexpr int E = 192, HID = 768, HD = 64, HEADS = 3, NTOK = 196, NTILE = 7, NPAD = 224, INNER = HEADS * HD, LDQ = 3 * INNER;
+constexpr int NCW = 7, NTHREADS = 64 * (NCW + 1), CTHREADS = 64 * NCW, BM = 32 * NCW;
+constexpr int ROWB = 128, ARR = NPAD * ROWB, SLOT = 24576, STAGE = 2 * SLOT, CH = 64, NCHUNK = HID / CH;
+constexpr int CP = E + 4;                           // pitch (elements) of the LayerNorm-backward staging tile
+constexpr int SMEM = 163840;
+// ---- M: two weight stages | per wave: gelu' tile, du tile
+constexpr int M_STG = 2 * STAGE;                    // 98304
+constexpr int TILE = 32 * ROWB;                     // 4096
+// ---- LayerNorm-backward epilogues: staging tile at 0, column-sum scratch behind it
+typedef rgbnm::LnBwdRows<CTHREADS, BM> LnBwd;
+constexpr int RED_OFF = (BM * CP * 2 + 1023) / 1024 * 1024;      // 88064
+static_assert(RED_OFF + LnBwd::RED_BYTES <= 132096, "LDS");
+// ---- P: slot 0 behind the epilogue's scratch (fetched during the epilogue), slots 1, 2 over the dead staging tile; out tiles
+constexpr int P_SLOT0 = 132096, P_SLOT1 = 0, P_SLOT2 = SLOT, P_TILES = 98304;
+static_assert(P_SLOT0 + SLOT <= SMEM && P_TILES + NCW * TILE <= P_SLOT0, "LDS");
+// ---- A: the layout of attn3_bwd_kernel
+constexpr int A_Q = 0, A_K = ARR, A_V = 2 * ARR, A_G = 3 * ARR, A_L2 = 4 * ARR, A_D = A_L2 + NPAD * 4, A_STG = A_D + NPAD * 4;
+constexpr int STG_PITCH = 144, STG_WAVE = 32 * STG_PITCH;
+static_assert(A_STG + NCW * STG_WAVE <= SMEM, "LDS");
+// ---- X: three weight slots | three sets of d(qkv) row tiles
+constexpr int X_SLOTS = 0, X_TILES = 3 * SLOT, X_TSET = NCW * TILE;
+static_assert(X_TILES + 3 * X_TSET <= SMEM, "LDS");
+
+struct BwdBlk {              // = rgbnm_chain_bwd_block (rgbnm.h) with typed pointers
+  const bf16* wimg;          // 12 x (W2^T chunk | W1^T chunk) | 3 projection chunks | 9 qkv chunks
+  const float *ln1_g, *ln2_g;
+  const bf16* x_in; const float *mean1, *rstd1;
+  const bf16* qkv; const float* lse; const bf16* attn; const bf16* x_mid; const float *mean2, *rstd2; const bf16* gp;
+  const bf16* dy;            // gradient w.r.t. the block's output
+  bf16* du; bf16* dx_mid; bf16* dqkv; bf16* dx;     // dx = gradient w.r.t. the block's input (the next block's dy)
+  float *part2, *part1;      // [nimg][2][192] partial sums of d(gamma), d(beta) of LN2 / LN1
+};
+static_assert(sizeof(BwdBlk) == sizeof(rgbnm_chain_bwd_block), "rgbnm_chain_bwd_block layout");
+struct BwdArgs {
+  const BwdBlk* blk; bf16* dattn;      // dattn: [M, 192] scratch shared by all blocks (written and read by the same workgroup)
+  int depth, nimg;
+  float scale;
+};
+
+__device__ __forceinline__ int fswz(int row) {
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+}
+struct Geo {
+  int lane, l31, g, fl;
+  unsigned tr0;
+};
+__device__ __forceinline__ Geo make_geo() {
+  Geo L;
+  L.lane = threadIdx.x & 63;
+  L.l31 = L.lane & 31;
+  L.g = L.lane >> 5;
+  L.fl = fswz(L.l31);
+  const int k = (L.lane >> 2) & 3, G1 = (L.lane >> 4) & 1, l3 = L.lane & 3;
+  const int pc = (2 * G1 + (l3 >> 1)) ^ (((k >> 1) << 2) | L.g);
+  L.tr0 = (unsigned)((4 * L.g + k) * ROWB + pc * 16 + 8 * (l3 & 1));
+  return L;
+}
+template <int T> struct TileLoop {
+  template <typename F> static __device__ __forceinline__ void run(F&& f) {
+    TileLoop<T - 1>::run(f);
+    f(std::integral_constant<int, T - 1>{});
+  }
+};
+template <> struct TileLoop<0> {
+  template <typename F> static __device__ __forceinline__ void run(F&&) {}
+};
+__device__ __forceinline__ bf16x8 pack8(u32x2 lo, u32x2 hi) {
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int T>
+__device__ __forceinline__ void tfrag4(unsigned a0, Frag<bf16> (&f)[4]) {
+  u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+  const unsigned a00 = a0, a01 = (a0 ^ 32u) + 1024u, a10 = a0 ^ 64u, a11 = (a0 ^ 96u) + 1024u;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "i"(T * 4096), "i"(T * 4096 + 2048)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  f[0].v = pack8(r0, r1);
+  f[1].v = pack8(r2, r3);
+  f[2].v = pack8(r4, r5);
+  f[3].v = pack8(r6, r7);
+}
+__device__ __forceinline__ Frag<bf16> pfrag(const float (&p)[16], int fi) {
+  Frag<bf16> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (bf16)p[fi * 8 + j];
+  return f;
+}
+__device__ __forceinline__ Frag<bf16> rowfrag_x(const unsigned char* arr, unsigned rb, int t, int c) {
+  Frag<bf16> f;
+  f.v = *reinterpret_cast<const bf16x8*>(arr + (rb ^ (unsigned)(c << 5)) + t * 32 * ROWB);
+  return f;
+}
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const bf16x2v v = {(bf16)a, (bf16)b};
+  unsigned r = __builtin_bit_cast(unsigned, v);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+struct Rows { u32x4 v[12]; };      // 12 operand fragments: features 16 c + 8 g + (0..7) of the lane's token (vit_chain.hip)
+
+template <int NKB>
+__device__ __forceinline__ void dma_linear(const unsigned char* src, unsigned char* dst, int lane) {
+#pragma unroll
+  for (int i = 0; i < NKB; ++i)
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + i * 1024 + lane * 16), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+}
+// [N][64] bf16 matrix (row stride ld) -> LDS array, chunk q of row r at q ^ fswz(r): 28 pieces of 1 KB; rows >= N repeat row N - 1
+__device__ __forceinline__ void dma_matrix_all(const bf16* __restrict__ src, int ld, unsigned char* dst, int lane) {
+#pragma unroll 4
+  for (int i = 0; i < 28; ++i) {
+    const int row = 8 * i + (lane >> 3), pc = lane & 7;
+    const int lc = pc ^ fswz(row);
+    const int srow = row < NTOK ? row : NTOK - 1;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)srow * ld + lc * 8), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+  }
+}
+// the seven waves' own 32 x 64 pieces of a [N][ld] matrix (columns c0 .. c0 + 63) -> row tiles, chunk q of row r at q ^ (r & 7)
+__device__ __forceinline__ void dma_row_tiles(const bf16* __restrict__ src, int ld, unsigned char* dst, int lane) {
+#pragma unroll 4
+  for (int i = 0; i < 28; ++i) {
+    const int row = 8 * i + (lane >> 3), pc = lane & 7;
+    const int lc = pc ^ (row & 7);
+    const int srow = row < NTOK ? row : NTOK - 1;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)srow * ld + lc * 8), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+  }
+}
+
+// one 64-column piece of the wave's 32 rows -> private tile -> whole 128-byte row pieces -> global (vit_chain.hip tile_out)
+__device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, const u32x4& p0, const u32x4& p1, const u32x4& p2,
+                                         const u32x4& p3, bf16* dst, int ld, int live) {
+  const int ln = lane_id_here();
+  const unsigned wo = stg + (unsigned)((ln & 31) * ROWB + (((ln >> 5) ^ (ln & 7)) << 4));
+  *reinterpret_cast<u32x4*>(smem + wo) = p0;
+  *reinterpret_cast<u32x4*>(smem + (wo ^ 32u)) = p1;
+  *reinterpret_cast<u32x4*>(smem + (wo ^ 64u)) = p2;
+  *reinterpret_cast<u32x4*>(smem + (wo ^ 96u)) = p3;
+  wait_lds();
+  const int rl = ln >> 3, seg = ln & 7;
+  const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));
+  bf16* gp = dst + (size_t)rl * ld + seg * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+    if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v;
+  }
+  wait_lds();
+}
+
+// acc (32 output rows x 32 tokens, swapped) += chunk rows [32 ht .. +31] (384 B rows, pchunk swizzle) . x
+__device__ __forceinline__ void gemm_k192(f32x16& acc, const unsigned char* sW, int ht, const Rows& x, const Geo& L) {
+  int wbase = L.l31 * (E * 2) + ((L.g ^ L.fl) << 4) + ht * 32 * (E * 2);
+  asm volatile("" : "+v"(wbase));
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    Frag<bf16> fb, fx;
+    fb.v = *reinterpret_cast<const bf16x8*>(sW + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+    fx.v = as_bf16x8(x.v[c]);
+    mma(acc, fb, fx);
+  }
+}
+
+// ---- gradient tiles of the attention backward (attention_v2.hip)
+__device__ __forceinline__ void tile_park_private(unsigned char* stg, const f32x16 (&acc)[2], float mul, const Geo& L) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 v = {acc[dt][rq * 4 + 0], acc[dt][rq * 4 + 1], acc[dt][rq * 4 + 2], acc[dt][rq * 4 + 3]};
+      store4<bf16>(reinterpret_cast<bf16*>(stg + L.l31 * STG_PITCH) + dt * 32 + rq * 8 + L.g * 4, v * mul);
+    }
+}
+__device__ __forceinline__ void tile_park_rows(unsigned char* arr, int w, const f32x16 (&acc)[2], float mul) {
+  const int ln = lane_id_here();
+  const unsigned off0 = (unsigned)((w * 32 + (ln & 31)) * ROWB + ((ln & 7) << 4) + (ln >> 5) * 8);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 v = {acc[dt][rq * 4 + 0], acc[dt][rq * 4 + 1], acc[dt][rq * 4 + 2], acc[dt][rq * 4 + 3]};
+      store4<bf16>(reinterpret_cast<bf16*>(arr + (off0 ^ (unsigned)((dt * 4 + rq) << 4))), v * mul);
+    }
+}
+template <bool PRIVATE>
+__device__ __forceinline__ void tiles_read(const unsigned char* src, int lane, u32x4 (&v)[NTILE][4]) {
+  const int rl = lane >> 3, seg = lane & 7;
+#pragma unroll
+  for (int wv = 0; wv < NTILE; ++wv)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = i * 8 + rl;
+      v[wv][i] = PRIVATE ? *reinterpret_cast<const u32x4*>(src + wv * STG_WAVE + r * STG_PITCH + seg * 16)
+                         : *reinterpret_cast<const u32x4*>(src + (wv * 32 + r) * ROWB + ((seg ^ (r & 7)) << 4));
+    }
+}
+__device__ __forceinline__ void tiles_write(const u32x4 (&v)[NTILE][4], bf16* __restrict__ g0, size_t ld, int lane) {
+  const int rl = lane >> 3, seg = lane & 7;
+#pragma unroll
+  for (int wv = 0; wv < NTILE; ++wv)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wv * 32 + i * 8 + rl;
+      if (row < NTOK) *reinterpret_cast<u32x4*>(g0 + (size_t)row * ld + seg * 8) = v[wv][i];
+    }
+}
+
+#ifdef CHAINB_PROF
+__device__ unsigned long long g_chainb_prof[8 * 8 * 128];
+#define CP_(i)                                                                                          \
+  do {                                                                                                  \
+    if (ib == CHAINB_PROF_BLK && blockIdx.x < 8) {                                                      \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                       \
+      if ((threadIdx.x & 63) == 0) g_chainb_prof[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 128 + (i)] = t_; \
+    }                                                                                                   \
+  } while (0)
+#ifndef CHAINB_PROF_BLK
+#define CHAINB_PROF_BLK 6
+#endif
+#else
+#define CP_(i) do {} while (0)
+#endif
+// barrier number s of a block: stamps 2 s (arrival) and 2 s + 1 (release)
+#define BAR(s) do { CP_(2 * (s)); wg_barrier(); CP_(2 * (s) + 1); } while (0)
+// barrier numbers inside a block
+constexpr int B_M0 = 0;                 // 0..11   hidden chunks
+constexpr int B_E2 = 12;                // 12..18  LN2-backward epilogue (7 barriers)
+constexpr int B_P = 19;                 // 19: staging tile dead, 20..22 projection steps, 23: d(attn) stored
+constexpr int B_A = 24;                 // 24: start, then 4 per head: 25..36
+constexpr int B_X = 37;                 // 37..45  qkv steps
+constexpr int B_E1 = 46;                // 46..52  LN1-backward epilogue
+constexpr int B_END = 53;               // 53: staging tile dead (dy fragments of the next block are in registers)
+
+// The LayerNorm-backward epilogue shared by M and X (the code of mlp_bwd_kernel's / gemm_nt_kpipe<LNBWD>'s epilogue): acc -> staging
+// tile -> rows; writes dx to global AND back into the tile, from which the caller reads its own rows as operand fragments.
+// Seven workgroup barriers: b0 .. b0 + 6 (the DMA wave mirrors them).  Compute threads only.
+template <int B0>
+__device__ __forceinline__ void ln_bwd_epilogue(unsigned char* smem, const f32x16 (&acc)[6], const bf16* X, const float* mean,
+                                                const float* rstd, const float* gamma, const bf16* R, bf16* DX, float* part,
+                                                int img, int tid, int rloc, int g, int ib) {
+  LnBwd lnb;
+  lnb.request_x(X, E, mean, rstd, img * NTOK, NTOK, tid);
+  lnb.request_res(R, E, img * NTOK, NTOK, tid);
+  wait_lds();
+  BAR(B0);                                // every wave is done with the phase's LDS: the staging tile takes its place
+  bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = 32 * b + 8 * q + 4 * g;
+      const f32x4 v = {acc[b][4 * q + 0], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]};
+      store4<bf16>(Cs + rloc * CP + nl, v);
+    }
+  wait_lds();
+  BAR(B0 + 1);
+  lnb.run(Cs, CP, DX, E, gamma, true, part, img, reinterpret_cast<float*>(smem + RED_OFF), img * NTOK, NTOK, tid, Cs,
+          [&](int k) { if (k == 0) BAR(B0 + 2); else if (k == 1) BAR(B0 + 3); else if (k == 2) BAR(B0 + 4); else BAR(B0 + 5); });
+  wait_lds();
+  BAR(B0 + 6);                            // dx rows are back in the tile
+}
+__device__ __forceinline__ void read_own_rows(const unsigned char* smem, int rloc, int g, Rows& x) {
+  const unsigned char* rp = smem + rloc * (CP * 2) + 16 * g;      // 8-byte aligned (pitch 392 B)
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(rp + 32 * c), hi = *reinterpret_cast<const u32x2*>(rp + 32 * c + 8);
+    x.v[c] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+  }
+}
+
+__global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int img = blockIdx.x;
+  if (img >= p.nimg) return;
+  const Geo L = make_geo();
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int depth = p.depth;
+
+  if (w == NCW) {
+    // ================================================================ DMA wave
+    const int lane = L.lane;
+    for (int ib = depth - 1; ib >= 0; --ib) {
+      const BwdBlk& b = p.blk[ib];
+      const unsigned char* wimg = reinterpret_cast<const unsigned char*>(b.wimg);
+      // ---- M: hidden chunk c into stage c & 1, one chunk ahead
+      dma_linear<48>(wimg, smem, lane);
+      for (int c = 0; c < NCHUNK; ++c) {
+        wait_vm<0>();
+        BAR(B_M0 + c);
+        if (c + 1 < NCHUNK) dma_linear<48>(wimg + (size_t)(c + 1) * STAGE, smem + ((c + 1) & 1) * STAGE, lane);
+      }
+      // ---- LN2-backward epilogue: first projection chunk behind the scratch while it runs
+      BAR(B_E2);
+      dma_linear<24>(wimg + (size_t)NCHUNK * STAGE, smem + P_SLOT0, lane);
+#pragma unroll
+      for (int k = 1; k < 7; ++k) BAR(B_E2 + k);
+      // ---- P
+      BAR(B_P);                                           // the staging tile is dead
+      dma_linear<24>(wimg + (size_t)NCHUNK * STAGE + SLOT, smem + P_SLOT1, lane);
+      dma_linear<24>(wimg + (size_t)NCHUNK * STAGE + 2 * SLOT, smem + P_SLOT2, lane);
+      wait_vm<48>(); BAR(B_P + 1);
+      wait_vm<24>(); BAR(B_P + 2);
+      wait_vm<0>(); BAR(B_P + 3);
+      BAR(B_P + 4);                                       // d(attention output) of this image is in L2
+      // ---- A: the DMA wave of attn3_bwd_kernel for the three heads of this image
+      {
+        const bf16* qkv0 = b.qkv + (size_t)img * NTOK * LDQ;
+        const bf16* do0 = p.dattn + (size_t)img * NTOK * INNER;
+        bf16* dq0 = b.dqkv + (size_t)img * NTOK * LDQ;
+        const unsigned char* stg0 = smem + A_STG;
+        auto issue_kv = [&](int h) {
+          dma_matrix_all(qkv0 + INNER + h * HD, LDQ, smem + A_K, lane);
+          dma_matrix_all(qkv0 + 2 * INNER + h * HD, LDQ, smem + A_V, lane);
+        };
+        auto issue_qg = [&](int h) {
+          dma_matrix_all(qkv0 + h * HD, LDQ, smem + A_Q, lane);
+          dma_matrix_all(do0 + h * HD, INNER, smem + A_G, lane);
+        };
+        issue_kv(0);
+        issue_qg(0);
+        wait_vm<56>();
+        BAR(B_A);                                         // start: K, V of head 0 are in LDS
+        for (int h = 0; h < HEADS; ++h) {
+          bf16* g0 = dq0 + h * HD;
+          wait_vm<0>();                                   // Q, dO landed (and the previous head's stores are done)
+          BAR(B_A + 1 + 4 * h);                           // mid
+          u32x4 tq[NTILE][4];
+          tiles_read<true>(stg0, lane, tq);               // dQ tiles
+          wait_lds();
+          BAR(B_A + 2 + 4 * h);                           // mid2
+          tiles_write(tq, g0, LDQ, lane);
+          if (h + 1 < HEADS) issue_kv(h + 1);
+          wait_vm<0>();
+          BAR(B_A + 3 + 4 * h);                           // end
+          tiles_read<true>(stg0, lane, tq);               // dK tiles
+          wait_lds();
+          BAR(B_A + 4 + 4 * h);                           // end2
+          tiles_write(tq, g0 + INNER, LDQ, lane);
+          tiles_read<false>(smem + A_G, lane, tq);        // dV
+          wait_lds();
+          if (h + 1 < HEADS) issue_qg(h + 1);
+          tiles_write(tq, g0 + 2 * INNER, LDQ, lane);
+        }
+        wait_vm<0>();                                     // every d(qkv) row of this image is in L2
+      }
+      // ---- X: chunk j -> slot j % 3, the waves' own d(qkv) rows (columns 64 j ..) -> tile set j % 3; two steps ahead
+      {
+        const unsigned char* xw = wimg + (size_t)NCHUNK * STAGE + 3 * SLOT;
+        const bf16* dq0 = b.dqkv + (size_t)img * NTOK * LDQ;
+        auto issue_x = [&](int j) {
+          dma_linear<24>(xw + (size_t)j * SLOT, smem + X_SLOTS + (j % 3) * SLOT, lane);
+          dma_row_tiles(dq0 + j * 64, LDQ, smem + X_TILES + (j % 3) * X_TSET, lane);
+        };
+        // (the attention arrays are dead only when every compute wave has passed end2 of the last head: they have -- the DMA wave
+        // arrives at that barrier last of all, after the waves parked their dV tiles)
+        issue_x(0);
+        issue_x(1);
+        for (int j = 0; j < 9; ++j) {
+          if (j + 1 < 9) wait_vm<52>(); else wait_vm<0>();
+          BAR(B_X + j);
+          if (j + 2 < 9 && j >= 1) issue_x(j + 2);        // slot / tile set (j + 2) % 3 = (j - 1) % 3: free since step j - 1 ended
+          if (j == 0) issue_x(2);                         // (nothing used set 2 before)
+        }
+      }
+      // ---- LN1-backward epilogue
+#pragma unroll
+      for (int k = 0; k < 7; ++k) BAR(B_E1 + k);
+      BAR(B_END);
+    }
+    return;
+  }
+
+  // ==================================================================== compute waves
+  const int row0 = 32 * w;
+  const int live = NTOK - row0 < 32 ? NTOK - row0 : 32;
+  const int rloc = row0 + L.l31;
+  const size_t grow0 = (size_t)img * NTOK + row0;
+  const int fl = L.fl;
+  const int woff0 = L.l31 * (E * 2) + ((L.g ^ fl) << 4);
+  const float LOG2E = 1.4426950408889634f;
+  const float c2 = p.scale * LOG2E;
+
+  Rows dyf;                                                       // dy rows of this lane's token as operand fragments
+  {
+    const int tok = rloc < NTOK ? rloc : NTOK - 1;
+    const bf16* yrow = p.blk[depth - 1].dy + ((size_t)img * NTOK + tok) * E + 8 * L.g;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) dyf.v[c] = *reinterpret_cast<const u32x4*>(yrow + 16 * c);
+  }
+
+  for (int ib = depth - 1; ib >= 0; --ib) {
+    const BwdBlk& b = p.blk[ib];
+    // ================================================================ M: the loop of mlp_bwd_kernel
+    f32x16 acc2[6];
+#pragma unroll
+    for (int bt = 0; bt < 6; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[bt][r] = 0.f;
+    {
+      const unsigned stg = (unsigned)(M_STG + w * 2 * TILE);      // tile 0: gelu' in, tile 1: du out
+      const int ln = lane_id_here();
+      bf16x8 gpraw[4];
+      auto load_gp = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+          int rr = row0 + row;
+          rr = rr < NTOK ? rr : NTOK - 1;
+          gpraw[i] = *reinterpret_cast<const bf16x8*>(b.gp + ((size_t)img * NTOK + rr) * HID + chunk * CH + vec * 8);
+        }
+      };
+      load_gp(0);
+      for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+          *reinterpret_cast<bf16x8*>(smem + stg + row * ROWB + ((vec ^ (row & 7)) << 4)) = gpraw[i];
+        }
+        if (chunk + 1 < NCHUNK) load_gp(chunk + 1);
+        wait_lds();
+        BAR(B_M0 + chunk);
+        const unsigned st_off = (unsigned)((chunk & 1) * STAGE);
+        const unsigned char* sW1 = smem + st_off;
+        const unsigned w2o = opaque(st_off + (unsigned)(SLOT + L.l31 * ROWB + ((L.g ^ fl) << 4)));
+        const unsigned two = opaque(stg + (unsigned)(L.l31 * ROWB + ((L.g ^ (L.l31 & 7)) << 4)));
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+          f32x16 a1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+          int wbase = woff0 + ht * 32 * (E * 2);
+          asm volatile("" : "+v"(wbase));
+#pragma unroll
+          for (int c = 0; c < 12; ++c) {
+            Frag<bf16> fb, fx;
+            fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+            fx.v = as_bf16x8(dyf.v[c]);
+            mma(a1, fb, fx);                               // D rows = hidden (rows stored swap23-ed), D cols = tokens
+          }
+          Frag<bf16> pg[2];
+#pragma unroll
+          for (int hs = 0; hs < 2; ++hs) {
+            const unsigned to = two ^ (unsigned)((2 * ht + hs) << 5);
+            const bf16x8 gpv = *reinterpret_cast<const bf16x8*>(smem + to);
+            bf16x8 dv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dv[j] = (bf16)((float)(bf16)a1[8 * hs + j] * (float)gpv[j]);
+            pg[hs].v = dv;
+            *reinterpret_cast<bf16x8*>(smem + to + TILE) = dv;
+          }
+#pragma unroll
+          for (int hs = 0; hs < 2; ++hs) {
+            const int s = 2 * ht + hs;
+            Frag<bf16> fw[6];
+#pragma unroll
+            for (int bt = 0; bt < 6; ++bt)
+              fw[bt].v = *reinterpret_cast<const bf16x8*>(smem + (w2o ^ (unsigned)(s << 5)) + bt * 32 * ROWB);
+#pragma unroll
+            for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw[bt], pg[hs]);   // D rows = input features, D cols = tokens
+          }
+        }
+        // the chunk's du tile out as whole row pieces
+        wait_lds();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(smem + stg + TILE + row * ROWB + ((vec ^ (row & 7)) << 4));
+          if (row < live) *reinterpret_cast<bf16x8*>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8) = v0;
+        }
+      }
+    }
+    // ================================================================ d(x_mid) = dy + LN2'(dxn2)
+    ln_bwd_epilogue<B_E2>(smem, acc2, b.x_mid, b.mean2, b.rstd2, b.ln2_g, b.dy, b.dx_mid, b.part2, img, tid, rloc, L.g, ib);
+    // ================================================================ P: d(attention output) = d(x_mid) . Wproj
+    {
+      Rows dxf;
+      read_own_rows(smem, rloc, L.g, dxf);
+      wait_lds();
+      BAR(B_P);
+      const unsigned stg = (unsigned)(P_TILES + w * TILE);
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        BAR(B_P + 1 + h);
+        const unsigned char* sW = smem + (h == 0 ? P_SLOT0 : (h == 1 ? P_SLOT1 : P_SLOT2));
+        f32x16 acc[2];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ht][r] = 0.f;
+          gemm_k192(acc[ht], sW, ht, dxf, L);
+        }
+        u32x4 pc[4];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+          for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) pc[2 * ht + hs][d] = pack2(acc[ht][8 * hs + 2 * d], acc[ht][8 * hs + 2 * d + 1]);
+        tile_out(smem, stg, pc[0], pc[1], pc[2], pc[3], p.dattn + grow0 * INNER + h * HD, INNER, live);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the rows are in L2 before anybody fetches them back
+      BAR(B_P + 4);
+    }
+    // ================================================================ A: attn3_bwd_kernel over the three heads
+    {
+      unsigned char* Qs = smem + A_Q;
+      unsigned char* Ks = smem + A_K;
+      unsigned char* Vs = smem + A_V;
+      unsigned char* Gs = smem + A_G;
+      float* L2_s = reinterpret_cast<float*>(smem + A_L2);
+      float* D_s = reinterpret_cast<float*>(smem + A_D);
+      unsigned char* stg = smem + A_STG + w * STG_WAVE;
+      const unsigned rb0 = (unsigned)(L.l31 * ROWB + ((L.g ^ fl) << 4));
+      const int row = rloc;
+      u32x4 qraw[4], graw[4], oraw[4];
+      float lq = 0.f;
+      const bf16* qkv0 = b.qkv + (size_t)img * NTOK * LDQ;
+      const bf16* do0 = p.dattn + (size_t)img * NTOK * INNER;
+      const bf16* o0 = b.attn + (size_t)img * NTOK * INNER;
+      auto load_own_qg = [&](int h) {
+        const int lane_ = lane_id_here();
+        const int seg = lane_ & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int r = row0 + i * 8 + (lane_ >> 3);
+          r = r < NTOK ? r : NTOK - 1;
+          qraw[i] = *reinterpret_cast<const u32x4*>(qkv0 + (size_t)r * LDQ + h * HD + seg * 8);
+          graw[i] = *reinterpret_cast<const u32x4*>(do0 + (size_t)r * INNER + h * HD + seg * 8);
+        }
+      };
+      auto load_own_o = [&](int h) {
+        const int lane_ = lane_id_here();
+        const int seg = lane_ & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int r = row0 + i * 8 + (lane_ >> 3);
+          r = r < NTOK ? r : NTOK - 1;
+          oraw[i] = *reinterpret_cast<const u32x4*>(o0 + (size_t)r * INNER + h * HD + seg * 8);
+        }
+        int rq_ = row0 + (lane_ & 31);
+        rq_ = rq_ < NTOK ? rq_ : NTOK - 1;
+        lq = b.lse[((size_t)img * HEADS + h) * NTOK + rq_];
+      };
+      load_own_qg(0);
+      load_own_o(0);
+      BAR(B_A);                                                   // start: K, V of head 0 are in LDS
+      for (int h = 0; h < HEADS; ++h) {
+        const bool more = h + 1 < HEADS;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own rows
+        // ---------------- phase A: wave = 32 queries -> dQ, D
+        Frag<bf16> kf[4], vf[4];
+        {
+          f32x16 dq[2];
+          Frag<bf16> qf[4], gf[4];
+          const int rl = L.lane >> 3, seg = L.lane & 7;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bf16x8 gv = __builtin_bit_cast(bf16x8, graw[i]), ov = __builtin_bit_cast(bf16x8, oraw[i]);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)gv[e] * (float)ov[e];
+            d += lane_xor1(d);
+            d += lane_xor2(d);
+            d += lane_xor4(d);
+            if (seg == 0) D_s[row0 + i * 8 + rl] = d;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = qraw[i];
+          wait_lds();
+#pragma unroll
+          for (int c = 0; c < 4; ++c) qf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
+          wait_lds();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = graw[i];
+          wait_lds();
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
+          const float Dq = D_s[row];
+          wait_lds();
+          const float lq2 = lq * LOG2E;
+          if (L.g == 0) L2_s[row] = lq2;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+          unsigned rb = rb0, tr = L.tr0;
+          asm volatile("" : "+v"(rb), "+v"(tr));
+          const unsigned kt = (unsigned)A_K + tr;
+          TileLoop<NTILE>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            f32x16 sa, da;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              mma(sa, rowfrag_x(Ks, rb, t, c), qf[c]);
+              mma(da, rowfrag_x(Vs, rb, t, c), gf[c]);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lq2));
+              ds[r] = pr * (da[r] - Dq);
+            }
+            if (t * 32 + 32 > NTOK) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (t * 32 + acc_row(r, L.lane) >= NTOK) ds[r] = 0.f;
+            }
+            Frag<bf16> kk[4];
+            tfrag4<t>(kt, kk);
+            Frag<bf16> sf = pfrag(ds, 0);
+            mma(dq[0], kk[0], sf);
+            mma(dq[1], kk[1], sf);
+            sf = pfrag(ds, 1);
+            mma(dq[0], kk[2], sf);
+            mma(dq[1], kk[3], sf);
+          });
+          tile_park_private(stg, dq, p.scale, L);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            kf[c] = rowfrag_x(Ks, rb, w, c);
+            vf[c] = rowfrag_x(Vs, rb, w, c);
+          }
+        }
+        wait_lds();
+        BAR(B_A + 1 + 4 * h);                                     // mid
+        BAR(B_A + 2 + 4 * h);                                     // mid2
+        // ---------------- phase B: wave = 32 keys -> dK, dV
+        {
+          f32x16 dk[2], dv[2];
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+          unsigned rb = rb0, tr = L.tr0;
+          asm volatile("" : "+v"(rb), "+v"(tr));
+          const unsigned qt_ = (unsigned)A_Q + tr, gt_ = (unsigned)A_G + tr;
+          TileLoop<NTILE>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            f32x16 sa, da;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              mma(sa, rowfrag_x(Qs, rb, t, c), kf[c]);
+              mma(da, rowfrag_x(Gs, rb, t, c), vf[c]);
+            }
+            float pp[16], ds[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const f32x4 l4 = *reinterpret_cast<const f32x4*>(L2_s + t * 32 + 8 * q4 + 4 * L.g);
+              const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + t * 32 + 8 * q4 + 4 * L.g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int r = 4 * q4 + e;
+                const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -l4[e]));
+                pp[r] = pr;
+                ds[r] = pr * (da[r] - d4[e]);
+              }
+            }
+            if (t * 32 + 32 > NTOK) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (t * 32 + acc_row(r, L.lane) >= NTOK) { pp[r] = 0.f; ds[r] = 0.f; }
+            }
+            Frag<bf16> gg[4];
+            tfrag4<t>(gt_, gg);
+            Frag<bf16> f = pfrag(pp, 0);
+            mma(dv[0], gg[0], f);
+            mma(dv[1], gg[1], f);
+            f = pfrag(pp, 1);
+            mma(dv[0], gg[2], f);
+            mma(dv[1], gg[3], f);
+            tfrag4<t>(qt_, gg);
+            f = pfrag(ds, 0);
+            mma(dk[0], gg[0], f);
+            mma(dk[1], gg[1], f);
+            f = pfrag(ds, 1);
+            mma(dk[0], gg[2], f);
+            mma(dk[1], gg[3], f);
+          });
+          if (more) load_own_qg(h + 1);
+          tile_park_private(stg, dk, p.scale, L);
+          wait_lds();
+          BAR(B_A + 3 + 4 * h);                                   // end
+          tile_park_rows(Gs, w, dv, 1.0f);
+        }
+        if (more) load_own_o(h + 1);
+        wait_lds();
+        BAR(B_A + 4 + 4 * h);                                     // end2
+      }
+    }
+    // ================================================================ X: dxn1 = d(qkv) . Wqkv
+    f32x16 accx[6];
+#pragma unroll
+    for (int bt = 0; bt < 6; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[bt][r] = 0.f;
+    for (int j = 0; j < 9; ++j) {
+      BAR(B_X + j);
+      const int set = j % 3;
+      const unsigned wo = opaque((unsigned)(X_SLOTS + set * SLOT + L.l31 * ROWB + ((L.g ^ fl) << 4)));
+      const unsigned to = opaque((unsigned)(X_TILES + set * X_TSET + w * TILE + L.l31 * ROWB + ((L.g ^ (L.l31 & 7)) << 4)));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<bf16> fx, fw[6];
+        fx.v = *reinterpret_cast<const bf16x8*>(smem + (to ^ (unsigned)(s << 5)));
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt)
+          fw[bt].v = *reinterpret_cast<const bf16x8*>(smem + (wo ^ (unsigned)(s << 5)) + bt * 32 * ROWB);
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt) mma(accx[bt], fw[bt], fx);
+      }
+    }
+    // ================================================================ dx = d(x_mid) + LN1'(dxn1); the next block's dy
+    ln_bwd_epilogue<B_E1>(smem, accx, b.x_in, b.mean1, b.rstd1, b.ln1_g, b.dx_mid, b.dx, b.part1, img, tid, rloc, L.g, ib);
+    read_own_rows(smem, rloc, L.g, dyf);
+    wait_lds();
+    BAR(B_END);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rgbnm_chain_bwd_block_bytes(void) { return sizeof(BwdBlk); }
+
+// 1 = not eligible
+int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* c, const void* blk_table_dev, int depth, void* dattn, void* stream) {
+  if (!c || !blk_table_dev || !dattn || depth <= 0) return RGBNM_EINVAL;
+  if (c->dtype != RGBNM_DT_BF16 || c->E != E || c->heads != HEADS || c->N != NTOK || c->B < 1) return 1;
+  BwdArgs p;
+  p.blk = (const BwdBlk*)blk_table_dev; p.dattn = (bf16*)dattn; p.depth = depth; p.nimg = c->B; p.scale = c->attn_scale;
+  static DevOnce attr;
+  if (attr.need()) {
+    if (hipFuncSetAttribute((const void*)vit_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return RGBNM_ELAUNCH;
+    attr.done();
+  }
+  hipLaunchKernelGGL(vit_chain_bwd_kernel, dim3(c->B), dim3(NTHREADS), SMEM, (hipStream_t)stream, p);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+}  // extern "C"

@@ -61,6 +61,11 @@ class ChainBlock(C.Structure):
                                    "rstd1", "qkv", "lse", "attn", "x_mid", "xn2", "mean2", "rstd2", "u", "gl", "x_out")]
 
 
+class ChainBwdBlock(C.Structure):
+    _fields_ = [(n, _vp) for n in ("wimg", "ln1_g", "ln2_g", "x_in", "mean1", "rstd1", "qkv", "lse", "attn", "x_mid", "mean2",
+                                   "rstd2", "u", "dy", "du", "dx_mid", "dqkv", "dx", "part2", "part1")]
+
+
 ABI_VERSION = 2      # include/rgbnm.h RGBNM_ABI_VERSION this binding was written against
 
 _P = C.POINTER
@@ -127,6 +132,9 @@ PROTOTYPES = {
     "rgbnm_chain_image_elems": (_ll, []),
     "rgbnm_chain_gather": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "rgbnm_vit_chain_fwd": (_i, [_P(VitCfg), _vp, _i, _vp, _vp]),
+    "rgbnm_chain_bwd_block_bytes": (_sz, []),
+    "rgbnm_vit_chain_bwd": (_i, [_P(VitCfg), _vp, _i, _vp, _vp]),
+    "rgbnm_vit_block_bwd_dw": (_i, [_P(VitCfg), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp, _vp, _vp, _vp]),
     "rgbnm_vit_block_fwd_chain": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _i, _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
                                  _vp, _vp]),
@@ -159,7 +167,7 @@ def lib():
         if L.rgbnm_abi_version() != ABI_VERSION:
             raise RgbnmError(f"{LIB_PATH} has ABI version {L.rgbnm_abi_version()}, this binding expects {ABI_VERSION}: rebuild "
                              "(python rgb-no-more_amd/build.py)")
-        if L.rgbnm_chain_block_bytes() != C.sizeof(ChainBlock):
+        if L.rgbnm_chain_block_bytes() != C.sizeof(ChainBlock) or L.rgbnm_chain_bwd_block_bytes() != C.sizeof(ChainBwdBlock):
             raise RgbnmError("rgbnm_chain_block layout mismatch between librgbnm.so and lib.py")
         _lib = L
     return _lib

@@ -175,6 +175,7 @@ class _Arena:
         self.ws_bytes = ws_bytes
         self.ws_blk = self.ws_head = self.hold_table = self.hold_table_host = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
         self.chain_table = None      # device array of rgbnm_chain_block, built by the first one-launch forward (ViT._chain_forward)
+        self.chain_bwd_table = self.chain_bwd_dy = None     # the same for the backward (ViT._chain_backward: + per-block operand buffers)
         self.acts = []
         for i in range(D):
             b = self.blk[i if need_grad else 0]
@@ -496,10 +497,22 @@ class _BlockFn(torch.autograd.Function):
         grads = [m._gview(st.gbuf, n) for n in m._block_names[idx]]
         g = L.BlockGrads(*[t.data_ptr() for t in grads])
         scratch = a.scratch_blk[idx] if st.holding else a.scratch
+        # the data path of EVERY block's backward as one launch (rgbnm.h rgbnm_vit_chain_bwd), issued by the first block node
+        # that runs (the last block); each node then only launches its weight-gradient GEMMs and reductions
+        if idx == m.depth - 1:
+            st.chain_bwd = m._chain_backward(a, dy)
         try:
-            L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
-                                                C.byref(g), C.byref(scratch), dy.data_ptr(), dx.data_ptr(),
-                                                L.stream()), "vit_block_bwd")
+            if getattr(st, "chain_bwd", False):
+                dx = a.dx_blk[idx]
+                sc = L.BlockScratch(a.du_blk[idx].data_ptr(), a.dxn.data_ptr(), a.dxmid_blk[idx].data_ptr(),
+                                    a.dattn_chain.data_ptr(), a.dqkv_blk[idx].data_ptr(), scratch.ws, scratch.ws_bytes)
+                L.check(L.lib().rgbnm_vit_block_bwd_dw(C.byref(a.cfg), C.byref(a.acts[idx]), C.byref(g), C.byref(sc), dy.data_ptr(),
+                                                       a.lnpart[idx, 0].data_ptr(), a.lnpart[idx, 1].data_ptr(), L.stream()),
+                        "vit_block_bwd_dw")
+            else:
+                L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
+                                                    C.byref(g), C.byref(scratch), dy.data_ptr(), dx.data_ptr(),
+                                                    L.stream()), "vit_block_bwd")
             if m._grad_sync is not None:        # this block's gradients are final: start their all-reduce now
                 m._grad_sync.ready(st.gbuf, m._block_names[idx])
         except BaseException:
@@ -693,6 +706,12 @@ class ViT(FlatParamModule):
             assert idx.max() < 2 ** 31 and _chain.BLOCK_ELEMS == L.lib().rgbnm_chain_image_elems()
             self._chain_idx = torch.from_numpy(idx.astype(np.int32)).to(dev)
             self._chain_img = torch.zeros(idx.size, device=dev, dtype=torch.bfloat16)
+            idb = np.concatenate([_chain.block_index_bwd(self._sh_off[f"qkv{i}"][1], self._sh_off[f"proj{i}"][1],
+                                                         self._sh_off[f"fc1{i}"][1], self._sh_off[f"fc2{i}"][1])
+                                  for i in range(self.depth)])
+            assert idb.max() < 2 ** 31
+            self._chain_idx_bwd = torch.from_numpy(idb.astype(np.int32)).to(dev)
+            self._chain_img_bwd = torch.zeros(idb.size, device=dev, dtype=torch.bfloat16)
         self._pos = sincos_table(14, 14, self.emb_size, dev)
         self._pos7 = sincos_table(7, 7, self.emb_size, dev) if self.embed_kind == "concat" else None
         self._zc = {}
@@ -768,6 +787,11 @@ class ViT(FlatParamModule):
         if cdtype == torch.bfloat16 and self._chain_idx is not None and L.lib().rgbnm_get_option(b"fwd_chain"):
             L.check(L.lib().rgbnm_chain_gather(self._shadow[cdtype].data_ptr(), self._chain_idx.data_ptr(),
                                                self._chain_img.data_ptr(), self._chain_idx.numel(), L.stream()), "chain_gather")
+        if (cdtype == torch.bfloat16 and self._chain_idx is not None and L.lib().rgbnm_get_option(b"bwd_chain")
+                and torch.is_grad_enabled()):
+            L.check(L.lib().rgbnm_chain_gather(self._shadow[cdtype].data_ptr(), self._chain_idx_bwd.data_ptr(),
+                                               self._chain_img_bwd.data_ptr(), self._chain_idx_bwd.numel(), L.stream()),
+                    "chain_gather (backward image)")
         if cdtype not in self._bparams_by_dtype:
             bps = []
             for i in range(self.depth):
@@ -812,6 +836,40 @@ class ViT(FlatParamModule):
         if rc == 1:
             return False
         L.check(rc, "vit_chain_fwd")
+        return True
+
+    def _chain_backward(self, a, dy):
+        """Run the data path of every block's backward as one launch (rgbnm_vit_chain_bwd); False = not eligible."""
+        if (a.cdtype != torch.bfloat16 or self._chain_idx is None or not a.need_grad
+                or not L.lib().rgbnm_get_option(b"bwd_chain")):
+            return False
+        D, dev = self.depth, self._flat.device
+        if a.chain_bwd_table is None or a.chain_bwd_dy != dy.data_ptr():
+            from . import chain as _chain
+            M, E, I = a.B * self.n_tokens, self.emb_size, self.inner
+            if a.chain_bwd_table is None:
+                e = lambda *s, dt=a.cdtype: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+                a.du_blk = [e(M, 4 * E) for _ in range(D)]
+                a.dxmid_blk = [e(M, E) for _ in range(D)]
+                a.dqkv_blk = [e(M, 3 * I) for _ in range(D)]
+                a.dx_blk = [e(M, E) for _ in range(D)]
+                a.dattn_chain = e(M, I)
+                a.lnpart = torch.empty(D, 2, a.B, 2, E, device=dev, dtype=torch.float32)
+            blocks = (L.ChainBwdBlock * D)()
+            for i in range(D):
+                bp, ac = self._bparams[i], a.acts[i]
+                blocks[i] = L.ChainBwdBlock(
+                    self._chain_img_bwd.data_ptr() + i * _chain.BLOCK_ELEMS * 2, bp.ln1_g, bp.ln2_g, ac.x_in, ac.mean1, ac.rstd1,
+                    ac.qkv, ac.lse, ac.attn, ac.x_mid, ac.mean2, ac.rstd2, ac.u,
+                    dy.data_ptr() if i == D - 1 else a.dx_blk[i + 1].data_ptr(),
+                    a.du_blk[i].data_ptr(), a.dxmid_blk[i].data_ptr(), a.dqkv_blk[i].data_ptr(), a.dx_blk[i].data_ptr(),
+                    a.lnpart[i, 0].data_ptr(), a.lnpart[i, 1].data_ptr())
+            a.chain_bwd_table = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(dev)
+            a.chain_bwd_dy = dy.data_ptr()
+        rc = L.lib().rgbnm_vit_chain_bwd(C.byref(a.cfg), a.chain_bwd_table.data_ptr(), D, a.dattn_chain.data_ptr(), L.stream())
+        if rc == 1:
+            return False
+        L.check(rc, "vit_chain_bwd")
         return True
 
     # ---------------------------------------------------------------- arenas

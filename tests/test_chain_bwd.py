@@ -1,0 +1,72 @@
+"""The one-launch encoder backward (csrc/vit_chain_bwd.hip, option bwd_chain) against the per-operation backward kernels.
+
+Its phases are the bodies of those kernels (fused MLP backward, attention-output dX GEMM, attention backward, qkv dX GEMM with the
+LayerNorm backward) with the same arithmetic and summation order, fed by the same saved tensors, so every parameter gradient
+must come out with the SAME BITS at the bench batch (256 images: there one LayerNorm partial-sum panel of the per-operation
+kernels is one image, as in the chain kernel); at other batch sizes the LayerNorm parameter gradients are summed in a different
+panel grouping (fp32 rounding) and everything else stays bit-identical.  Reference values: the golden gradient norms of the
+reference model (g20, make_golden_r3.py) at B = 256.
+"""
+import numpy as np
+import pytest
+import torch
+
+import rgb_no_more_amd as rg
+from rgb_no_more_amd import lib as L
+from test_chain_fwd import build
+
+pytestmark = pytest.mark.gpu
+
+
+def step(m, y, c, tgt, bwd_chain):
+    L.lib().rgbnm_set_option(b"bwd_chain", 1 if bwd_chain else 0)
+    try:
+        m.train()
+        m.zero_grad()
+        logits = m(y, c)
+        loss = rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16)
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.float().cpu().numpy().copy() for n, p in m.named_parameters()}
+    finally:
+        L.lib().rgbnm_set_option(b"bwd_chain", 1)
+
+
+@pytest.mark.parametrize("depth,B", [(2, 256), (12, 256)])
+def test_same_bits_at_the_bench_batch(depth, B):
+    m, y, c, tgt = build(depth, B)
+    gc = step(m, y, c, tgt, True)
+    gp = step(m, y, c, tgt, False)
+    bad = [n for n in gp if not np.array_equal(gc[n], gp[n])]
+    assert not bad, (len(bad), bad[:6], [float(np.abs(gc[n] - gp[n]).max() / (np.abs(gp[n]).max() + 1e-30)) for n in bad[:6]])
+
+
+@pytest.mark.parametrize("depth,B", [(1, 2), (3, 5), (12, 64)])
+def test_other_batches(depth, B):
+    m, y, c, tgt = build(depth, B)
+    gc = step(m, y, c, tgt, True)
+    gp = step(m, y, c, tgt, False)
+    for n in gp:
+        if "lrnorm" in n and not n.startswith("classhead"):
+            d = np.abs(gc[n] - gp[n]).max() / (np.abs(gp[n]).max() + 1e-30)
+            assert d < 1e-5, (n, d)                 # a different grouping of the fp32 partial sums
+        else:
+            assert np.array_equal(gc[n], gp[n]), n
+
+
+def test_gradient_norms_vs_reference_golden(golden):
+    g = golden("g20_fullsize.npz")
+    m, y, c, tgt = build(12, 256)
+    gc = step(m, y, c, tgt, True)
+    gn = np.array([np.linalg.norm(gc[n].astype(np.float64).ravel()) for n, _ in m.named_parameters()])
+    rel = np.abs(gn - g["ti_d12_b256_gradnorms"]) / (g["ti_d12_b256_gradnorms"] + 1e-12)
+    print(f"grad-norm rel err vs the reference: median {np.median(rel):.3e} max {rel.max():.3e}")
+    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+
+
+def test_bit_reproducible():
+    m, y, c, tgt = build(4, 7)
+    a = step(m, y, c, tgt, True)
+    b = step(m, y, c, tgt, True)
+    for n in a:
+        np.testing.assert_array_equal(a[n], b[n])
