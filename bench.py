@@ -475,7 +475,17 @@ def main():
             return graph[1]
         opt.zero_grad(set_to_none=True)
         (my, mc), mt = data_part()
-        loss = model_part(my, mc, mt)
+        if world > 1 and graph is not None and use_graph:
+            # an eager step (rank 0's event-bracketed ones) inside the "graph replay, then one all-reduce" schedule must issue the
+            # SAME collective as the replaying ranks: no exchange from inside the backward, one all-reduce of the flat buffer after it
+            fs_, model._grad_sync = model._grad_sync, None
+            try:
+                loss = model_part(my, mc, mt)
+            finally:
+                model._grad_sync = fs_
+            exchange_after_replay()
+        else:
+            loss = model_part(my, mc, mt)
         opt.step()
         return loss
 
@@ -486,7 +496,14 @@ def main():
         torch.cuda.synchronize()
 
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < a.prewarm_sec:     # DVFS ramp: cold clocks cost up to 40 % on the first runs
+    while True:                                            # DVFS ramp: cold clocks cost up to 40 % on the first runs
+        go = time.perf_counter() - t_pre < a.prewarm_sec
+        if world > 1:                                      # every rank runs the SAME number of steps (each one holds collectives)
+            gf = torch.tensor([1 if go else 0], device=dev)
+            dist.all_reduce(gf, op=dist.ReduceOp.MIN)
+            go = gf.item() == 1
+        if not go:
+            break
         step()
         torch.cuda.synchronize()
     sync_schedule = None

@@ -301,8 +301,9 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_block_params* p, c
  * 3 heads, 196 tokens (JPEG-Ti); needs rgbnm_gelu_table_init on the device.  The residual stream, LayerNorm outputs, q and the
  * attention output stay in registers, K / V of one head in LDS; every tensor the backward reads (rgbnm_block_acts) is written
  * exactly as rgbnm_vit_block_fwd writes it, so rgbnm_vit_block_bwd runs unchanged behind it.
- * rgbnm_chain_block: one block's parameters and outputs (device pointers); the caller keeps an array of `depth` of them in
- *   DEVICE memory.  x_in of block 0 is the x0 argument; block i's x_out is block i + 1's input.
+ * rgbnm_chain_block: one block's parameters and outputs (device pointers); `blocks` is a HOST array of `depth` (<= 12) of them,
+ *   copied into the kernel's argument segment (no upload: the call may be captured into a HIP graph).  x_in of block 0 is the
+ *   x0 argument; block i's x_out is block i + 1's input.
  * wimg: the block's "chain image" -- its four weight matrices as they lie in LDS (rows permuted, 16-byte chunks swizzled,
  *   consumption order), rgbnm_chain_image_elems() bf16 elements, written per step by rgbnm_chain_gather(src = operand shadows,
  *   idx = constant int32 table built on the host: rgb-no-more_amd/chain.py documents the layout).
@@ -317,7 +318,7 @@ typedef struct rgbnm_chain_block {
 size_t rgbnm_chain_block_bytes(void);          /* sizeof(rgbnm_chain_block) as the library was built */
 long long rgbnm_chain_image_elems(void);       /* bf16 elements of one block's chain image */
 int rgbnm_chain_gather(const void* src, const int* idx, void* dst, long long n, void* stream);   /* dst[i] = src[idx[i]], bf16, n % 8 == 0 */
-int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* cfg, const void* blocks_dev, int depth, const void* x0, void* stream);
+int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* cfg, const rgbnm_chain_block* blocks, int depth, const void* x0, void* stream);
 
 /* ---- The data path of the whole encoder BACKWARD as ONE launch, one workgroup per image (csrc/vit_chain_bwd.hip) -----------
  * Reference: the backward of the same `depth` blocks as autograd runs it (models/plainvit.py:493-529).  For every block, last to
@@ -326,8 +327,8 @@ int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* cfg, const void* blocks_dev, int de
  * leaves du / dx_mid / dqkv / dx of EVERY block in the caller's buffers (operands of the weight-gradient GEMMs) and the
  * per-image partial sums of the LayerNorm parameter gradients in part2 / part1 ([B][2][192] each: d(gamma) | d(beta)); the caller
  * then runs rgbnm_vit_block_bwd_dw per block (any order), which launches the four weight-gradient GEMMs and submits the
- * reductions exactly as rgbnm_vit_block_bwd does.  blocks_dev: DEVICE array of `depth` rgbnm_chain_bwd_block; blk[i].dy must be
- * blk[i + 1].dx for i < depth - 1.  wimg: the backward chain image (rgb-no-more_amd/chain.py, from the TRANSPOSED operand
+ * reductions exactly as rgbnm_vit_block_bwd does.  blocks: HOST array of `depth` (<= 12) rgbnm_chain_bwd_block (copied into the
+ * kernel's argument segment); blk[i].dy must be blk[i + 1].dx for i < depth - 1.  wimg: the backward chain image (rgb-no-more_amd/chain.py, from the TRANSPOSED operand
  * shadows by rgbnm_chain_gather).  dattn: [B * 196, 192] scratch.  Returns RGBNM_OK, 1 = not eligible, negative = error. */
 typedef struct rgbnm_chain_bwd_block {
   const void* wimg;
@@ -339,7 +340,7 @@ typedef struct rgbnm_chain_bwd_block {
   float *part2, *part1;
 } rgbnm_chain_bwd_block;
 size_t rgbnm_chain_bwd_block_bytes(void);
-int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* cfg, const void* blocks_dev, int depth, void* dattn, void* stream);
+int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_chain_bwd_block* blocks, int depth, void* dattn, void* stream);
 /* The weight / bias / LayerNorm-parameter gradients of one block from what rgbnm_vit_chain_bwd left behind: the dW part of
  * rgbnm_vit_block_bwd (scratch->du / dx_mid / dqkv as filled by the chain kernel; dy = the block's output gradient). */
 int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* cfg, const rgbnm_block_acts* a, const rgbnm_block_grads* g,

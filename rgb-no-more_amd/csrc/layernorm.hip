@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
       }
     }
-    const float c1 = row_sum<LPR>(s1) * (1.f / E), c2 = row_sum<LPR>(s2) * (1.f / E);
+    float c1 = row_sum<LPR>(s1) * (1.f / E), c2 = row_sum<LPR>(s2) * (1.f / E);
+    asm volatile("" : "+v"(c1), "+v"(c2));       // as ln_bwd_rows.h: products, never contracted into ln_bwd_dx's subtraction
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const size_t off = (size_t)row * E + (v * LPR + l16) * 4;

@@ -94,7 +94,8 @@ struct LnBwdRows {
                        dg[v][4 + i], db[v][4 + i]);
           }
         }
-        const float c1 = group8_pair_sum(s1a, s1b) * (1.f / E), c2 = group8_pair_sum(s2a, s2b) * (1.f / E);
+        float c1 = group8_pair_sum(s1a, s1b) * (1.f / E), c2 = group8_pair_sum(s2a, s2b) * (1.f / E);
+        asm volatile("" : "+v"(c1), "+v"(c2));       // (products: never contracted into the subtractions of ln_bwd_dx, whatever the caller)
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
           bf16x8 ob;

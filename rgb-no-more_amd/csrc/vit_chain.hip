@@ -29,6 +29,7 @@
 // on the accumulator (one rounding instead of two) and the LayerNorm sums run in a different order -- results agree to bf16
 // rounding, not bit for bit (tests/test_chain_fwd.py compares with the per-operation kernels and with the reference golden).
 #include "common.h"
+#include <string.h>
 #include <type_traits>
 #include "internal.h"
 #include "../../include/rgbnm.h"
@@ -81,8 +82,9 @@ struct ChainBlk {            // = rgbnm_chain_block (rgbnm.h) with typed pointer
   bf16* gp; bf16* gl; bf16* x_out;       // gp = gelu'(u) (rgbnm_block_acts.u), gl = gelu(u)
 };
 static_assert(sizeof(ChainBlk) == sizeof(rgbnm_chain_block), "rgbnm_chain_block layout");
-struct ChainArgs {
-  const ChainBlk* blk; const bf16* x0;
+constexpr int MAX_DEPTH = 12;
+struct ChainArgs {            // passed BY VALUE (kernel argument segment): nothing to upload, safe inside a stream capture
+  ChainBlk blk[MAX_DEPTH]; const bf16* x0;
   int depth, nimg;
   float eps, scale;
   const unsigned* tab_img; int tab_pieces;
@@ -847,14 +849,15 @@ int rgbnm_chain_gather(const void* src, const int* idx, void* dst, long long n, 
 }
 
 // 1 = not eligible (the caller runs the blocks one by one)
-int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* c, const void* blk_table_dev, int depth, const void* x0, void* stream) {
-  if (!c || !blk_table_dev || !x0 || depth <= 0) return RGBNM_EINVAL;
-  if (c->dtype != RGBNM_DT_BF16 || c->E != E || c->heads != HEADS || c->N != NTOK || c->B < 1) return 1;
+int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* c, const rgbnm_chain_block* blocks, int depth, const void* x0, void* stream) {
+  if (!c || !blocks || !x0 || depth <= 0) return RGBNM_EINVAL;
+  if (c->dtype != RGBNM_DT_BF16 || c->E != E || c->heads != HEADS || c->N != NTOK || c->B < 1 || depth > MAX_DEPTH) return 1;
   const unsigned* img = nullptr;
   int A0 = 0, P1 = 0, N1 = 0, ndw = 0;
   if (rgbnm_gelu_table_query(&img, &A0, &P1, &N1, &ndw) != 1 || ndw * 4 > TAB_LIMIT) return 1;
   ChainArgs p;
-  p.blk = (const ChainBlk*)blk_table_dev; p.x0 = (const bf16*)x0; p.depth = depth; p.nimg = c->B;
+  memcpy(p.blk, blocks, sizeof(ChainBlk) * depth);
+  p.x0 = (const bf16*)x0; p.depth = depth; p.nimg = c->B;
   p.eps = c->ln_eps; p.scale = c->attn_scale;
   p.tab_img = img; p.tab_pieces = (ndw * 4 + 15) / 16;
   p.kneg = 0x00010001u * (unsigned)(0x8000 | N1);

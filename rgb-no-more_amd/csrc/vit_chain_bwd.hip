@@ -21,6 +21,7 @@
 //       backward as in M, whose staging tile hands the next block its dy
 // Weights come from a second chain image (transposed shadows, consumption order, LDS layout: rgb-no-more_amd/chain.py).
 #include "common.h"
+#include <string.h>
 #include <type_traits>
 #include "internal.h"
 #include "ln_bwd_rows.h"
@@ -67,8 +68,9 @@ struct BwdBlk {              // = rgbnm_chain_bwd_block (rgbnm.h) with typed poi
   float *part2, *part1;      // [nimg][2][192] partial sums of d(gamma), d(beta) of LN2 / LN1
 };
 static_assert(sizeof(BwdBlk) == sizeof(rgbnm_chain_bwd_block), "rgbnm_chain_bwd_block layout");
-struct BwdArgs {
-  const BwdBlk* blk; bf16* dattn;      // dattn: [M, 192] scratch shared by all blocks (written and read by the same workgroup)
+constexpr int MAX_DEPTH = 12;
+struct BwdArgs {              // passed BY VALUE (kernel argument segment): nothing to upload, safe inside a stream capture
+  BwdBlk blk[MAX_DEPTH]; bf16* dattn;      // dattn: [M, 192] scratch shared by all blocks (written and read by the same workgroup)
   int depth, nimg;
   float scale;
 };
@@ -787,11 +789,12 @@ extern "C" {
 size_t rgbnm_chain_bwd_block_bytes(void) { return sizeof(BwdBlk); }
 
 // 1 = not eligible
-int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* c, const void* blk_table_dev, int depth, void* dattn, void* stream) {
-  if (!c || !blk_table_dev || !dattn || depth <= 0) return RGBNM_EINVAL;
-  if (c->dtype != RGBNM_DT_BF16 || c->E != E || c->heads != HEADS || c->N != NTOK || c->B < 1) return 1;
+int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* c, const rgbnm_chain_bwd_block* blocks, int depth, void* dattn, void* stream) {
+  if (!c || !blocks || !dattn || depth <= 0) return RGBNM_EINVAL;
+  if (c->dtype != RGBNM_DT_BF16 || c->E != E || c->heads != HEADS || c->N != NTOK || c->B < 1 || depth > MAX_DEPTH) return 1;
   BwdArgs p;
-  p.blk = (const BwdBlk*)blk_table_dev; p.dattn = (bf16*)dattn; p.depth = depth; p.nimg = c->B; p.scale = c->attn_scale;
+  memcpy(p.blk, blocks, sizeof(BwdBlk) * depth);
+  p.dattn = (bf16*)dattn; p.depth = depth; p.nimg = c->B; p.scale = c->attn_scale;
   static DevOnce attr;
   if (attr.need()) {
     if (hipFuncSetAttribute((const void*)vit_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)

@@ -21,8 +21,12 @@ into .grad while a collective would still own it) -- use torch DDP for that.  A 
 collectives in flight; they are drained at the next forward (`begin_step`).  A frozen patch embedding (no last node) is
 refused at the forward.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_DEBUG = bool(os.environ.get("RGBNM_FLATSYNC_DEBUG"))
 
 
 class FlatGradSync:
@@ -86,6 +90,9 @@ class FlatGradSync:
         lo, hi = self._pending
         self._pending = None
         seg = self._gbuf[lo:hi]
+        if _DEBUG:
+            import sys
+            print(f"[flatsync r{dist.get_rank(self.pg)}] all_reduce #{self.collectives} [{lo}, {hi}) bucket {self.bucket_elems}", file=sys.stderr, flush=True)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         h = dist.all_reduce(seg, op=op, group=self.pg, async_op=True)
         self._handles.append((h, seg))

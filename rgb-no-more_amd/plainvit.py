@@ -174,7 +174,7 @@ class _Arena:
                                           self.dattn.data_ptr(), self.dqkv.data_ptr(), self.ws.data_ptr(), ws_bytes)
         self.ws_bytes = ws_bytes
         self.ws_blk = self.ws_head = self.hold_table = self.hold_table_host = self.scratch_blk = None      # allocated by the first held backward (_FwdState.begin_hold)
-        self.chain_table = None      # device array of rgbnm_chain_block, built by the first one-launch forward (ViT._chain_forward)
+        self.chain_table = None      # host array of rgbnm_chain_block, built by the first one-launch forward (ViT._chain_forward)
         self.chain_bwd_table = self.chain_bwd_dy = None     # the same for the backward (ViT._chain_backward: + per-block operand buffers)
         self.acts = []
         for i in range(D):
@@ -831,8 +831,8 @@ class ViT(FlatParamModule):
                                          bp.ln1_g, bp.ln1_b, bp.ln2_g, bp.ln2_b, bp.bqkv_perm, bp.bproj, bp.b1, bp.b2,
                                          ac.xn1, ac.mean1, ac.rstd1, ac.qkv, ac.lse, ac.attn, ac.x_mid, ac.xn2, ac.mean2, ac.rstd2,
                                          ac.u, ac.gl, ac.x_out)
-            a.chain_table = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(self._flat.device)
-        rc = L.lib().rgbnm_vit_chain_fwd(C.byref(a.cfg), a.chain_table.data_ptr(), self.depth, a.xbuf(0).data_ptr(), L.stream())
+            a.chain_table = blocks        # host array: the library copies it into the kernel's argument segment
+        rc = L.lib().rgbnm_vit_chain_fwd(C.byref(a.cfg), a.chain_table, self.depth, a.xbuf(0).data_ptr(), L.stream())
         if rc == 1:
             return False
         L.check(rc, "vit_chain_fwd")
@@ -864,9 +864,9 @@ class ViT(FlatParamModule):
                     dy.data_ptr() if i == D - 1 else a.dx_blk[i + 1].data_ptr(),
                     a.du_blk[i].data_ptr(), a.dxmid_blk[i].data_ptr(), a.dqkv_blk[i].data_ptr(), a.dx_blk[i].data_ptr(),
                     a.lnpart[i, 0].data_ptr(), a.lnpart[i, 1].data_ptr())
-            a.chain_bwd_table = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(dev)
+            a.chain_bwd_table = blocks
             a.chain_bwd_dy = dy.data_ptr()
-        rc = L.lib().rgbnm_vit_chain_bwd(C.byref(a.cfg), a.chain_bwd_table.data_ptr(), D, a.dattn_chain.data_ptr(), L.stream())
+        rc = L.lib().rgbnm_vit_chain_bwd(C.byref(a.cfg), a.chain_bwd_table, D, a.dattn_chain.data_ptr(), L.stream())
         if rc == 1:
             return False
         L.check(rc, "vit_chain_bwd")
