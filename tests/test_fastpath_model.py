@@ -23,6 +23,17 @@ from rgb_no_more_amd import lib as L
 from oracle import vit_torch as V
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def per_operation_kernels():
+    """This file is about the per-operation kernels: the one-launch encoder forward / backward (tests/test_chain_*.py) is off."""
+    lib = L.lib()
+    lib.rgbnm_set_option(b"fwd_chain", 0)
+    lib.rgbnm_set_option(b"bwd_chain", 0)
+    yield
+    lib.rgbnm_set_option(b"fwd_chain", 1)
+    lib.rgbnm_set_option(b"bwd_chain", 1)
 DEV = "cuda"
 
 CASES = {"ti_d2_b64": (192, 3, 2, 64, False), "ti_d12_b64": (192, 3, 12, 64, False), "s_d2_b64": (384, 6, 2, 64, False),

@@ -11,6 +11,17 @@ L = rg.lib
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def per_operation_kernels():
+    """This file is about the per-operation kernels: the one-launch encoder forward / backward (tests/test_chain_*.py) is off."""
+    lib = L.lib()
+    lib.rgbnm_set_option(b"fwd_chain", 0)
+    lib.rgbnm_set_option(b"bwd_chain", 0)
+    yield
+    lib.rgbnm_set_option(b"fwd_chain", 1)
+    lib.rgbnm_set_option(b"bwd_chain", 1)
+
+
 def _grads(m, y, c, tgt, cdt):
     m.zero_grad(set_to_none=True)
     logits = m(y, c)

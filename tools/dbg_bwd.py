@@ -18,7 +18,8 @@ def run(m, y, c, tgt, chain):
         return dict(du=f(arena.du_blk[0]), dx_mid=f(arena.dxmid_blk[0]), dattn=f(arena.dattn_chain), dqkv=f(arena.dqkv_blk[0]), dx=f(arena.dx_blk[0]))
     return dict(du=f(arena.du), dx_mid=f(arena.dx_mid), dattn=f(arena.dattn), dqkv=f(arena.dqkv), dx=f(arena.dx[0]), dx1=f(arena.dx[1]))
 
-m, y, c, tgt = build(1, 256)
+import sys as _s
+m, y, c, tgt = build(1, int(_s.argv[1]) if len(_s.argv) > 1 else 256)
 a = run(m, y, c, tgt, 1); b = run(m, y, c, tgt, 0)
 for k in a:
     ref = b[k]
