@@ -93,6 +93,19 @@ __device__ __forceinline__ Geo make_geo() {
   L.tr0 = (unsigned)((4 * L.g + k) * ROWB + pc * 16 + 8 * (l3 & 1));
   return L;
 }
+// The same from a lane id the optimiser cannot trace (common.h lane_id_here): every phase derives its per-lane constants anew, so
+// none of them is live -- or spilled -- across the register-heavy phases in between
+__device__ __forceinline__ Geo fresh_geo() {
+  Geo L;
+  L.lane = lane_id_here();
+  L.l31 = L.lane & 31;
+  L.g = L.lane >> 5;
+  L.fl = fswz(L.l31);
+  const int k = (L.lane >> 2) & 3, G1 = (L.lane >> 4) & 1, l3 = L.lane & 3;
+  const int pc = (2 * G1 + (l3 >> 1)) ^ (((k >> 1) << 2) | L.g);
+  L.tr0 = (unsigned)((4 * L.g + k) * ROWB + pc * 16 + 8 * (l3 & 1));
+  return L;
+}
 template <int T> struct TileLoop {
   template <typename F> static __device__ __forceinline__ void run(F&& f) {
     TileLoop<T - 1>::run(f);
@@ -297,7 +310,9 @@ constexpr int B_END = 53;               // 53: staging tile dead (dy fragments o
 template <int B0>
 __device__ __forceinline__ void ln_bwd_epilogue(unsigned char* smem, const f32x16 (&acc)[6], const bf16* X, const float* mean,
                                                 const float* rstd, const float* gamma, const bf16* R, bf16* DX, float* part,
-                                                int img, int tid, int rloc, int g, int ib) {
+                                                int img, int w, int ib) {
+  const int lane_ = lane_id_here();
+  const int tid = w * 64 + lane_, rloc = w * 32 + (lane_ & 31), g = lane_ >> 5;
   LnBwd lnb;
   lnb.request_x(X, E, mean, rstd, img * NTOK, NTOK, tid);
   lnb.request_res(R, E, img * NTOK, NTOK, tid);
@@ -319,8 +334,9 @@ __device__ __forceinline__ void ln_bwd_epilogue(unsigned char* smem, const f32x1
   wait_lds();
   BAR(B0 + 6);                            // dx rows are back in the tile
 }
-__device__ __forceinline__ void read_own_rows(const unsigned char* smem, int rloc, int g, Rows& x) {
-  const unsigned char* rp = smem + rloc * (CP * 2) + 16 * g;      // 8-byte aligned (pitch 392 B)
+__device__ __forceinline__ void read_own_rows(const unsigned char* smem, int w, Rows& x) {
+  const int lane_ = lane_id_here();
+  const unsigned char* rp = smem + (w * 32 + (lane_ & 31)) * (CP * 2) + 16 * (lane_ >> 5);      // 8-byte aligned (pitch 392 B)
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
     const u32x2 lo = *reinterpret_cast<const u32x2*>(rp + 32 * c), hi = *reinterpret_cast<const u32x2*>(rp + 32 * c + 8);
@@ -332,14 +348,12 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int img = blockIdx.x;
   if (img >= p.nimg) return;
-  const Geo L = make_geo();
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int depth = p.depth;
 
   if (w == NCW) {
     // ================================================================ DMA wave
-    const int lane = L.lane;
+    const int lane = threadIdx.x & 63;
     for (int ib = depth - 1; ib >= 0; --ib) {
       const BwdBlk& b = p.blk[ib];
       const unsigned char* wimg = reinterpret_cast<const unsigned char*>(b.wimg);
@@ -434,17 +448,15 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
   // ==================================================================== compute waves
   const int row0 = 32 * w;
   const int live = NTOK - row0 < 32 ? NTOK - row0 : 32;
-  const int rloc = row0 + L.l31;
   const size_t grow0 = (size_t)img * NTOK + row0;
-  const int fl = L.fl;
-  const int woff0 = L.l31 * (E * 2) + ((L.g ^ fl) << 4);
   const float LOG2E = 1.4426950408889634f;
   const float c2 = p.scale * LOG2E;
 
   Rows dyf;                                                       // dy rows of this lane's token as operand fragments
   {
-    const int tok = rloc < NTOK ? rloc : NTOK - 1;
-    const bf16* yrow = p.blk[depth - 1].dy + ((size_t)img * NTOK + tok) * E + 8 * L.g;
+    const int lane_ = lane_id_here();
+    const int rloc = row0 + (lane_ & 31), tok = rloc < NTOK ? rloc : NTOK - 1;
+    const bf16* yrow = p.blk[depth - 1].dy + ((size_t)img * NTOK + tok) * E + 8 * (lane_ >> 5);
 #pragma unroll
     for (int c = 0; c < 12; ++c) dyf.v[c] = *reinterpret_cast<const u32x4*>(yrow + 16 * c);
   }
@@ -458,10 +470,13 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[bt][r] = 0.f;
     {
+      const Geo L = fresh_geo();
+      const int fl = L.fl;
+      const int woff0 = L.l31 * (E * 2) + ((L.g ^ fl) << 4);
       const unsigned stg = (unsigned)(M_STG + w * 2 * TILE);      // tile 0: gelu' in, tile 1: du out
-      const int ln = lane_id_here();
       bf16x8 gpraw[4];
       auto load_gp = [&](int chunk) {
+        const int ln = lane_id_here();           // (row / segment addresses re-derived at every use: nothing to hoist and spill)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
@@ -472,10 +487,13 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       };
       load_gp(0);
       for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        {
+          const int ln = lane_id_here();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
-          *reinterpret_cast<bf16x8*>(smem + stg + row * ROWB + ((vec ^ (row & 7)) << 4)) = gpraw[i];
+          for (int i = 0; i < 4; ++i) {
+            const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+            *reinterpret_cast<bf16x8*>(smem + stg + row * ROWB + ((vec ^ (row & 7)) << 4)) = gpraw[i];
+          }
         }
         if (chunk + 1 < NCHUNK) load_gp(chunk + 1);
         wait_lds();
@@ -522,6 +540,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
         }
         // the chunk's du tile out as whole row pieces
         wait_lds();
+        const int ln = lane_id_here();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
@@ -531,11 +550,12 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       }
     }
     // ================================================================ d(x_mid) = dy + LN2'(dxn2)
-    ln_bwd_epilogue<B_E2>(smem, acc2, b.x_mid, b.mean2, b.rstd2, b.ln2_g, b.dy, b.dx_mid, b.part2, img, tid, rloc, L.g, ib);
+    ln_bwd_epilogue<B_E2>(smem, acc2, b.x_mid, b.mean2, b.rstd2, b.ln2_g, b.dy, b.dx_mid, b.part2, img, w, ib);
     // ================================================================ P: d(attention output) = d(x_mid) . Wproj
     {
+      const Geo L = fresh_geo();
       Rows dxf;
-      read_own_rows(smem, rloc, L.g, dxf);
+      read_own_rows(smem, w, dxf);
       wait_lds();
       BAR(B_P);
       const unsigned stg = (unsigned)(P_TILES + w * TILE);
@@ -571,8 +591,10 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       float* L2_s = reinterpret_cast<float*>(smem + A_L2);
       float* D_s = reinterpret_cast<float*>(smem + A_D);
       unsigned char* stg = smem + A_STG + w * STG_WAVE;
+      const Geo L = fresh_geo();
+      const int fl = L.fl;
       const unsigned rb0 = (unsigned)(L.l31 * ROWB + ((L.g ^ fl) << 4));
-      const int row = rloc;
+      const int row = row0 + L.l31;
       u32x4 qraw[4], graw[4], oraw[4];
       float lq = 0.f;
       const bf16* qkv0 = b.qkv + (size_t)img * NTOK * LDQ;
@@ -760,6 +782,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       for (int r = 0; r < 16; ++r) accx[bt][r] = 0.f;
     for (int j = 0; j < 9; ++j) {
       BAR(B_X + j);
+      const Geo L = fresh_geo();
+      const int fl = L.fl;
       const int set = j % 3;
       const unsigned wo = opaque((unsigned)(X_SLOTS + set * SLOT + L.l31 * ROWB + ((L.g ^ fl) << 4)));
       const unsigned to = opaque((unsigned)(X_TILES + set * X_TSET + w * TILE + L.l31 * ROWB + ((L.g ^ (L.l31 & 7)) << 4)));
@@ -775,14 +799,20 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       }
     }
     // ================================================================ dx = d(x_mid) + LN1'(dxn1); the next block's dy
-    ln_bwd_epilogue<B_E1>(smem, accx, b.x_in, b.mean1, b.rstd1, b.ln1_g, b.dx_mid, b.dx, b.part1, img, tid, rloc, L.g, ib);
-    read_own_rows(smem, rloc, L.g, dyf);
+    ln_bwd_epilogue<B_E1>(smem, accx, b.x_in, b.mean1, b.rstd1, b.ln1_g, b.dx_mid, b.dx, b.part1, img, w, ib);
+    read_own_rows(smem, w, dyf);
     wait_lds();
     BAR(B_END);
   }
 }
 
 }  // namespace
+
+#ifdef CHAINB_PROF
+extern "C" int rgbnm_chainb_prof_read(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chainb_prof), sizeof(unsigned long long) * 8 * 8 * 128) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" {
 
