@@ -554,14 +554,21 @@ def main():
         use_graph = best[3]
         sync_schedule = best[1]
     TAG_NT = 1
+    # every traced kernel class: (tag, key in profiles/pmc_traffic*.json, description)
+    TRACED = ((6, "chain_bwd", "vit_chain_bwd_kernel: the data path of the whole encoder backward, one launch, one workgroup per image"),
+              (5, "chain_fwd", "vit_chain_fwd_kernel: the whole encoder forward, one launch, one workgroup per image"),
+              (2, "gemm_tn", "gemm_tn_pipe: the four weight-gradient GEMMs of a block as one grouped launch"),
+              (1, "gemm_nt", "gemm_nt family (gemm_nt_wres / gemm_nt_kpipe / gemm_nt / fused MLP: nn.Linear forward + dX GEMMs with their fused epilogues)"))
+    TRACE_MASK = sum(1 << t for t, _, _ in TRACED)
     trace_on = (not a.no_trace) and rank == 0
     for i in range(a.warmup):
         if trace_on and i == 0:            # fill the library's event pool outside the timed region
-            lib.rgbnm_set_option(b"trace", 1 << TAG_NT)
+            lib.rgbnm_set_option(b"trace", TRACE_MASK)
         step(eager=trace_on and i == 0)
         if trace_on and i == 0:
             lib.rgbnm_set_option(b"trace", 0)
-            lib.rgbnm_trace_collect(TAG_NT, None, None, None, None)
+            for t_, _, _ in TRACED:
+                lib.rgbnm_trace_collect(t_, None, None, None, None)
     traced_steps = 0
     barrier()
     t0 = time.perf_counter()
@@ -570,7 +577,7 @@ def main():
         # ~200 event records per traced step, below 1 % of the timed region)
         tr = trace_on and (i % 8 == 0)
         if tr:
-            lib.rgbnm_set_option(b"trace", 1 << TAG_NT)
+            lib.rgbnm_set_option(b"trace", TRACE_MASK)
             traced_steps += 1
         loss = step(eager=tr)
         if tr:
@@ -588,30 +595,45 @@ def main():
         peak = MFMA_PEAK[a.dtype]
         step_tflops = value / world * FLOP_PER_IMG[a.arch] / 1e12
         roof = None
+        roof_all = []
         if not a.no_trace:
-            tms, fl, by, cnt = C.c_double(), C.c_double(), C.c_double(), C.c_int()
-            L.check(lib.rgbnm_trace_collect(TAG_NT, C.byref(tms), C.byref(fl), C.byref(by), C.byref(cnt)))
-            if cnt.value:
+            # HBM bytes per launch from the PMC counters cannot be read inside this process: they come from separate
+            # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools/gpu.sh pass, corrected as
+            # MI355X_MICROARCH.md prescribes) whose summary is committed under profiles/
+            tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.arch}.json")
+            if not os.path.exists(tpath) and a.arch == "vitti":
+                tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            tjs = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            # attainable peaks measured on an MI355X box by tools/calib.py (nominal peaks are what `frac` is priced against)
+            attain = None
+            for cal in ("r04_calibration.json", "r01_calibration.json"):
+                cpath = os.path.join(ROOT, "profiles", cal)
+                if os.path.exists(cpath):
+                    cj = json.load(open(cpath))
+                    attain = {"hbm_copy_GBs": cj.get("hbm_copy_GBps[1 GiB]"), "hbm_read_GBs": cj.get("hbm_read_GBps[1 GiB]"),
+                              "hbm_write_GBs": cj.get("hbm_write_GBps[1 GiB]"),
+                              "mfma_bf16_TFLOPs": cj.get("mfma_bf16_tflops[1 workgroup (4 waves) per CU]"), "source": "profiles/" + cal}
+                    break
+            for tag, key, desc in TRACED:
+                tms, fl, by, cnt = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+                L.check(lib.rgbnm_trace_collect(tag, C.byref(tms), C.byref(fl), C.byref(by), C.byref(cnt)))
+                if not cnt.value:
+                    continue
                 sec = tms.value / 1e3
                 gbs, tfs = by.value / sec / 1e9, fl.value / sec / 1e12
-                # HBM bytes per launch from the PMC counters cannot be read inside this process: they come from separate
-                # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools/gpu.sh pass,
-                # corrected as MI355X_MICROARCH.md prescribes) whose summary is committed under profiles/
-                traffic, traffic_src = None, None
-                tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.arch}.json")
-                if not os.path.exists(tpath) and a.arch == "vitti":
-                    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get("gemm_nt_bytes_per_launch")
-                    traffic_src = os.path.relpath(tpath, ROOT) + " (separate --pmc passes of this command)"
-                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "gemm_nt family (gemm_nt_wres / gemm_nt_kpipe / gemm_nt: all nn.Linear forward + dX GEMMs with their fused epilogues; largest share of step time)",
-                        "launches_per_step": cnt.value // max(1, traced_steps), "traced_steps": traced_steps,
-                        "avg_launch_us": round(1e3 * tms.value / cnt.value, 2),
-                        "algorithmic_bytes_per_launch": round(by.value / cnt.value),
-                        "algorithmic_flops_per_launch": round(fl.value / cnt.value),
-                        "kernel_tflops": round(tfs, 1), "kernel_mfma_frac": round(tfs / peak, 4)}
+                traffic = tjs.get(key + "_bytes_per_launch")
+                roof_all.append({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                 "traffic_source": (os.path.relpath(tpath, ROOT) + " (separate --pmc passes of this command)") if traffic else None,
+                                 "kernel": desc, "launches_per_step": cnt.value // max(1, traced_steps), "traced_steps": traced_steps,
+                                 "avg_launch_us": round(1e3 * tms.value / cnt.value, 2),
+                                 "us_per_step": round(1e3 * tms.value / max(1, traced_steps), 1),
+                                 "algorithmic_bytes_per_launch": round(by.value / cnt.value),
+                                 "algorithmic_flops_per_launch": round(fl.value / cnt.value),
+                                 "kernel_tflops": round(tfs, 1), "kernel_mfma_frac": round(tfs / peak, 4),
+                                 "attainable_peaks_measured": attain})
+            roof_all.sort(key=lambda r: -r["us_per_step"])
+            roof = roof_all[0] if roof_all else None       # the dominant kernel (largest share of the step)
         out = {
             "metric": f"images/sec {NAMES[a.arch]} DCT 512x512 train step",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -631,6 +653,7 @@ def main():
             "mfma_pct_whole_step": round(100 * step_tflops / peak, 2),
             "step_tflops_per_gpu": round(step_tflops, 1),
             "roofline": roof,
+            "roofline_kernels": roof_all[1:],            # the other traced kernel classes, by time per step
         }
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(a.arch, a.cpu_baseline_images)

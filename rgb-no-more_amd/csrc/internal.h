@@ -30,8 +30,9 @@ int rgbnm_launch_attn_proj_fwd(const void* qkv, void* out, float* lse, const voi
                                const float* gamma, const float* beta, void* Y2, float* mean, float* rstd, float eps, int B, int N,
                                int heads, float scale, hipStream_t st);
 
-// per-kernel HIP-event tracing (vit.hip); tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd
-enum { TR_NT = 1, TR_TN = 2, TR_ATTN_FWD = 3, TR_ATTN_BWD = 4 };
+// per-kernel HIP-event tracing (vit.hip); tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd, 5 / 6 the one-launch encoder
+// forward / backward (vit_chain.hip, vit_chain_bwd.hip)
+enum { TR_NT = 1, TR_TN = 2, TR_ATTN_FWD = 3, TR_ATTN_BWD = 4, TR_CHAIN_FWD = 5, TR_CHAIN_BWD = 6 };
 // Weight-resident K = 192 bf16 NT GEMM (gemm_nt_wres.hip).  Returns RGBNM_OK / error, or 1 if the shape is not eligible.
 int rgbnm_launch_nt_wres(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                          const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st);

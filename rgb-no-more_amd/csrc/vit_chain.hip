@@ -871,7 +871,14 @@ int rgbnm_vit_chain_fwd(const rgbnm_vit_cfg* c, const rgbnm_chain_block* blocks,
       return RGBNM_ELAUNCH;
     attr.done();
   }
+  // algorithmic work per block and image: 0.20292 GFLOP; bytes that must cross HBM: the twelve saved tensors
+  // (xn1, qkv, attn, x_mid, xn2, gelu, gelu', x_out: (5 * 192 + 576 + 2 * 768) bf16 per token + statistics) and the weights once
+  const double tok = (double)c->B * NTOK;
+  const double flops = depth * tok * 2.0 * (E * 3.0 * INNER + 2.0 * NTOK * INNER + INNER * E + 2.0 * E * HID);
+  const double bytes = depth * (tok * ((5.0 * E + 3.0 * INNER + 2.0 * HID) * 2.0 + 4 * 4 + HEADS * 4) + 12.0 * SLOT + 12.0 * STAGE) + tok * E * 2.0;
+  const int slot = rgbnm_trace_begin(TR_CHAIN_FWD, flops, bytes, (hipStream_t)stream);
   hipLaunchKernelGGL(vit_chain_fwd_kernel, dim3(c->B), dim3(NTHREADS), SMEM, (hipStream_t)stream, p);
+  rgbnm_trace_end(slot, (hipStream_t)stream);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

@@ -42,6 +42,7 @@ pass)
   if [ "$2" != "notests" ]; then
     timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $OUT/pytest.log; tail -3 $OUT/pytest.log
   fi
+  timeout 200 python tools/calib.py > $OUT/calibration.json 2>/dev/null; cat $OUT/calibration.json
   timeout 400 python bench.py --steps 100 --warmup 10 > $OUT/bench_line.json 2> $OUT/bench.err; cat $OUT/bench_line.json
   kstats $OUT
   timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-sec 0 --no-cpu-baseline --no-trace --no-graph --no-parity-check > $OUT/pmc_mfma.log 2>&1

@@ -18,7 +18,7 @@ import sys
 import pandas as pd
 
 PEAK = 2.5e15
-CLASSES = (("mlp_fused", r"mlp_fwd_kernel|mlp_bwd_kernel"), ("gemm_nt", r"gemm_nt_"), ("gemm_tn", r"gemm_tn_"), ("attn_fwd", r"attn[23]_fwd"), ("attn_bwd", r"attn[23]_bwd"),
+CLASSES = (("chain_fwd", r"vit_chain_fwd_kernel"), ("chain_bwd", r"vit_chain_bwd_kernel"), ("mlp_fused", r"mlp_fwd_kernel|mlp_bwd_kernel"), ("gemm_nt", r"gemm_nt_"), ("gemm_tn", r"gemm_tn_"), ("attn_fwd", r"attn[23]_fwd"), ("attn_bwd", r"attn[23]_bwd"),
            ("layernorm", r"ln_|layernorm|pool_"), ("augment", r"dct_"), ("embed", r"subblock|embed"),
            ("tail", r"adamw|sqnorm|softxent|mixup|prep_|reduce_"))
 

@@ -18,7 +18,7 @@ def load(d):
 def main(fetch_dir, write_dir, out):
     f, w = load(fetch_dir), load(write_dir)
     res = {}
-    for key, pat in (("gemm_nt", "gemm_nt_|mlp_fwd_kernel|mlp_bwd_kernel"), ("gemm_tn", "gemm_tn_pipe_kernel"), ("attn_fwd", "attn[23]_fwd_kernel"),
+    for key, pat in (("chain_fwd", "vit_chain_fwd_kernel"), ("chain_bwd", "vit_chain_bwd_kernel"), ("gemm_nt", "gemm_nt_|mlp_fwd_kernel|mlp_bwd_kernel"), ("gemm_tn", "gemm_tn_pipe_kernel"), ("attn_fwd", "attn[23]_fwd_kernel"),
                      ("attn_bwd", "attn[23]_bwd_kernel"), ("dct_resize", "dct_resize_kernel"), ("dct_randaug", "dct_randaug_kernel"),
                      ("subblock_embed", "subblock_embed_kernel"), ("reduce_table", "reduce_table_kernel"), ("window_attn", "win_attn|window_attention")):
         ff = f[f.Kernel_Name.str.contains(pat) & (f.Counter_Name == "FETCH_SIZE")]
