@@ -345,6 +345,12 @@ int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* cfg, const rgbnm_chain_bwd_block* b
  * rgbnm_vit_block_bwd (scratch->du / dx_mid / dqkv as filled by the chain kernel; dy = the block's output gradient). */
 int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* cfg, const rgbnm_block_acts* a, const rgbnm_block_grads* g,
                            const rgbnm_block_scratch* s, const void* dy, const float* part2, const float* part1, void* stream);
+/* The same for n <= 12 blocks in ONE grouped weight-gradient launch (arrays of n pointers; every block with its own workspace
+ * scratch[i]->ws): the 4 n GEMMs share the 256 workgroups, so the token axis is split 256 / (21 n) ways instead of 12 -- all twelve
+ * blocks of JPEG-Ti: no split, no fp32 partial sums to write and re-read. */
+int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* cfg, int n, const rgbnm_block_acts* const* a, const rgbnm_block_grads* const* g,
+                            const rgbnm_block_scratch* const* s, const void* const* dy, const float* const* part2,
+                            const float* const* part1, void* stream);
 
 /* Table GELU of the bf16 path (csrc/mlp_fused.hip): in bf16 mode the pre-activation is rounded to bf16 before the GELU
  * (models/plainvit.py:487-488 under autocast), so gelu / gelu' are functions of 16 bits.  _init is a SET-UP call (it

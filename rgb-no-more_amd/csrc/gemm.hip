@@ -535,14 +535,15 @@ int submit_tn_reduce(const GemmTN& p, float* dW, float* db, int S, int perm_head
 // deferred (grouped) weight-gradient launches
 struct TnPending { GemmTN p; float* dW; float* db; int perm_heads, accumulate; };
 thread_local bool g_tn_defer = false;     // per host thread, like the reduction queue (reduce.hip)
-thread_local TnPending g_tn_q[4];
-thread_local int g_tn_n = 0;
+constexpr int TN_QMAX = 48;
+thread_local TnPending g_tn_q[TN_QMAX];
+thread_local int g_tn_n = 0, g_tn_cap = 4;
 
 int tn_flush(hipStream_t st) {
   const int n = g_tn_n;
   g_tn_n = 0;
   if (!n) return RGBNM_OK;
-  RgbnmTnJob jobs[4];
+  RgbnmTnJob jobs[TN_QMAX];
   for (int i = 0; i < n; ++i) {
     const GemmTN& p = g_tn_q[i].p;
     jobs[i].dY = p.dY; jobs[i].X = p.X; jobs[i].part = p.part; jobs[i].bpart = g_tn_q[i].db ? p.bpart : nullptr;
@@ -577,7 +578,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
     if (g_tn_defer && tn_groupable(p)) {
       if (g_tn_n && g_tn_q[0].p.M != p.M) { const int rf = tn_flush(st); if (rf != RGBNM_OK) return rf; }
       g_tn_q[g_tn_n++] = TnPending{p, dW, db, perm_heads, accumulate};
-      return g_tn_n == 4 ? tn_flush(st) : RGBNM_OK;
+      return g_tn_n == g_tn_cap ? tn_flush(st) : RGBNM_OK;
     }
     if (rgbnm_get_option("tn_pipe")) {
       int Sp = 0;
@@ -670,9 +671,11 @@ __global__ void gather_bias_kernel(const rgbnm_linear_desc* __restrict__ descs, 
 
 }  // namespace
 
-void rgbnm_tn_defer_begin() { g_tn_defer = true; }
+void rgbnm_tn_defer_begin() { g_tn_defer = true; g_tn_cap = 4; }
+void rgbnm_tn_defer_begin_n(int max_jobs) { g_tn_defer = true; g_tn_cap = max_jobs < 1 ? 1 : (max_jobs > TN_QMAX ? TN_QMAX : max_jobs); }
 int rgbnm_tn_defer_flush(hipStream_t st) {
   g_tn_defer = false;
+  g_tn_cap = 4;
   return tn_flush(st);
 }
 

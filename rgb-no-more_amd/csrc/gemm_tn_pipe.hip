@@ -37,14 +37,19 @@ struct TnPipe {
   int ldy, ldx, M, No, Ki, S, kt_per_split, rtiles, ctiles;
 };
 
-// Up to 4 weight-gradient GEMMs over the same token axis share one launch: with T tiles in total every job is split
+// Several weight-gradient GEMMs over the same token axis share one launch: with T tiles in total every job is split
 // S = 256 / T ways, so the fp32 partials (S x No x Ki per job: the traffic that bounds these kernels next to the operand
-// reads) shrink with the number of jobs grouped, and the write burst at the end of the launch happens once.
-constexpr int TN_MAXJOBS = 4;
+// reads) shrink with the number of jobs grouped, and the write burst at the end of the launch happens once.  The four GEMMs of
+// one block (21 tiles) give S = 12; the 48 of all twelve blocks behind the one-launch backward (vit_chain_bwd.hip) 252 tiles and
+// S = 1: no split at all.
+constexpr int TN_MAXJOBS = 48;
+struct TnJobK {                   // per job, in the kernel argument segment
+  const bf16* dY; const bf16* X; float* part; float* bpart;
+  int ldy, ldx, No, Ki, ctiles, tile_end;       // tile_end: running sum of rtiles * ctiles
+};
 struct TnGroup {
-  TnPipe j[TN_MAXJOBS];
-  int tile_end[TN_MAXJOBS];       // running sum of rtiles * ctiles
-  int njobs, S, tiles;
+  TnJobK j[TN_MAXJOBS];
+  int njobs, S, tiles, M, kt_per_split;
 };
 
 __device__ __forceinline__ bf16x8 pack8(u32x2 lo, u32x2 hi) {
@@ -86,12 +91,14 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   if (u >= grp.S * grp.tiles) return;
   const int s = u / grp.tiles;
   int tile = u % grp.tiles, job = 0;
-  while (tile >= grp.tile_end[job]) ++job;
-  if (job) tile -= grp.tile_end[job - 1];
-  TnPipe p = grp.j[0];             // uniform selects (no dynamic indexing of the kernel argument)
-  if (job == 1) p = grp.j[1];
-  if (job == 2) p = grp.j[2];
-  if (job == 3) p = grp.j[3];
+  while (tile >= grp.j[job].tile_end) ++job;          // (uniform: scalar loads from the argument segment)
+  if (job) tile -= grp.j[job - 1].tile_end;
+  TnPipe p;
+  {
+    const TnJobK& q = grp.j[job];
+    p.dY = q.dY; p.X = q.X; p.part = q.part; p.bpart = q.bpart; p.ldy = q.ldy; p.ldx = q.ldx; p.No = q.No; p.Ki = q.Ki;
+    p.ctiles = q.ctiles; p.M = grp.M; p.S = grp.S; p.kt_per_split = grp.kt_per_split; p.rtiles = 0;
+  }
   const int rt = tile / p.ctiles, ct = tile % p.ctiles;
   const int r0 = rt * 128, c0 = ct * 192;
   const int kt0 = s * p.kt_per_split;
@@ -395,13 +402,16 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   for (int i = 0; i < n; ++i) {
     const RgbnmTnJob& j = jobs[i];
     if (j.M != jobs[0].M) return 1;
-    if (tn_fill(g.j[i], j.dY, j.ldy, j.X, j.ldx, j.part, j.bpart, j.M, j.No, j.Ki, false)) return 1;
-    tiles += g.j[i].rtiles * g.j[i].ctiles;
-    g.tile_end[i] = tiles;
+    TnPipe t;
+    if (tn_fill(t, j.dY, j.ldy, j.X, j.ldx, j.part, j.bpart, j.M, j.No, j.Ki, false)) return 1;
+    tiles += t.rtiles * t.ctiles;
+    TnJobK& q = g.j[i];
+    q.dY = t.dY; q.X = t.X; q.part = t.part; q.bpart = t.bpart; q.ldy = t.ldy; q.ldx = t.ldx; q.No = t.No; q.Ki = t.Ki;
+    q.ctiles = t.ctiles; q.tile_end = tiles;
     flops += 2.0 * j.M * (double)j.No * j.Ki;
     bytes += ((double)j.M * j.No + (double)j.M * j.Ki) * 2.0 + (double)j.No * j.Ki * 4.0;
   }
-  for (int i = n; i < TN_MAXJOBS; ++i) { g.j[i] = g.j[0]; g.tile_end[i] = tiles; }
+  for (int i = n; i < TN_MAXJOBS; ++i) { g.j[i] = g.j[0]; g.j[i].tile_end = tiles; }
   if (tiles > 256) return 1;
   const int ktiles = jobs[0].M / TK;
   // one workgroup per CU (120 KB LDS) and at most 256 of them: a 257th would wait for a whole first round
@@ -410,8 +420,7 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   if (S > ktiles) S = ktiles;
   const int kt_per = cdiv(ktiles, S);
   S = cdiv(ktiles, kt_per);
-  for (int i = 0; i < TN_MAXJOBS; ++i) { g.j[i].S = S; g.j[i].kt_per_split = kt_per; }
-  g.njobs = n; g.S = S; g.tiles = tiles;
+  g.njobs = n; g.S = S; g.tiles = tiles; g.M = jobs[0].M; g.kt_per_split = kt_per;
   *S_out = S;
   const int slot = rgbnm_trace_begin(TR_TN, flops, bytes, st);
   hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(256), dim3(512), SMEM, st, g);

@@ -14,6 +14,7 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
 // Queue the eligible bf16 rgbnm_gemm_tn calls that follow and run them as one grouped launch at flush (or when 4 are
 // queued); their partial reductions are submitted at flush.  Used by rgbnm_vit_block_bwd to pair fc2/fc1 and proj/qkv.
 void rgbnm_tn_defer_begin();
+void rgbnm_tn_defer_begin_n(int max_jobs);     // the same with room for up to max_jobs (<= 48) jobs per launch: the GEMMs of several blocks
 int rgbnm_tn_defer_flush(hipStream_t st);
 int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
                          int Ki, int* S_out, hipStream_t st);

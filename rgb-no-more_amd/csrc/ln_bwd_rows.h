@@ -56,12 +56,14 @@ struct LnBwdRows {
   // barrier that completes the tile.  red: RED_BYTES of LDS scratch that does not overlap Cs.  Contains two __syncthreads.
   __device__ __forceinline__ void run(const bf16* Cs, int cp, bf16* __restrict__ C, int ldc, const float* __restrict__ gamma,
                                       bool has_res, float* __restrict__ part, int panel, float* red, int m0, int rows, int tid) {
-    run(Cs, cp, C, ldc, gamma, has_res, part, panel, red, m0, rows, tid, nullptr, [](int) { __syncthreads(); });
+    run<false>(Cs, cp, C, ldc, gamma, has_res, part, panel, red, m0, rows, tid, nullptr, [](int) { __syncthreads(); });
   }
   // The same with (i) wb != null: every dx row is also written back into the staging tile (pitch cp, same pieces), from which a
   // persistent caller takes its rows as operand fragments; (ii) the four workgroup barriers of the column sums supplied by the
   // caller (bar(0) .. bar(3)): a workgroup with a non-participating wave must let that wave mirror them (vit_chain_bwd.hip).
-  template <typename BarF>
+  // (iii) SPLIT2: the column sums of a pass are taken by 384 threads -- two per column, even / odd row groups, combined by
+  // one lane exchange -- instead of 192 walking all 56 groups (fp32 sums in a different order than the other callers').
+  template <bool SPLIT2 = false, typename BarF>
   __device__ __forceinline__ void run(const bf16* Cs, int cp, bf16* __restrict__ C, int ldc, const float* __restrict__ gamma,
                                       bool has_res, float* __restrict__ part, int panel, float* red, int m0, int rows, int tid,
                                       bf16* wb, BarF&& bar) {
@@ -123,11 +125,23 @@ struct LnBwdRows {
           *reinterpret_cast<f32x4*>(red + grp * (E + 4) + v * 64 + l8 * 8 + hf * 4) = q;
         }
       bar(2 * pass + 1);
-      for (int e = tid; e < E; e += NT) {
-        float a = 0.f;
+      if constexpr (SPLIT2) {
+        static_assert(GROUPS % 2 == 0 && NT >= 2 * E, "two threads per column");
+        if (tid < 2 * E) {
+          const int e = tid >> 1, q = tid & 1;
+          float a = 0.f;
+#pragma unroll 7
+          for (int r = 0; r < GROUPS / 2; ++r) a += red[(2 * r + q) * (E + 4) + e];
+          a += lane_xor1(a);
+          if (q == 0) part[((size_t)panel * 2 + pass) * E + e] = a;
+        }
+      } else {
+        for (int e = tid; e < E; e += NT) {
+          float a = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < GROUPS; ++r) a += red[r * (E + 4) + e];
-        part[((size_t)panel * 2 + pass) * E + e] = a;
+          for (int r = 0; r < GROUPS; ++r) a += red[r * (E + 4) + e];
+          part[((size_t)panel * 2 + pass) * E + e] = a;
+        }
       }
     }
   }

@@ -286,43 +286,58 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   return rc != RGBNM_OK ? rc : (rt != RGBNM_OK ? rt : rf);
 }
 
-// The weight / bias / LayerNorm-parameter gradients of one block after rgbnm_vit_chain_bwd (vit_chain_bwd.hip) has run its data
-// path: the four weight-gradient GEMMs as ONE grouped launch and the batched reduction, as rgbnm_vit_block_bwd issues them.
-int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* c, const rgbnm_block_acts* a, const rgbnm_block_grads* g,
-                           const rgbnm_block_scratch* s, const void* dy, const float* part2, const float* part1, void* st) {
-  if (!c || !a || !g || !s || !dy || !part2 || !part1) return RGBNM_EINVAL;
+// The weight / bias / LayerNorm-parameter gradients of n blocks after rgbnm_vit_chain_bwd (vit_chain_bwd.hip) has run their data
+// path: ALL their weight-gradient GEMMs as one grouped launch (4 n jobs, 21 n tiles: the more blocks, the fewer token splits
+// -- twelve blocks: 252 tiles, no split) and the batched reduction.  Every block brings its own workspace (scratch->ws).
+int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* c, int n, const rgbnm_block_acts* const* a, const rgbnm_block_grads* const* g,
+                            const rgbnm_block_scratch* const* s, const void* const* dy, const float* const* part2,
+                            const float* const* part1, void* st) {
+  if (!c || n < 1 || n > 12 || !a || !g || !s || !dy || !part2 || !part1) return RGBNM_EINVAL;
   const int dt = c->dtype, M = c->B * c->N, E = c->E, I = c->heads * 64;
   size_t off[7];
-  if (s->ws_bytes < block_ws_offsets(M, E, I, off)) return RGBNM_EWORKSPACE;
-  char* wsb = (char*)s->ws;
-#define WS(i) (wsb + off[i]), (off[(i) + 1] - off[i])
+  const size_t need = block_ws_offsets(M, E, I, off);
+  for (int i = 0; i < n; ++i) {
+    if (!a[i] || !g[i] || !s[i] || !dy[i] || !part2[i] || !part1[i]) return RGBNM_EINVAL;
+    if (s[i]->ws_bytes < need) return RGBNM_EWORKSPACE;
+    for (int k = 0; k < i; ++k)
+      if (s[k]->ws == s[i]->ws) return RGBNM_EINVAL;          // the partial sums of the grouped blocks live side by side
+  }
   rgbnm_reduce_defer_begin();
   const int rc = [&]() -> int {
     const int group = rgbnm_get_option("tn_group");
-    if (group) rgbnm_tn_defer_begin();
-    TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
-    TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, WS(1), st));
-    if (group == 1) { TRY(rgbnm_tn_defer_flush((hipStream_t)st)); rgbnm_tn_defer_begin(); }
-    TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, WS(2), st));
-    TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
+    if (group) rgbnm_tn_defer_begin_n(group == 1 ? 2 : 4 * n);
+    for (int i = 0; i < n; ++i) {
+      char* wsb = (char*)s[i]->ws;
+#define WS(k) (wsb + off[k]), (off[(k) + 1] - off[k])
+      TRY(rgbnm_gemm_tn(dt, dy[i], E, a[i]->gl, 4 * E, g[i]->dw2, g[i]->db2, M, E, 4 * E, 0, 0, WS(0), st));
+      TRY(rgbnm_gemm_tn(dt, s[i]->du, 4 * E, a[i]->xn2, E, g[i]->dw1, g[i]->db1, M, 4 * E, E, 0, 0, WS(1), st));
+      TRY(rgbnm_gemm_tn(dt, s[i]->dx_mid, E, a[i]->attn, I, g[i]->dwproj, g[i]->dbproj, M, E, I, 0, 0, WS(2), st));
+      TRY(rgbnm_gemm_tn(dt, s[i]->dqkv, 3 * I, a[i]->xn1, E, g[i]->dwqkv, g[i]->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
+#undef WS
+    }
     if (group) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
-    // per-image partial sums of the LayerNorm parameter gradients (one panel per image)
-    RgbnmReduceJob j;
-    j.stride = 2LL * E; j.n = E; j.S = c->B; j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
-    j.part = part2; j.out = g->dln2_g;
-    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
-    j.part = part2 + E; j.out = g->dln2_b;
-    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
-    j.part = part1; j.out = g->dln1_g;
-    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
-    j.part = part1 + E; j.out = g->dln1_b;
-    TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+    for (int i = 0; i < n; ++i) {       // per-image partial sums of the LayerNorm parameter gradients (one panel per image)
+      RgbnmReduceJob j;
+      j.stride = 2LL * E; j.n = E; j.S = c->B; j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
+      j.part = part2[i]; j.out = g[i]->dln2_g;
+      TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+      j.part = part2[i] + E; j.out = g[i]->dln2_b;
+      TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+      j.part = part1[i]; j.out = g[i]->dln1_g;
+      TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+      j.part = part1[i] + E; j.out = g[i]->dln1_b;
+      TRY(rgbnm_reduce_submit(j, (hipStream_t)st));
+    }
     return RGBNM_OK;
   }();
-#undef WS
   const int rt = rgbnm_tn_defer_flush((hipStream_t)st);
   const int rf = rgbnm_reduce_defer_flush((hipStream_t)st);
   return rc != RGBNM_OK ? rc : (rt != RGBNM_OK ? rt : rf);
+}
+
+int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* c, const rgbnm_block_acts* a, const rgbnm_block_grads* g,
+                           const rgbnm_block_scratch* s, const void* dy, const float* part2, const float* part1, void* st) {
+  return rgbnm_vit_blocks_bwd_dw(c, 1, &a, &g, &s, &dy, &part2, &part1, st);
 }
 
 int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* c, int in_dtype, const void* y, const void* cbcr, const float* conv16,

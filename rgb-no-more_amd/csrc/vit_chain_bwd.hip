@@ -48,15 +48,16 @@ typedef rgbnm::LnBwdRows<CTHREADS, BM> LnBwd;
 constexpr int RED_OFF = (BM * CP * 2 + 1023) / 1024 * 1024;      // 88064
 static_assert(RED_OFF + LnBwd::RED_BYTES <= 132096, "LDS");
 // ---- P: slot 0 behind the epilogue's scratch (fetched during the epilogue), slots 1, 2 over the dead staging tile; out tiles
-constexpr int P_SLOT0 = 132096, P_SLOT1 = 0, P_SLOT2 = SLOT, P_TILES = 98304;
+constexpr int P_SLOT0 = 132096, P_SLOT1 = 0, P_TILES = 98304;     // chunks 0, 2 in slot 0, chunk 1 in slot 1; K, V of head 0 arrive meanwhile
 static_assert(P_SLOT0 + SLOT <= SMEM && P_TILES + NCW * TILE <= P_SLOT0, "LDS");
 // ---- A: the layout of attn3_bwd_kernel
 constexpr int A_Q = 0, A_K = ARR, A_V = 2 * ARR, A_G = 3 * ARR, A_L2 = 4 * ARR, A_D = A_L2 + NPAD * 4, A_STG = A_D + NPAD * 4;
 constexpr int STG_PITCH = 144, STG_WAVE = 32 * STG_PITCH;
 static_assert(A_STG + NCW * STG_WAVE <= SMEM, "LDS");
 // ---- X: three weight slots | three sets of d(qkv) row tiles
-constexpr int X_SLOTS = 0, X_TILES = 3 * SLOT, X_TSET = NCW * TILE;
-static_assert(X_TILES + 3 * X_TSET <= SMEM, "LDS");
+// chunks 0, 1 over the K, V arrays (fetched during the last head's second phase), chunk 2 over Q; the tile sets fill the rest
+constexpr int X_SLOT0 = A_K, X_SLOT1 = A_K + SLOT, X_SLOT2 = 0, X_TILES = A_K + 2 * SLOT, X_TSET = NCW * TILE;
+static_assert(X_SLOT1 + SLOT <= X_TILES && X_TILES + 3 * X_TSET <= SMEM && SLOT <= A_K, "LDS");
 
 struct BwdBlk {              // = rgbnm_chain_bwd_block (rgbnm.h) with typed pointers
   const bf16* wimg;          // 12 x (W2^T chunk | W1^T chunk) | 3 projection chunks | 9 qkv chunks
@@ -307,10 +308,16 @@ constexpr int B_END = 53;               // 53: staging tile dead (dy fragments o
 // The LayerNorm-backward epilogue shared by M and X (the code of mlp_bwd_kernel's / gemm_nt_kpipe<LNBWD>'s epilogue): acc -> staging
 // tile -> rows; writes dx to global AND back into the tile, from which the caller reads its own rows as operand fragments.
 // Seven workgroup barriers: b0 .. b0 + 6 (the DMA wave mirrors them).  Compute threads only.
+__device__ __forceinline__ void ln_bwd_request(LnBwd& lnb, const bf16* X, const float* mean, const float* rstd, const bf16* R, int img,
+                                               int w) {
+  const int tid = w * 64 + lane_id_here();
+  lnb.request_x(X, E, mean, rstd, img * NTOK, NTOK, tid);
+  lnb.request_res(R, E, img * NTOK, NTOK, tid);
+}
 template <int B0>
 __device__ __forceinline__ void ln_bwd_epilogue(unsigned char* smem, const f32x16 (&acc)[6], const bf16* X, const float* mean,
-                                                const float* rstd, const float* gamma, const bf16* R, bf16* DX, float* part,
-                                                int img, int w, int ib) {
+                                                const float* rstd, const bf16* R, const float* gamma, bf16* DX,
+                                                float* part, int img, int w, int ib) {
   const int lane_ = lane_id_here();
   const int tid = w * 64 + lane_, rloc = w * 32 + (lane_ & 31), g = lane_ >> 5;
   LnBwd lnb;
@@ -329,7 +336,7 @@ __device__ __forceinline__ void ln_bwd_epilogue(unsigned char* smem, const f32x1
     }
   wait_lds();
   BAR(B0 + 1);
-  lnb.run(Cs, CP, DX, E, gamma, true, part, img, reinterpret_cast<float*>(smem + RED_OFF), img * NTOK, NTOK, tid, Cs,
+  lnb.run<true>(Cs, CP, DX, E, gamma, true, part, img, reinterpret_cast<float*>(smem + RED_OFF), img * NTOK, NTOK, tid, Cs,
           [&](int k) { if (k == 0) BAR(B0 + 2); else if (k == 1) BAR(B0 + 3); else if (k == 2) BAR(B0 + 4); else BAR(B0 + 5); });
   wait_lds();
   BAR(B0 + 6);                            // dx rows are back in the tile
@@ -369,32 +376,34 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       dma_linear<24>(wimg + (size_t)NCHUNK * STAGE, smem + P_SLOT0, lane);
 #pragma unroll
       for (int k = 1; k < 7; ++k) BAR(B_E2 + k);
-      // ---- P
+      // ---- P (and, behind it, the first head's K, V, Q: their arrays are free from here on)
+      const bf16* qkv0 = b.qkv + (size_t)img * NTOK * LDQ;
+      const bf16* do0 = p.dattn + (size_t)img * NTOK * INNER;
+      bf16* dq0 = b.dqkv + (size_t)img * NTOK * LDQ;
+      const unsigned char* stg0 = smem + A_STG;
+      auto issue_kv = [&](int h) {
+        dma_matrix_all(qkv0 + INNER + h * HD, LDQ, smem + A_K, lane);
+        dma_matrix_all(qkv0 + 2 * INNER + h * HD, LDQ, smem + A_V, lane);
+      };
+      auto issue_q = [&](int h) { dma_matrix_all(qkv0 + h * HD, LDQ, smem + A_Q, lane); };
+      auto issue_g = [&](int h) { dma_matrix_all(do0 + h * HD, INNER, smem + A_G, lane); };
+      const unsigned char* xw = wimg + (size_t)NCHUNK * STAGE + 3 * SLOT;                 // the nine qkv chunks
+      auto issue_xt = [&](int j) { dma_row_tiles(dq0 + j * 64, LDQ, smem + X_TILES + (j % 3) * X_TSET, lane); };
+      wait_vm<0>();                                       // chunk 0 (fetched during the epilogue) has landed long ago
       BAR(B_P);                                           // the staging tile is dead
       dma_linear<24>(wimg + (size_t)NCHUNK * STAGE + SLOT, smem + P_SLOT1, lane);
-      dma_linear<24>(wimg + (size_t)NCHUNK * STAGE + 2 * SLOT, smem + P_SLOT2, lane);
-      wait_vm<48>(); BAR(B_P + 1);
-      wait_vm<24>(); BAR(B_P + 2);
-      wait_vm<0>(); BAR(B_P + 3);
+      issue_kv(0);
+      BAR(B_P + 1);
+      wait_vm<56>(); BAR(B_P + 2);                        // chunk 1; step 0 is over: slot 0 takes chunk 2
+      dma_linear<24>(wimg + (size_t)NCHUNK * STAGE + 2 * SLOT, smem + P_SLOT0, lane);
+      wait_vm<0>(); BAR(B_P + 3);                         // chunk 2; step 1 is over: Q of head 0 over slot 1
+      issue_q(0);
       BAR(B_P + 4);                                       // d(attention output) of this image is in L2
       // ---- A: the DMA wave of attn3_bwd_kernel for the three heads of this image
       {
-        const bf16* qkv0 = b.qkv + (size_t)img * NTOK * LDQ;
-        const bf16* do0 = p.dattn + (size_t)img * NTOK * INNER;
-        bf16* dq0 = b.dqkv + (size_t)img * NTOK * LDQ;
-        const unsigned char* stg0 = smem + A_STG;
-        auto issue_kv = [&](int h) {
-          dma_matrix_all(qkv0 + INNER + h * HD, LDQ, smem + A_K, lane);
-          dma_matrix_all(qkv0 + 2 * INNER + h * HD, LDQ, smem + A_V, lane);
-        };
-        auto issue_qg = [&](int h) {
-          dma_matrix_all(qkv0 + h * HD, LDQ, smem + A_Q, lane);
-          dma_matrix_all(do0 + h * HD, INNER, smem + A_G, lane);
-        };
-        issue_kv(0);
-        issue_qg(0);
-        wait_vm<56>();
-        BAR(B_A);                                         // start: K, V of head 0 are in LDS
+        issue_g(0);
+        wait_vm<0>();
+        BAR(B_A);                                                          // start: K, V, Q, dO of head 0 are in LDS
         for (int h = 0; h < HEADS; ++h) {
           bf16* g0 = dq0 + h * HD;
           wait_vm<0>();                                   // Q, dO landed (and the previous head's stores are done)
@@ -405,6 +414,10 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
           BAR(B_A + 2 + 4 * h);                           // mid2
           tiles_write(tq, g0, LDQ, lane);
           if (h + 1 < HEADS) issue_kv(h + 1);
+          else {                                          // K, V are dead for good: the first two qkv weight chunks take their place
+            dma_linear<24>(xw, smem + X_SLOT0, lane);
+            dma_linear<24>(xw + SLOT, smem + X_SLOT1, lane);
+          }
           wait_vm<0>();
           BAR(B_A + 3 + 4 * h);                           // end
           tiles_read<true>(stg0, lane, tq);               // dK tiles
@@ -413,28 +426,33 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
           tiles_write(tq, g0 + INNER, LDQ, lane);
           tiles_read<false>(smem + A_G, lane, tq);        // dV
           wait_lds();
-          if (h + 1 < HEADS) issue_qg(h + 1);
+          if (h + 1 < HEADS) {
+            issue_q(h + 1);
+            issue_g(h + 1);
+          } else {
+            // every attention array is dead (the DMA wave is the last to arrive at end2, and the dV tiles are in registers): the
+            // waves' own d(qkv) rows come back as row tiles; sets 0 .. 2 = dq of the three heads, stored long ago
+            issue_xt(0);
+          }
           tiles_write(tq, g0 + 2 * INNER, LDQ, lane);
         }
-        wait_vm<0>();                                     // every d(qkv) row of this image is in L2
       }
-      // ---- X: chunk j -> slot j % 3, the waves' own d(qkv) rows (columns 64 j ..) -> tile set j % 3; two steps ahead
-      {
-        const unsigned char* xw = wimg + (size_t)NCHUNK * STAGE + 3 * SLOT;
-        const bf16* dq0 = b.dqkv + (size_t)img * NTOK * LDQ;
-        auto issue_x = [&](int j) {
-          dma_linear<24>(xw + (size_t)j * SLOT, smem + X_SLOTS + (j % 3) * SLOT, lane);
-          dma_row_tiles(dq0 + j * 64, LDQ, smem + X_TILES + (j % 3) * X_TSET, lane);
-        };
-        // (the attention arrays are dead only when every compute wave has passed end2 of the last head: they have -- the DMA wave
-        // arrives at that barrier last of all, after the waves parked their dV tiles)
-        issue_x(0);
-        issue_x(1);
-        for (int j = 0; j < 9; ++j) {
-          if (j + 1 < 9) wait_vm<52>(); else wait_vm<0>();
-          BAR(B_X + j);
-          if (j + 2 < 9 && j >= 1) issue_x(j + 2);        // slot / tile set (j + 2) % 3 = (j - 1) % 3: free since step j - 1 ended
-          if (j == 0) issue_x(2);                         // (nothing used set 2 before)
+      // ---- X: chunk j -> slot j % 3, the waves' own d(qkv) rows (columns 64 j ..) -> tile set j % 3; two steps ahead.  The wait in
+      // front of barrier j leaves the 52 pieces of group j + 1 (at most) in flight: everything older -- group j, and the d(qkv)
+      // stores a later group will read back -- is complete
+      for (int j = 0; j < 9; ++j) {
+        if (j == 0) wait_vm<28>();                        // tile set 0 (only the 28 dV stores are younger); chunk 0 landed long ago
+        else if (j + 1 < 9) wait_vm<52>();
+        else wait_vm<0>();
+        BAR(B_X + j);
+        if (j == 0) {                                     // what steps 1 and 2 need: behind the first barrier, not in front of it
+          issue_xt(1);
+          dma_linear<24>(xw + 2 * SLOT, smem + X_SLOT2, lane);
+          issue_xt(2);
+        }
+        if (j + 2 < 9 && j >= 1) {                        // slot / tile set (j + 2) % 3 = (j - 1) % 3: free since step j - 1 ended
+          dma_linear<24>(xw + (size_t)(j + 2) * SLOT, smem + ((j + 2) % 3 == 0 ? X_SLOT0 : ((j + 2) % 3 == 1 ? X_SLOT1 : X_SLOT2)), lane);
+          issue_xt(j + 2);
         }
       }
       // ---- LN1-backward epilogue
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       }
     }
     // ================================================================ d(x_mid) = dy + LN2'(dxn2)
-    ln_bwd_epilogue<B_E2>(smem, acc2, b.x_mid, b.mean2, b.rstd2, b.ln2_g, b.dy, b.dx_mid, b.part2, img, w, ib);
+    ln_bwd_epilogue<B_E2>(smem, acc2, b.x_mid, b.mean2, b.rstd2, b.dy, b.ln2_g, b.dx_mid, b.part2, img, w, ib);
     // ================================================================ P: d(attention output) = d(x_mid) . Wproj
     {
       const Geo L = fresh_geo();
@@ -562,7 +580,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
 #pragma unroll
       for (int h = 0; h < HEADS; ++h) {
         BAR(B_P + 1 + h);
-        const unsigned char* sW = smem + (h == 0 ? P_SLOT0 : (h == 1 ? P_SLOT1 : P_SLOT2));
+        const unsigned char* sW = smem + (h == 1 ? P_SLOT1 : P_SLOT0);
         f32x16 acc[2];
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
@@ -785,7 +803,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       const Geo L = fresh_geo();
       const int fl = L.fl;
       const int set = j % 3;
-      const unsigned wo = opaque((unsigned)(X_SLOTS + set * SLOT + L.l31 * ROWB + ((L.g ^ fl) << 4)));
+      const unsigned wo = opaque((unsigned)((set == 0 ? X_SLOT0 : (set == 1 ? X_SLOT1 : X_SLOT2)) + L.l31 * ROWB + ((L.g ^ fl) << 4)));
       const unsigned to = opaque((unsigned)(X_TILES + set * X_TSET + w * TILE + L.l31 * ROWB + ((L.g ^ (L.l31 & 7)) << 4)));
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -799,7 +817,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       }
     }
     // ================================================================ dx = d(x_mid) + LN1'(dxn1); the next block's dy
-    ln_bwd_epilogue<B_E1>(smem, accx, b.x_in, b.mean1, b.rstd1, b.ln1_g, b.dx_mid, b.dx, b.part1, img, w, ib);
+    // (requesting the operand rows of this epilogue three steps earlier would hide their latency, but 104 more live registers in
+    // the step loop spill: 29 dwords)
+    ln_bwd_epilogue<B_E1>(smem, accx, b.x_in, b.mean1, b.rstd1, b.dx_mid, b.ln1_g, b.dx, b.part1, img, w, ib);
     read_own_rows(smem, w, dyf);
     wait_lds();
     BAR(B_END);

@@ -501,14 +501,36 @@ class _BlockFn(torch.autograd.Function):
         # that runs (the last block); each node then only launches its weight-gradient GEMMs and reductions
         if idx == m.depth - 1:
             st.chain_bwd = m._chain_backward(a, dy)
+            st.dw_pending = []
         try:
             if getattr(st, "chain_bwd", False):
+                # the weight-gradient GEMMs of several blocks share ONE grouped launch (rgbnm_vit_blocks_bwd_dw: the more blocks,
+                # the fewer token splits); a block's gradients are final -- and handed to the exchange -- when its group has run
                 dx = a.dx_blk[idx]
-                sc = L.BlockScratch(a.du_blk[idx].data_ptr(), a.dxn.data_ptr(), a.dxmid_blk[idx].data_ptr(),
-                                    a.dattn_chain.data_ptr(), a.dqkv_blk[idx].data_ptr(), scratch.ws, scratch.ws_bytes)
-                L.check(L.lib().rgbnm_vit_block_bwd_dw(C.byref(a.cfg), C.byref(a.acts[idx]), C.byref(g), C.byref(sc), dy.data_ptr(),
-                                                       a.lnpart[idx, 0].data_ptr(), a.lnpart[idx, 1].data_ptr(), L.stream()),
-                        "vit_block_bwd_dw")
+                st.dw_pending.append((idx, g, dy.data_ptr()))       # (no reference to the gradient views: autograd must be able to adopt them)
+                if st.gbuf.data_ptr() != m._gflat.data_ptr():
+                    group = 1          # a side buffer that autograd ADDS to attached gradients when this node returns: no deferring
+                else:
+                    group = m.depth if (m._grad_sync is None or st.holding) else m.dw_group_overlapped
+                if len(st.dw_pending) >= group or idx == 0:
+                    pend, st.dw_pending = st.dw_pending, []
+                    n = len(pend)
+                    scs = [L.BlockScratch(a.du_blk[i].data_ptr(), a.dxn.data_ptr(), a.dxmid_blk[i].data_ptr(), a.dattn_chain.data_ptr(),
+                                          a.dqkv_blk[i].data_ptr(), a.ws_chain.data_ptr() + i * a.ws_bytes, a.ws_bytes)
+                           for i, _, _ in pend]
+                    pa = (C.POINTER(L.BlockActs) * n)(*[C.pointer(a.acts[i]) for i, _, _ in pend])
+                    pg = (C.POINTER(L.BlockGrads) * n)(*[C.pointer(gg) for _, gg, _ in pend])
+                    ps = (C.POINTER(L.BlockScratch) * n)(*[C.pointer(x) for x in scs])
+                    pdy = (C.c_void_p * n)(*[d for _, _, d in pend])
+                    p2 = (C.c_void_p * n)(*[a.lnpart[i, 0].data_ptr() for i, _, _ in pend])
+                    p1 = (C.c_void_p * n)(*[a.lnpart[i, 1].data_ptr() for i, _, _ in pend])
+                    L.check(L.lib().rgbnm_vit_blocks_bwd_dw(C.byref(a.cfg), n, pa, pg, ps, pdy, p2, p1, L.stream()), "vit_blocks_bwd_dw")
+                    if m._grad_sync is not None:
+                        for i, _, _ in pend[:-1]:
+                            m._grad_sync.ready(st.gbuf, m._block_names[i])
+                else:
+                    by_name = dict(zip(m._block_names[idx], grads))
+                    return (dx, None, None) + tuple(by_name[n] for n in m._block_param_order[idx])
             else:
                 L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
                                                     C.byref(g), C.byref(scratch), dy.data_ptr(), dx.data_ptr(),
@@ -585,6 +607,7 @@ class ViT(FlatParamModule):
     gradient exchange or with FlatGradSync's single all-reduce after the backward; NOT with torch DDP or any hook that reads
     `.grad` during the backward (leave it False there)."""
     defer_grad_reduction = False
+    dw_group_overlapped = 4        # blocks per grouped weight-gradient launch while gradient slices are exchanged during the backward
 
     def __init__(self, in_channels: int = 3, patch_size: int = 16, emb_size: int = 768, input_embed: int = -1,
                  depth: int = 12, n_classes: int = 1000, drop_p=0.1, pixel_space="RGB", ver=1, use_subblock=True,
@@ -855,6 +878,8 @@ class ViT(FlatParamModule):
                 a.dx_blk = [e(M, E) for _ in range(D)]
                 a.dattn_chain = e(M, I)
                 a.lnpart = torch.empty(D, 2, a.B, 2, E, device=dev, dtype=torch.float32)
+                # every block's split sums side by side (the weight-gradient GEMMs of several blocks run as one launch)
+                a.ws_chain = a.ws_blk if a.ws_blk is not None else torch.empty(D * a.ws_bytes, device=dev, dtype=torch.uint8)
             blocks = (L.ChainBwdBlock * D)()
             for i in range(D):
                 bp, ac = self._bparams[i], a.acts[i]
