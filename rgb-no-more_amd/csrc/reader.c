@@ -208,6 +208,15 @@ static void* batch_worker(void* arg) {
     const int32_t* bx = j->box ? j->box + 4 * (size_t)i : NULL;
     int16_t* yd = bx ? j->Y + j->yoff[i] : j->Y + (size_t)i * ysz;
     int16_t* cd = bx ? j->CbCr + j->coff[i] : j->CbCr + (size_t)i * csz;
+    if (bx) {
+      /* the box is validated against the EXPECTED grid before anything is written through it (read_impl checks it again against
+       * the file's own grid): a negative or oversized box from a C caller is RD_EARG, not an out-of-bounds memset */
+      if (bx[0] < 0 || bx[1] < 0 || bx[2] <= 0 || bx[3] <= 0 || ((bx[0] | bx[1] | bx[2] | bx[3]) & 1) ||
+          (long long)bx[0] + bx[2] > j->expect[0] || (long long)bx[1] + bx[3] > j->expect[1] || j->yoff[i] < 0 || j->coff[i] < 0) {
+        j->status[i] = RD_EARG;
+        continue;
+      }
+    }
     memset(cd, 0, (bx ? (size_t)2 * (bx[2] / 2) * (bx[3] / 2) * 64 : csz) * sizeof(int16_t));
     FILE* fp = fopen(j->paths[i], "rb");
     if (!fp) {

@@ -163,7 +163,7 @@ class _Arena:
                                  mean2=e(M, dt=f32), rstd2=e(M, dt=f32), u=e(M, 4 * E), gl=e(M, 4 * E)))
         self.hmean, self.hrstd = e(M, dt=f32), e(M, dt=f32)
         self.pooled, self.h1 = e(B, E), e(B, E)
-        ws_bytes = L.lib().rgbnm_vit_workspace_ex(C.byref(self.cfg), model.n_classes)
+        ws_bytes = L.lib().rgbnm_vit_workspace_ex(C.byref(self.cfg), model._ncls_pad)      # the PADDED head width: its dW partials live here
         self.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         if need_grad:
             self.du, self.dxn, self.dx_mid = e(M, 4 * E), e(M, E), e(M, E)
@@ -216,7 +216,7 @@ class _FwdState:
         if a.ws_blk is None:                           # the partial sums of every block now live until the end of the pass
             a.ws_blk = torch.empty(m.depth * a.ws_bytes, device=a.ws.device, dtype=torch.uint8)
             # ... and the head's three producers side by side (a.ws stays the patch embedding's)
-            a.ws_head = torch.empty(L.lib().rgbnm_head_bwd_workspace(C.byref(a.cfg), m.n_classes), device=a.ws.device, dtype=torch.uint8)
+            a.ws_head = torch.empty(L.lib().rgbnm_head_bwd_workspace(C.byref(a.cfg), m._ncls_pad), device=a.ws.device, dtype=torch.uint8)
             a.hold_table = torch.zeros(L.lib().rgbnm_reduce_hold_table_bytes(), device=a.ws.device, dtype=torch.uint8)
             # host record of what hold_table holds: allocated and freed WITH it (rgbnm.h), so a recycled device address
             # never inherits somebody else's "already uploaded"

@@ -108,5 +108,22 @@ def test_cropped_batch_read_is_a_slice_of_the_full_read(files):
     for bad in ((1, 0, 2, 2), (0, 0, 10, 2), (0, 8, 2, 2), (0, 0, 0, 2)):       # odd / outside the 8 x 8 grid / empty
         with pytest.raises(ValueError):
             dm.read_coefficients_batch_crop(paths[:1], [bad], grid=(8, 8))
+    # straight through the C ABI (no Python-side checks): a negative or oversized box is RD_EARG for that file -- nothing is
+    # written through it (the chroma pre-fill used to run before the box was validated: a negative size wrapped to ~2^64 bytes)
+    import ctypes as C
+    lib = dm.lib()
+    for bad in ((0, 0, -2, 4), (0, 0, 2, -4), (-2, 0, 2, 2), (0, 0, 4096, 4096), (6, 6, 4, 4)):
+        arr = (C.c_char_p * 1)(paths[0].encode())
+        box = torch.tensor([bad], dtype=torch.int32)
+        off = torch.zeros(1, dtype=torch.int64)
+        ybuf = torch.full((8 * 8 * 64,), 7, dtype=torch.int16)
+        cbuf = torch.full((2 * 4 * 4 * 64,), 7, dtype=torch.int16)
+        q = torch.zeros(192, dtype=torch.int16)
+        st = torch.zeros(1, dtype=torch.int32)
+        lib.rgbnm_read_coefficients_batch_crop(arr, 1, 1, 8, 8, 4, 4, C.c_void_p(box.data_ptr()), C.c_void_p(off.data_ptr()),
+                                               C.c_void_p(off.data_ptr()), C.c_void_p(ybuf.data_ptr()), C.c_void_p(cbuf.data_ptr()),
+                                               C.c_void_p(q.data_ptr()), C.c_void_p(st.data_ptr()))
+        assert st.item() != 0, bad
+        assert bool((ybuf == 7).all()) and bool((cbuf == 7).all()), bad
     with pytest.raises(ValueError):
         DCTBatchLoader(paths, list(range(11)), batch_size=4, device="cpu", grid=(8, 8), crop_on_host=True)

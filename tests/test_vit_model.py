@@ -474,10 +474,12 @@ def _fp32_and_bf16_vs_oracle(emb, heads, depth, B, ncls, bf16_tol=1e-2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ncls", [10, 37])
+@pytest.mark.parametrize("ncls", [10, 37, 8142])
 def test_class_counts_that_are_not_multiples_of_eight(ncls):
     """The reference's ctor takes any n_classes (models/plainvit.py:542-557); the head GEMMs move 16-byte rows, so such a count
-    is padded inside (zero weight rows / bias / logit-gradient columns): logits, loss and every gradient against the oracle."""
+    is padded inside (zero weight rows / bias / logit-gradient columns): logits, loss and every gradient against the oracle.
+    8142 (iNaturalist-sized, not a multiple of 8): the head's weight-gradient partial sums are larger than a block's, so the arena
+    workspace must be sized by the PADDED count."""
     _fp32_and_bf16_vs_oracle(192, 3, 2, 4, ncls)
 
 
