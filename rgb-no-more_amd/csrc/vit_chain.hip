@@ -65,12 +65,13 @@ constexpr int TA_OFF = ST1_OFF + STAGE;           // 62592: gelu tiles of wave 5
 constexpr int B1R_OFF = TA_OFF + 2 * STG_TILE + 2 * 4 * ROWB;   // 71808: fc1-bias ring, 2 x 64 floats (inside slot 2 of the attention part:
                                                                 //        the first piece is fetched after the last projection step)
 constexpr int B2_OFF = B1R_OFF + 512;             // 72320: fc2 bias (fetched with the first fc1-bias piece)
+constexpr int FLAG_OFF = B2_OFF + E * 4;           // 73088: the last hidden chunk whose tiles of waves 4-6 the DMA wave has taken
 constexpr int ST0_OFF = K_OFF;                    // even hidden chunks (over K, V: dead by then)
 constexpr int TB_OFF = ST0_OFF + STAGE;           // 122880: gelu | gelu' tiles of waves 0..4
 constexpr int SMEM = 163840;
 static_assert(BQKV_OFF + 3 * INNER * 4 <= SMEM, "LDS");
 static_assert(TB_OFF + 10 * STG_TILE <= SMEM, "LDS");
-static_assert(B2_OFF + E * 4 <= ST0_OFF, "LDS");
+static_assert(FLAG_OFF + 16 <= ST0_OFF, "LDS");
 static_assert(LN1P_OFF + 2 * E * 4 <= V_OFF, "LDS");
 static_assert(TAB_LIMIT <= ST1_OFF && ST1_OFF % 128 == 0 && TA_OFF % 128 == 0, "LDS");
 
@@ -385,14 +386,62 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
       BAR(15);                                           // 14b: the projection MFMAs are done: slot 2 is free
       bias1(b, 0);
       dma_f32x192(b.b2, smem + B2_OFF, lane);
+      volatile int* flag = reinterpret_cast<volatile int*>(smem + FLAG_OFF);
+      if (lane == 0) *flag = 0;
+      // The gelu / gelu' tiles of waves 4-6 -- the younger, slower wave of each SIMD pair (mlp_fused.hip) -- leave through this
+      // wave: behind the barrier that starts chunk c it copies the tiles of chunk c - 1 into registers, raises the flag their
+      // owners poll before overwriting them, and stores them (whole 128-byte row pieces) before fetching the next weight chunk.
+      u32x4 tv[3][2][4];
+      const int trow = lane >> 3, tvec = lane & 7;
+      auto take_tiles = [&]() {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const unsigned tb = (unsigned)(q == 0 ? TB_OFF + 8 * STG_TILE : (q == 1 ? TA_OFF : TA_OFF + 2 * STG_TILE));
+          const int lr = q == 2 ? NTOK - 6 * 32 : 32;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = trow + 8 * i;
+              if (row < lr) tv[q][t][i] = *reinterpret_cast<const u32x4*>(smem + tb + t * lr * ROWB + row * ROWB + ((tvec ^ (row & 7)) << 4));
+            }
+        }
+        wait_lds();
+      };
+      auto store_tiles = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int lr = q == 2 ? NTOK - 6 * 32 : 32;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = trow + 8 * i;
+            if (row < lr) {
+              const size_t go = ((size_t)img * NTOK + 32 * (4 + q) + row) * HID + chunk * 64 + tvec * 8;
+              *reinterpret_cast<u32x4*>(b.gl + go) = tv[q][0][i];
+              *reinterpret_cast<u32x4*>(b.gp + go) = tv[q][1][i];
+            }
+          }
+        }
+      };
       wait_vm<0>(); BAR(16);                             // 15: hidden chunk 0, table, bias
       for (int c = 0; c < 11; ++c) {
+        if (c >= 1) {
+          take_tiles();
+          if (lane == 0) *flag = c;
+          store_tiles(c - 1);
+        }
         chunkM(b, c + 1);
         bias1(b, c + 1);
         wait_vm<0>(); BAR(17 + c);                       // 16 + c
       }
+      take_tiles();                                      // (chunk 10's, behind barrier 27 = the start of chunk 11)
+      if (lane == 0) *flag = 11;
+      store_tiles(10);
       if (ib + 1 < depth) ln1p(p.blk[ib + 1]);                           // stage 0 (over the K pad rows) is dead since barrier 26
       wait_vm<0>(); BAR(28);                             // 27: every wave has left the last hidden chunk
+      take_tiles();                                      // chunk 11's: the compute waves poll the flag before they touch their row tiles
+      if (lane == 0) *flag = 12;
+      store_tiles(11);
       if (ib + 1 < depth) {
         const ChainBlk& nb = p.blk[ib + 1];
         misc(nb);
@@ -662,6 +711,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
                                          : (w == 5 ? TA_OFF : TA_OFF + 2 * STG_TILE));       // gelu tile (LDS offset); gelu' follows
     const unsigned tpoff = (unsigned)(live * ROWB);                // (32 or 4 rows per tile)
     const bool lane_live = L.l31 < live;
+    const bool handed = w >= 4;                                    // this wave's gelu / gelu' tiles leave through the DMA wave
+    const volatile int* flag = reinterpret_cast<const volatile int*>(smem + FLAG_OFF);
     const unsigned kneg = p.kneg, kpos = p.kpos, klo = p.klo, koff = p.koff, ksgn = p.ksgn;
     unsigned k4v = 0x00040004u;
     asm volatile("" : "+v"(k4v));
@@ -694,6 +745,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
           mma(a1, fb, fx);
         }
         Frag<bf16> pg[2];
+        if (handed && ht == 0 && chunk > 0) {                      // the DMA wave has taken the previous chunk's tiles (normally long ago)
+          while (__builtin_amdgcn_readfirstlane(*flag) < chunk) __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) {
           const float* bp = bch + 32 * ht + 16 * hs + 8 * L.g;
@@ -758,7 +812,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
       }
       // the chunk's gelu / gelu' tiles out as whole 128-byte row pieces
       wait_lds();
-      {
+      if (!handed) {
         const int ln = lane_id_here();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -775,7 +829,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         wait_lds();
       }
     }
-    BAR(28);                                      // step 27: the MLP tiles and stages are dead
+    BAR(28);                                      // step 27: the MLP stages are dead; the last tiles of waves 4-6 are being taken
+    while (__builtin_amdgcn_readfirstlane(*flag) < HID / 64) __builtin_amdgcn_s_sleep(1);
     // ---------------- x_out = x_mid + fc2(...) + b2 ; next block's LN1
     {
       const float* b2p = reinterpret_cast<const float*>(smem + B2_OFF) + 8 * L.g;
