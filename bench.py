@@ -210,19 +210,20 @@ BF16_LOGIT_TOL = 1e-2      # bf16 operands / fp32 accumulate vs the fp32 referen
 def parity_check(arch, cdt, dev):
     """The exact kernel mix of the timed step against the reference: a second model instance with the deterministic detfill
     weights on detfill inputs at the fast-path batch sizes, compared with golden vectors captured from the reference model
-    itself -- EVERY logit (tests/golden/g20_fullsize.npz, make_golden_r3.py: JPEG-Ti B = 256 depth 12 = the bench
-    configuration, JPEG-S B = 64 depth 12, SwinV2-T B = 64).  Data only -- nothing of oracle/ is imported here."""
+    itself -- EVERY logit, at the batch that is timed (tests/golden/g20_fullsize.npz: JPEG-Ti B = 256 depth 12;
+    g21_b256.npz: JPEG-S depth 12 and SwinV2-T at B = 256).  Data only -- nothing of oracle/ is imported here."""
     import numpy as np
     import torch
     import rgb_no_more_amd as rg
     from rgb_no_more_amd import detfill
-    path = os.path.join(ROOT, "tests", "golden", "g20_fullsize.npz")
+    # JPEG-Ti: g20 (B = 256 = the timed batch); JPEG-S / SwinV2-T: g21 (make_golden_r4.py), also at the timed batch 256
+    path = os.path.join(ROOT, "tests", "golden", "g20_fullsize.npz" if arch == "vitti" else "g21_b256.npz")
     if not os.path.exists(path):
         return None
     g = np.load(path)
     bf16 = cdt == torch.bfloat16
     if arch == "swinv2t":
-        tag, B, hard = "swt_b64", 64, False
+        tag, B, hard = "swt_b256", 256, False
         depths, sheads = [2, 2, 6, 2], [3, 6, 12, 24]
         m = rg.SwinTransformerV2(img_size=256, patch_size=4, embed_dim=96, depths=depths, num_heads=sheads, window_size=8,
                                  mlp_ratio=4.0, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, qkv_bias=True, ape=False,
@@ -235,11 +236,11 @@ def parity_check(arch, cdt, dev):
         y = torch.from_numpy(detfill.normalish((B, 1, 32, 32, 8, 8), 171)).to(dev)
         c = torch.from_numpy(detfill.normalish((B, 2, 16, 16, 8, 8), 172)).to(dev)
         t = detfill.uniform((B, 1000), 173, 0.0, 1.0)
-        tol = 6e-2 if bf16 else 1e-3                     # cosine attention with logit scales up to 30 (tests/test_swin.py)
+        tol = 3e-2 if bf16 else 1e-3                     # cosine attention with logit scales up to 30 (tests/test_swin.py; measured 1.9e-2)
         desc = f"reference SwinV2-T DCT, detfill weights, B={B}, drop_path 0"
     else:
         tag, emb, heads, depth, B, hard = {"vitti": ("ti_d12_b256", 192, 3, 12, 256, True),
-                                           "vits": ("s_d12_b64", 384, 6, 12, 64, False)}[arch]
+                                           "vits": ("s_d12_b256", 384, 6, 12, 256, False)}[arch]
         m = rg.ViT(3, 16, emb, depth=depth, n_classes=1000, drop_p=0.0, device=dev, num_heads=heads, head_size=64,
                    pixel_space="DCT", ver=1, use_subblock=True)
         shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
@@ -265,7 +266,7 @@ def parity_check(arch, cdt, dev):
     ref = g[tag + "_logits"]
     got = logits.detach().float().cpu().numpy()
     err = float(np.abs(got - ref).max()) if got.shape == ref.shape else float("inf")
-    out = {"golden": f"tests/golden/g20_fullsize.npz:{tag} ({desc}; all {ref.shape[0]} x {ref.shape[1]} logits)",
+    out = {"golden": f"tests/golden/{os.path.basename(path)}:{tag} ({desc}; all {ref.shape[0]} x {ref.shape[1]} logits)",
            "max_abs_dlogit": round(err, 6), "tol": tol, "loss": round(float(loss.item()), 6),
            "loss_reference": round(float(g[tag + "_loss"]), 6), "gradnorm_rel_err_median": round(float(np.median(rel)), 6),
            "ok": bool(err <= tol and abs(float(loss.item()) - float(g[tag + "_loss"])) < 5e-3 and np.median(rel) < 2e-2)}

@@ -352,3 +352,62 @@ def test_fused_attention_projection_equals_the_separate_launches(tag):
         L.check(lib.rgbnm_set_option(b"attn_proj", old))
     for k in fused:
         assert torch.equal(fused[k], plain[k]), k
+
+
+@pytest.mark.parametrize("compute", [torch.bfloat16, torch.float32])
+def test_jpeg_s_at_the_timed_batch_256_vs_reference_golden(golden, compute):
+    """g21 (make_golden_r4.py): the reference JPEG-S (E = 384, depth 12) at B = 256 -- the batch bench.py --arch vits times, where
+    the row-panel GEMM geometry (kp7 / kp8, persistent or not) is chosen from the row count: every logit, the loss, every
+    gradient norm and strided slices of twelve gradients (per-tensor relative error)."""
+    g = golden("g21_b256.npz")
+    tag, B = "s_d12_b256", 256
+    m = rg.ViT(3, 16, 384, depth=12, n_classes=1000, drop_p=0.0, device=DEV, num_heads=6, head_size=64, pixel_space="DCT", ver=1,
+               use_subblock=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in detfill.fill_state_dict(shapes, base_seed=1).items()})
+    m.compute_dtype = compute
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 71)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 72)).to(DEV)
+    t = detfill.uniform((B, 1000), 73, 0.0, 1.0)
+    tgt = torch.from_numpy(t / t.sum(1, keepdims=True)).to(DEV)
+    logits, loss, gn = run(m, y, c, tgt, compute)
+    err = np.abs(logits - g[tag + "_logits"]).max()
+    rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for nm in [str(x) for x in g[tag + "_slice_names"]]:
+        got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
+        want = g[tag + "_grad_" + nm].astype(np.float64)
+        worst = max(worst, float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30)))
+    print(f"[{tag} {compute}] max |dlogit| = {err:.3e}, loss {loss:.6f} vs {float(g[tag + '_loss']):.6f}, grad-norm rel median "
+          f"{np.median(rel):.3e} max {rel.max():.3e}, worst gradient slice rel {worst:.3e}")
+    if compute == torch.float32:
+        assert err <= 1e-4 and abs(loss - float(g[tag + "_loss"])) < 2e-5
+        np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=1e-3, atol=1e-7)
+        assert worst < 2e-3
+    else:
+        assert err <= BF16_LOGIT_TOL and abs(loss - float(g[tag + "_loss"])) < 5e-3
+        assert np.median(rel) < 2e-2 and rel.max() < 0.15
+        assert worst < 3e-2                      # per-tensor bf16 gradient bar (VERDICT r3 item 3)
+
+
+def test_bf16_gradient_slices_per_tensor_at_the_bench_configuration(golden):
+    """JPEG-Ti, B = 256, depth 12, bf16, chain kernels on (the default = what bench.py times): the three gradient slices g20 holds,
+    per-tensor relative error <= 3e-2, next to the logit / loss / gradient-norm checks above."""
+    lib = L.lib()
+    lib.rgbnm_set_option(b"fwd_chain", 1)
+    lib.rgbnm_set_option(b"bwd_chain", 1)
+    g = golden("g20_fullsize.npz")
+    tag = "ti_d12_b256"
+    m, sd, y, c, tgt = build(tag, torch.bfloat16)
+    logits, loss, gn = run(m, y, c, tgt, torch.bfloat16)
+    assert np.abs(logits - g[tag + "_logits"]).max() <= BF16_LOGIT_TOL
+    rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
+    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+    named = dict(m.named_parameters())
+    for nm in ("encoder.0.0.fn.eb_mha.qkv.weight", "encoder.11.1.fn.eb_ffb.0.weight", "patchembed.projection.0.weight"):
+        got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
+        want = g[tag + "_grad_" + nm].astype(np.float64)
+        r = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+        print(nm, "bf16 gradient slice rel", f"{r:.3e}")
+        assert r < 3e-2, (nm, r)

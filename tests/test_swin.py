@@ -254,9 +254,54 @@ def test_swinv2t_at_batch_64_vs_reference_golden(golden, dt):
         assert abs(loss.item() - float(g[tag + "_loss"])) < 2e-5
         np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=2e-3, atol=2e-7)
     else:
-        assert err <= 6e-2
+        assert err <= 3e-2                                   # (measured 1.9e-2; the bar was 6e-2 until round 4)
         assert abs(loss.item() - float(g[tag + "_loss"])) < 5e-3
         assert np.median(rel) < 3e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_swinv2t_at_the_timed_batch_256_vs_reference_golden(golden, dt):
+    """g21 (make_golden_r4.py): the reference SwinV2-T DCT at B = 256 -- the batch bench.py --arch swinv2t times, where the GEMM
+    geometry is chosen from the row count -- every logit, the loss, every gradient norm and strided slices of twelve gradients."""
+    g = golden("g21_b256.npz")
+    tag, B = "swt_b256", 256
+    m, img, depths, heads, _ = _model("swt", DEV)
+    names = [str(n) for n in g[tag + "_names"]]
+    shapes = S.param_shapes(depths, heads)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in S.fill_params({n: shapes[n] for n in names}).items()}, strict=False)
+    nb = img // 8
+    y = torch.from_numpy(detfill.normalish((B, 1, nb, nb, 8, 8), 171)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, nb // 2, nb // 2, 8, 8), 172)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 173, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    m.train()
+    m.compute_dtype = dt
+    logits = m(y, c)
+    loss = rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=dt)
+    loss.backward()
+    torch.cuda.synchronize()
+    err = np.abs(logits.detach().float().cpu().numpy() - g[tag + "_logits"]).max()
+    named = dict(m.named_parameters())
+    gn = np.array([named[n].grad.double().norm().item() for n in names])
+    rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-9)
+    worst = 0.0
+    for nm in [str(x) for x in g[tag + "_slice_names"]]:
+        got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
+        want = g[tag + "_grad_" + nm].astype(np.float64)
+        worst = max(worst, float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30)))
+    print(f"[swt B=256 {dt}] max |dlogit| = {err:.3e}, loss {loss.item():.6f} vs {float(g[tag + '_loss']):.6f}, grad-norm rel "
+          f"median {np.median(rel):.3e} max {rel.max():.3e}, worst gradient slice rel {worst:.3e}")
+    if dt == torch.float32:
+        assert err <= 1e-4
+        assert abs(loss.item() - float(g[tag + "_loss"])) < 2e-5
+        np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=2e-3, atol=2e-7)
+        assert worst < 2e-3
+    else:
+        assert err <= 3e-2
+        assert abs(loss.item() - float(g[tag + "_loss"])) < 5e-3
+        assert np.median(rel) < 3e-2
+        assert worst < 3e-2                                  # per-tensor bf16 gradient bar (measured 1.6e-2)
 
 
 @pytest.mark.gpu
