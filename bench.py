@@ -456,6 +456,8 @@ def main():
         gflag = torch.tensor([1 if graph is not None else 0], device=dev)
         dist.all_reduce(gflag, op=dist.ReduceOp.MIN)
         if gflag.item() == 0:
+            if graph is not None:
+                print(f"[bench rank {rank}] another rank could not capture the step; running eagerly", file=sys.stderr)
             graph = None
 
     def exchange_after_replay():
@@ -534,6 +536,9 @@ def main():
             okf = torch.tensor([1 if (model.flat_grad_base() is not None and err <= 1e-4 * g_eager.abs().max().item() + 1e-8) else 0],
                                device=dev)
             dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if okf.item() != 1:
+                print(f"[bench rank {rank}] graph replay + one all-reduce differs from the eager exchange "
+                      f"(max |d| {err:.3e} of {g_eager.abs().max().item():.3e}); schedule not a candidate", file=sys.stderr)
             if okf.item() == 1:
                 cands.append(("HIP graph replay, then one all-reduce", 1 << 60, True))
         for name, elems, ug in cands:

@@ -356,15 +356,17 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
       misc(b0);
       chunkA(b0, 0, 0);
       chunkA(b0, 1, 1);
-      chunkA(b0, 2, 2);
-      wait_vm<63>();                        // the parameter vectors have landed (they are older than the 72 chunk pieces)
-      wait_vm<48>();
+      wait_vm<24>();                        // the parameter vectors (older than the 48 chunk pieces) and q0 have landed
       wg_barrier();         // init
     }
     for (int ib = 0; ib < depth; ++ib) {
       const ChainBlk& b = p.blk[ib];
-      wait_vm<48>(); BAR(0);                             // 0: q0
-      wait_vm<24>(); BAR(1);                             // 1: k0
+      wait_vm<24>(); BAR(0);                             // 0: q0
+      // v0 goes into slot 2 only now: the slot's tail holds the fc2 bias and the hand-off flag of the PREVIOUS block's MLP part,
+      // which the compute waves read in that block's epilogue -- behind barrier 0 every wave has left it (fetched there from the
+      // tail of the previous block, the last pieces of this chunk landed on the bias while slow waves were still adding it:
+      // features 160..191 of x_out, tools/chain_determinism.py)
+      chunkA(b, 2, 2); wait_vm<24>(); BAR(1);            // 1: k0
       chunkA(b, 3, 0); wait_vm<24>(); BAR(2);            // 2: v0
       chunkA(b, 4, 1); BAR(3);                           // 3: attention 0
       chunkA(b, 5, 2); wait_vm<48>(); BAR(4);            // 4: q1
@@ -446,8 +448,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         const ChainBlk& nb = p.blk[ib + 1];
         misc(nb);
         chunkA(nb, 0, 0);
-        chunkA(nb, 1, 1);
-        chunkA(nb, 2, 2);
+        chunkA(nb, 1, 1);                                // (chunk 2 behind the next barrier 0, see there)
       }
     }
     return;

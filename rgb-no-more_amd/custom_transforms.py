@@ -543,7 +543,7 @@ class TrainTransform_DCT(torch.nn.Module):
             params = self.sample_params(B, Hy, Wy)
         arr, nops = self.pack(params)
         dev = Yq.device
-        pdev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev, non_blocking=True)
+        pdev = _params_to_device(self, np.frombuffer(bytes(arr), dtype=np.uint8), dev)
         if self._conv16 is None or self._conv16.device != dev:
             self._conv16 = dops.generate_conversion_matrix(8, 2).to(dev).contiguous()
         filt = self.bank.device_tensor(dev)
@@ -677,6 +677,33 @@ class FastParamSampler:
         return out, nops
 
 
+_PARAM_SLOTS = 16
+
+
+def _params_to_device(t, host, dev):
+    """The packed per-image parameters of one batch -> device, WITHOUT stalling the host: a copy from pageable memory makes the
+    host wait until the stream has drained (the whole previous step), so the bytes go through a small ring of pinned slots and one
+    asynchronous copy each, like the mixup lambda (cls_transforms.py).  A slot
+    is reused _PARAM_SLOTS batches later, after the event behind its copy has completed."""
+    nbytes = host.nbytes
+    ring = t.__dict__.get("_pring")
+    if ring is None or ring["dev"] != dev or ring["host"].shape[1] < nbytes:
+        ring = t.__dict__["_pring"] = {"dev": dev, "host": torch.empty(_PARAM_SLOTS, max(nbytes, 4096), dtype=torch.uint8).pin_memory(),
+                                       "ev": [None] * _PARAM_SLOTS, "i": 0}
+    i = ring["i"]
+    ring["i"] = (i + 1) % _PARAM_SLOTS
+    if ring["ev"][i] is not None:
+        ring["ev"][i].synchronize()
+    slot = ring["host"][i, :nbytes]
+    slot.numpy()[:] = host.view(np.uint8).reshape(-1)
+    pdev = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    pdev.copy_(slot, non_blocking=True)
+    if ring["ev"][i] is None:
+        ring["ev"][i] = torch.cuda.Event()
+    ring["ev"][i].record()
+    return pdev
+
+
 def apply_packed(transform, Yq, CbCrq, quant, packed, nops, y_off=None, c_off=None, grid=None):
     """Run the augment kernels with an AUG_DTYPE array produced by FastParamSampler.sample().
     y_off / c_off (device int64 (B,)) + grid=(Hy, Wy): Yq / CbCrq are the flat HOST-CROPPED buffers of
@@ -690,7 +717,7 @@ def apply_packed(transform, Yq, CbCrq, quant, packed, nops, y_off=None, c_off=No
         B, (Hy, Wy) = len(packed), grid
         Hc, Wc = (Hy + 1) // 2, (Wy + 1) // 2
     host = np.ascontiguousarray(packed)
-    pdev = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
+    pdev = _params_to_device(t, host, dev)
     if t._conv16 is None or t._conv16.device != dev:
         t._conv16 = dops.generate_conversion_matrix(8, 2).to(dev).contiguous()
     filt = t.bank.device_tensor(dev)

@@ -142,3 +142,29 @@ def test_no_grad_forward():
         b = m(y, c).float().cpu().numpy()
         L.lib().rgbnm_set_option(b"fwd_chain", 1)
     assert np.abs(a - b).max() < 2e-2
+
+
+def test_bit_reproducibility_at_the_bench_batch():
+    """B = 256, depth 12 (one workgroup per CU on every CU): repeated forwards give the same bits, in train mode (logits and what
+    the backward reads) and in no-grad mode, whose arena shares one block's buffers -- faster stores, other timing: this is where
+    the next block's v0 chunk once landed on the fc2 bias that slow waves were still adding (tools/chain_determinism.py)."""
+    m, y, c, tgt = build(12, 256)
+    L.lib().rgbnm_set_option(b"fwd_chain", 1)
+    m.train()
+    ref = None
+    for _ in range(3):
+        logits = m(y, c)
+        arena = logits.grad_fn.st.arena
+        cur = [logits.detach().clone(), arena.x[12].clone(), arena.blk[11]["gl"].clone(), arena.blk[8]["x_mid"].clone()]
+        del logits
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(ref, cur):
+                assert torch.equal(a, b)
+    m.eval()
+    with torch.no_grad():
+        outs = [m(y, c).clone() for _ in range(8)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    assert torch.equal(outs[0], ref[0])

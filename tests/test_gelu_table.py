@@ -61,6 +61,7 @@ def test_fused_forward_with_table_equals_arithmetic(scale):
                 p.mul_(scale)
     m.eval()
     outs = []
+    lib.rgbnm_set_option(b"fwd_chain", 0)      # the fused FeedForwardBlock kernel itself (the one-launch forward always uses the table)
     try:
         for opt in (1, 0):
             L.check(lib.rgbnm_set_option(b"gelu_table", opt))
@@ -69,5 +70,6 @@ def test_fused_forward_with_table_equals_arithmetic(scale):
             torch.cuda.synchronize()
     finally:
         lib.rgbnm_set_option(b"gelu_table", 1)
+        lib.rgbnm_set_option(b"fwd_chain", 1)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])

@@ -2,7 +2,7 @@
 """How long the HOST needs to enqueue one train step (bench.py's step), against how long the GPU needs to run it: if the two
 are close, a slow or shared host makes the step launch-bound."""
 import sys, time, json, subprocess
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity-check", "--no-trace", "--prewarm-sec", "0.5"]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity-check", "--no-trace", "--prewarm-sec", "0.5"] + sys.argv[1:]
 import torch
 # re-use bench.main's construction by running it once, then grab its step closure through a hook
 orig_sync = torch.cuda.synchronize
@@ -11,7 +11,8 @@ def main():
     import types
     src = open("bench.py").read()
     # expose `step` of main(): patch the timed loop to stash the closure
-    src = src.replace("    t_pre = time.perf_counter()\n    while time.perf_counter() - t_pre < a.prewarm_sec:", "    globals()['_STEP'] = step\n    t_pre = time.perf_counter()\n    while time.perf_counter() - t_pre < a.prewarm_sec:", 1)
+    assert "    t_pre = time.perf_counter()\n" in src
+    src = src.replace("    t_pre = time.perf_counter()\n", "    globals()['_STEP'] = step\n    t_pre = time.perf_counter()\n", 1)
     g = {"__name__": "bench_patched", "__file__": "bench.py"}
     exec(compile(src, "bench.py", "exec"), g)
     g["main"]()
@@ -36,5 +37,5 @@ for _ in range(50):
 pr.disable()
 torch.cuda.synchronize()
 st = io.StringIO()
-pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(30)
 print("\n".join(l[:150] for l in st.getvalue().splitlines()[:70]))
