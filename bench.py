@@ -54,6 +54,11 @@ def parse():
     ap.add_argument("--cpu-baseline-images", type=int, default=512)     # ~10 s of CPU work at JPEG-Ti (17.7 ms / image on 16 threads)
     ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel HIP-event trace of the timed region")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B experiments)")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS, set before the process group "
+                         "is created -- RCCL reads them once per process, so this is a launch-time knob, not a calibrated candidate): "
+                         "every channel is a workgroup that holds a CU while the 256-workgroup compute kernels of this library want "
+                         "all of them; 0 = RCCL's default")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step from the host (no HIP graph replay)")
     ap.add_argument("--no-defer-reduce", action="store_true",
                     help="run every block's gradient reductions inside its backward instead of one launch per step")
@@ -63,14 +68,15 @@ def parse():
     return ap.parse_args()
 
 
-def _flat_sync_selfcheck(model, fsync, cdt, dev, B, dist):
+def _flat_sync_selfcheck(model, fsync, cdt, dev, B, dist, S=28):
     """One backward with the overlapped slice-wise exchange vs the same backward followed by ONE blocking all-reduce of
-    the whole flat gradient buffer: must agree on every rank (summation order inside RCCL may differ: tolerance)."""
+    the whole flat gradient buffer: must agree on every rank (summation order inside RCCL may differ: tolerance).
+    (The caller puts a model with DropPath into eval mode: the two passes must draw the same masks.)"""
     import torch
     g = torch.Generator(device=dev)
     g.manual_seed(99 + dist.get_rank())
-    y = torch.randn(B, 1, 28, 28, 8, 8, device=dev, generator=g)
-    c = torch.randn(B, 2, 14, 14, 8, 8, device=dev, generator=g)
+    y = torch.randn(B, 1, S, S, 8, 8, device=dev, generator=g)
+    c = torch.randn(B, 2, S // 2, S // 2, 8, 8, device=dev, generator=g)
 
     def backward():
         model.zero_grad(set_to_none=True)
@@ -331,6 +337,8 @@ def main():
         torch.cuda.set_stream(work_stream)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.rccl_channels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = os.environ["NCCL_MIN_NCHANNELS"] = str(a.rccl_channels)
         # "nccl" IS RCCL on ROCm; RGBNM_BENCH_BACKEND=gloo only for the 1-GPU smoke test above
         dist.init_process_group(os.environ.get("RGBNM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
@@ -363,22 +371,40 @@ def main():
     net = model
     grad_sync = "none"
     if world > 1:
-        grad_sync = "ddp" if swin else a.grad_sync      # the flat exchange hooks the ViT's autograd nodes
+        grad_sync = a.grad_sync
         if grad_sync == "flat":
             # zero-copy exchange: ~4 MB slices of the flat gradient buffer are all-reduced (RCCL, AVG) from inside the
             # backward as soon as a block's gradients are final (rgb_no_more_amd/parallel.py); verified below against
-            # one blocking all-reduce, with torch DDP as the fallback
+            # one blocking all-reduce, with torch DDP as the fallback.  SwinV2's backward hands autograd separate gradient
+            # tensors: GatheredFlatGradSync gathers each 16 MB bucket into the flat buffer when its last gradient arrives
+            # (post-accumulate hooks) and all-reduces the slice -- the copy the fused optimizer would do anyway, instead of
+            # DDP's 2 x 221 bucket copies
             try:
-                fsync = rg.parallel.FlatGradSync(model, bucket_bytes=4 << 20)
-                ok = _flat_sync_selfcheck(model, fsync, cdt, dev, a.batch, dist)
+                if swin:
+                    fsync = rg.parallel.GatheredFlatGradSync(model, bucket_bytes=16 << 20)
+                    model.eval()
+                else:
+                    fsync = rg.parallel.FlatGradSync(model, bucket_bytes=4 << 20)
+                try:
+                    ok = _flat_sync_selfcheck(model, fsync, cdt, dev, min(a.batch, 32) if swin else a.batch, dist, 32 if swin else 28)
+                finally:
+                    if swin:
+                        model.train()
             except Exception as e:          # noqa: BLE001
-                print(f"[rank {rank}] FlatGradSync unavailable ({type(e).__name__}: {e}); using torch DDP", file=sys.stderr)
+                print(f"[rank {rank}] flat gradient exchange unavailable ({type(e).__name__}: {e}); using torch DDP", file=sys.stderr)
                 ok = False
             flag = torch.tensor([1 if ok else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if flag.item() == 0:
+                if swin and model._grad_sync is not None:
+                    try:
+                        model._grad_sync.detach()
+                    except Exception:           # noqa: BLE001
+                        pass
                 model._grad_sync = None
                 grad_sync = "ddp"
+            elif swin:
+                grad_sync = "flat-gathered: 16 MB buckets gathered into the flat gradient buffer and all-reduced from post-accumulate hooks"
         if grad_sync == "ddp":
             model.defer_grad_reduction = False          # DDP's reducer reads .grad from hooks during the backward
             from torch.nn.parallel import DistributedDataParallel as DDP
@@ -651,6 +677,7 @@ def main():
                                     "model-only on S-randn inputs" if a.no_augment else
                                     "HIP DCT-augment of S-coef 512x512 coefficient batches resident in HBM"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "HIP graph replay of mixup-out -> forward -> loss -> backward; data stage and optimizer eager" if (graph is not None and use_graph) else "eager", "grad_sync": grad_sync if sync_schedule is None else f"{grad_sync}: {sync_schedule}", "grad_sync_calibration_ms_per_step": calib,
+                       "rccl_channels": a.rccl_channels or "default",
                        "loss": round(float(loss.item()), 5)},
             "parity_mode": ("bf16 operands, fp32 accumulate: every logit within 1e-2 of the fp32 reference (torch's own bf16 autocast of "
                             "the reference deviates 6e-3); the fp32 strict mode (--dtype fp32) carries the 1e-3 north-star "

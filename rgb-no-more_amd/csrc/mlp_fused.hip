@@ -411,6 +411,11 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(MlpArgs p) {
           // {D | gelu' << 16} per element (all eight in flight, one wait) -> |gelu| = max(a, 0x80) - D  (see the table comment
           // above gelu_full_kernel).  Packed 16-bit VALU by inline asm: the compiler's own selection of the same arithmetic
           // needed 28 instructions per pair against 17 here.
+          // Non-finite pre-activations: the unsigned clamp at N1 also catches sign-bit-set magnitudes of exponent row 255, so a
+          // NEGATIVE-signed NaN or -inf gives gelu = -0 with the finite large-negative gelu' (positive NaN / +inf pass through
+          // as gelu = u, gelu' = 1).  A NaN pre-activation comes from a NaN LayerNorm output or weight, which also reaches the
+          // residual stream and the logits through the other operands, so overflow checks on the loss / gradients still see it;
+          // an exact patch costs three packed instructions per element pair in the loop that bounds this kernel.
           unsigned pb[4], agv[4], alo[4], ahi[4], e0[4], e1[4];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {

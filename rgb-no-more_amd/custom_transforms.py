@@ -450,15 +450,17 @@ class ToRange(torch.nn.Module):
     def forward(self, coeff):
         Y, C, single, batched = _unpack(coeff)
         if not self._fused or Y.shape[2] != Y.shape[3] or Y.shape[2] not in (28, 32):
-            # any other range (the class default is orig_max = 1024, which no pipeline uses) or grid: the reference's two fp32
-            # statements (custom_transforms.py:450-451) as device tensor ops -- same operations in the same order, same bits
+            # any other range (the class default is orig_max = 1024, which no pipeline uses) or grid: the reference's statements
+            # (custom_transforms.py:447-451) as device tensor ops -- cast to self.dtype FIRST, then the two statements in that
+            # dtype, same operations in the same order, same bits (for bf16 too)
             L.require_cuda(Y) if C is None else L.require_cuda(Y, C)
 
             def f(x):
                 # a TENSOR divisor: dividing by a Python scalar is turned into a multiplication by its reciprocal on the device
-                den = torch.full((), float(self.orig_max - self.orig_min), device=x.device, dtype=torch.float32)
-                x = (x.to(torch.float32) - self.orig_min) / den
-                return (self.val_min + x * (self.val_max - self.val_min)).to(self.dtype)
+                x = x.to(self.dtype)
+                den = torch.full((), float(self.orig_max - self.orig_min), device=x.device, dtype=self.dtype)
+                x = (x - self.orig_min) / den
+                return self.val_min + x * (self.val_max - self.val_min)
             return _pack(f(Y), None if C is None else f(C), single, batched)
         return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * Y.shape[0], None, None, 0, self.dtype), single, batched)
 

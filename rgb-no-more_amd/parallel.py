@@ -113,6 +113,125 @@ class FlatGradSync:
         self.module._grad_sync = None
 
 
+class GatheredFlatGradSync:
+    """The same exchange for a FlatParamModule whose backward hands autograd SEPARATE gradient tensors (SwinV2: 221 of them,
+    models/swinv2.py:578-711; reference wrap: torch DDP, train.py:137).
+
+    Parameters are cut into buckets of consecutive flat segments (>= bucket_bytes, walked in REVERSE registration order = the
+    order the backward finishes them).  A post-accumulate hook per parameter counts arrivals; when a bucket is complete its
+    gradients are gathered into the bucket's slice of the model's flat gradient buffer with ONE multi-tensor copy (the very copy
+    the fused optimizer would do at the end of the step), every .grad is re-pointed at its flat view -- so the optimizer takes
+    its zero-copy path and clip / unscale see reduced values -- and the slice is all-reduced in place, asynchronously, while the
+    backward of the earlier stages still runs.  torch DDP does the same work as 2 x 221 bucket copies around its collectives.
+
+    The bucket that completes last also orders the stream behind every collective, so when `backward()` returns the gradients
+    are final in stream order (GradScaler.unscale_ / clip_grad_norm_ of train.py:159-166 see reduced values, as with DDP).
+    `wait()` (called by FusedClipAdamWWD.step) additionally flushes buckets a backward left incomplete -- parameters without a
+    gradient this step are exchanged as zeros.  One backward per step and zero_grad() between steps, as FlatGradSync."""
+
+    def __init__(self, module, process_group=None, bucket_bytes=16 << 20, broadcast=True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.module, self.pg = module, process_group
+        self.world = dist.get_world_size(process_group)
+        module._ensure_flat()
+        if broadcast:
+            dist.broadcast(module._flat, src=0, group=process_group)
+        self._avg = dist.get_backend(process_group) == "nccl"
+        self.bucket_elems = 1          # (read by ViT-side code that asks whether gradients are consumed during the backward)
+        names = list(module._named.keys())
+        self._buckets, cur = [], []
+        lim = max(1, bucket_bytes // 4)
+        for n in reversed(names):
+            cur.append(n)
+            lo = module._offs[cur[-1]]
+            hi = module._offs[cur[0]] + _numel(module._shapes[cur[0]])
+            if hi - lo >= lim:
+                self._buckets.append({"names": cur, "lo": lo, "hi": hi})
+                cur = []
+        if cur:
+            self._buckets.append({"names": cur, "lo": module._offs[cur[-1]], "hi": module._offs[cur[0]] + _numel(module._shapes[cur[0]])})
+        self._of = {}
+        for b in self._buckets:
+            b["left"] = len(b["names"])
+            b["done"] = False
+            for n in b["names"]:
+                self._of[n] = b
+        self._handles = []
+        self.collectives = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(n)) for n, p in module._named.items()]
+        module._grad_sync = self
+
+    def _make_hook(self, name):
+        def hook(param):
+            if self.module._grad_sync is not self:      # switched off (bench.py's self-check runs one plain backward)
+                return
+            b = self._of[name]
+            if b["done"]:
+                raise RuntimeError("GatheredFlatGradSync: a second backward reached an exchanged bucket (gradient accumulation "
+                                   "is not supported by the flat exchange; use torch DDP)")
+            b["left"] -= 1
+            if b["left"] == 0:
+                self._flush(b)
+        return hook
+
+    def begin_step(self):
+        """At the start of a differentiated forward: nothing of an earlier backward may be in flight, counts start over."""
+        for h, _ in self._handles:
+            h.wait()
+        self._handles.clear()
+        if any(p.grad is not None for p in self.module._named.values()):
+            raise RuntimeError("GatheredFlatGradSync: gradients of an earlier backward are still attached (gradient accumulation / "
+                               "zero_grad(set_to_none=False)); the flat exchange supports one backward per step after "
+                               "zero_grad(set_to_none=True) -- use torch DDP for accumulation")
+        for b in self._buckets:
+            b["left"], b["done"] = len(b["names"]), False
+
+    def _flush(self, b):
+        m = self.module
+        g = m._gflat
+        views, grads = [], []
+        for n in b["names"]:
+            p = m._named[n]
+            v = m._gview(g, n)
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+        if views:
+            torch._foreach_copy_(views, grads)
+        b["done"] = True
+        seg = g[b["lo"]:b["hi"]]
+        h = dist.all_reduce(seg, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._handles.append((h, seg))
+        self.collectives += 1
+        if all(x["done"] for x in self._buckets):
+            self._finish()          # the last bucket of the pass: when backward() returns the gradients are final in stream order
+
+    def _finish(self):
+        for h, seg in self._handles:
+            h.wait()
+            if not self._avg:
+                seg.mul_(1.0 / self.world)
+        self._handles.clear()
+
+    def wait(self):
+        """Flush what the backward left incomplete and order the stream behind every collective (no-op after a complete pass)."""
+        if any(b["done"] for b in self._buckets) or any(b["left"] != len(b["names"]) for b in self._buckets):
+            for b in self._buckets:
+                if not b["done"]:
+                    self._flush(b)
+        self._finish()
+
+    def detach(self):
+        self.wait()
+        for h in self._hooks:
+            h.remove()
+        self.module._grad_sync = None
+
+
 def _numel(shape):
     n = 1
     for s in shape:

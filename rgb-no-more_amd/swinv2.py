@@ -527,6 +527,8 @@ class SwinTransformerV2(FlatParamModule):
                                          self._conv[0].data_ptr(), self._conv[1].data_ptr(), feat.data_ptr(), B, Hb, Wb,
                                          L.stream()), "swin_embed")
         sh = self._prep(cdt)
+        if self._grad_sync is not None and torch.is_grad_enabled():
+            self._grad_sync.begin_step()          # parallel.GatheredFlatGradSync: bucket counts start over
         pe = self.patch_embed
         x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias, sh["patch_embed.projection.0"])
         x = _LNFn.apply(x, pe.norm.weight, pe.norm.bias, None, None, 1)

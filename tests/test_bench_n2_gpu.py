@@ -63,3 +63,13 @@ def test_bench_two_ranks_torch_ddp_path():
     assert d["config"]["launch"] == "eager"
     loss = d["config"]["loss"]
     assert loss == loss and 0 < loss < 20
+
+
+def test_bench_two_ranks_swinv2_gathered_flat_exchange():
+    """bench.py --arch swinv2t at N = 2: the gathered flat exchange (parallel.GatheredFlatGradSync) passes its self-check against one
+    blocking all-reduce and carries the step (config 5 no longer goes through torch DDP's bucket copies)."""
+    d = _run(["--arch", "swinv2t", "--batch", "32", "--no-parity-check"])
+    assert d["n_gpus"] == 2 and d["config"]["grad_sync"].startswith("flat-gathered"), d["config"]["grad_sync"]
+    assert d["config"]["global_batch"] == 64
+    loss = d["config"]["loss"]
+    assert loss == loss and 0 < loss < 20

@@ -70,6 +70,12 @@ def test_flip_crop_torange_are_bit_exact_vs_oracle():
         assert np.array_equal(gy.cpu().numpy(), O.to_range(Y, **kw)) and np.array_equal(gc.cpu().numpy(), O.to_range(C, **kw))
     Yr, _ = coeffs(1, 20, 36, 5)
     assert np.array_equal(CT.ToRange(-1, 1, -1024, 1016)(dev(Yr)).cpu().numpy(), O.to_range(Yr))      # non-square grid
+    # bf16 through the fallback: the reference casts FIRST and evaluates both statements in bf16 (custom_transforms.py:447-451)
+    gb = CT.ToRange(-2.0, 3.0, -1000, 1000, torch.bfloat16)(dev(Y))
+    xb = torch.from_numpy(Y).to(torch.bfloat16)
+    xb = (xb - (-1000)) / (1000 - (-1000))
+    xb = -2.0 + (xb * (3.0 - (-2.0)))
+    assert gb.dtype == torch.bfloat16 and torch.equal(gb.cpu(), xb)
 
 
 @pytest.mark.parametrize("size,side", [(28, 56), (28, 28), (28, 14), (32, 64), (32, 16)])
