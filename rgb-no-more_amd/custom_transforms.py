@@ -24,6 +24,9 @@ OPS = {"Identity": 0, "AutoContrast": 1, "Posterize": 2, "SolarizeAdd": 3, "Colo
        "MidfreqAug": 7, "Cutout": 8, "TranslateX": 9, "TranslateY": 10, "Rotate90": 11, "AutoSaturation": 12,
        "Grayscale": 13, "ChromaDrop": 14, "Sharpness": 15, "Invert": 16, "Solarize": 17, "FreqEnhance": 18, "Equalize": 19}
 CHROMA_OPS = {"Grayscale", "Color", "AutoSaturation", "ChromaDrop"}
+# The reference's DFT-plane ops (utils/dct_ops.py:367-434, 957-1013): in no DCT op list of utils/configs.py; they run as device tensor
+# ops between kernel passes (dct_ops.rotate_block / shear_block) and only through RandAugment_dct, not through the fused transform
+DFT_OPS = {"Rotate", "ShearX", "ShearY"}
 # default vitti list (utils/configs.py:93)
 VITTI_OPS = ("AutoContrast,Posterize,SolarizeAdd,Color,Contrast,Brightness,MidfreqAug,Cutout,TranslateX,TranslateY,"
              "Rotate90,AutoSaturation,Grayscale,ChromaDrop").split(",")
@@ -141,7 +144,8 @@ def magnitude_table(num_bins=11, image_size=(28, 28)):
             "TranslateY": (ls(0.0, 150.0 / 336.0 * image_size[0]), True), "Rotate90": (torch.tensor(1), True),
             "AutoSaturation": (z, False), "Grayscale": (z, False), "MidfreqAug": (ls(0.0, 0.9), True),
             "ChromaDrop": (z, False), "Invert": (z, False), "Equalize": (z, False), "Solarize": (ls(818, -818), False),
-            "FreqEnhance": (ls(0.0, 0.9), True)}
+            "FreqEnhance": (ls(0.0, 0.9), True),
+            "Rotate": (ls(0.0, 30.0), True), "ShearX": (ls(0.0, 17.0), True), "ShearY": (ls(0.0, 17.0), True)}   # :1073, :1081-1082
 
 
 class _FilterBank:
@@ -396,22 +400,28 @@ class RandomFlip_DCT(torch.nn.Module):
         return _pack(*_run_chain(Y, C, Y.shape[2], [_whole(Y)] * B, flips, ops, 0, torch.int16), single, batched)
 
 
-# ops_list=None: the reference's own default (custom_transforms.py:1060-1062) minus the DFT-domain Rotate / ShearX / ShearY, which
-# are not built; the fused transform and datasets.get_transform(fused=...) use the same list
+# ops_list=None for the FUSED transform and datasets.get_transform(fused=...): the reference's own default
+# (custom_transforms.py:1060-1062) minus the DFT-plane Rotate / ShearX / ShearY, which only the class below runs
 DEFAULT_OPS = ("AutoContrast", "Equalize", "Invert", "Posterize", "Solarize", "SolarizeAdd", "Color", "Contrast",
                "Brightness", "Sharpness", "Cutout", "TranslateX", "TranslateY")
+# RandAugment_dct(ops_list=None): the reference's default list itself, in its order
+REFERENCE_DEFAULT_OPS = ("AutoContrast", "Equalize", "Invert", "Rotate", "Posterize", "Solarize", "SolarizeAdd", "Color", "Contrast",
+                         "Brightness", "Sharpness", "ShearX", "ShearY", "Cutout", "TranslateX", "TranslateY")
 
 
 class RandAugment_dct(torch.nn.Module):
     """custom_transforms.py:1024-1138: clamp, then num_ops operations drawn from ops_list at magnitude bin `magnitude`
-    (random sign for the signed ones; chroma / grayscale mutual exclusion), clamp after every op."""
+    (random sign for the signed ones; chroma / grayscale mutual exclusion), clamp after every op.
+    `Rotate` / `ShearX` / `ShearY` (the reference's default list has them, no DCT list of utils/configs.py does) resample the DFT plane
+    of the padded image (`pad`, default sqrt(2) as in the reference) as device tensor ops between the kernel passes; their
+    torchvision sampling is restated, not pinned (dct_ops.py, oracle/dft_np.py)."""
 
     def __init__(self, num_ops: int = 2, magnitude: int = 10, num_magnitude_bins: int = 11, pad=2 ** 0.5, ops_list=None):
         super().__init__()
         self.num_ops, self.magnitude, self.num_magnitude_bins, self.pad = num_ops, magnitude, num_magnitude_bins, pad
         if ops_list is None:
-            ops_list = DEFAULT_OPS
-        bad = [o for o in ops_list if o not in OPS]
+            ops_list = REFERENCE_DEFAULT_OPS
+        bad = [o for o in ops_list if o not in OPS and o not in DFT_OPS]
         if bad:
             raise NotImplementedError(f"operations {bad} are not implemented on the HIP path")
         self.ops_list = list(ops_list)
@@ -430,8 +440,29 @@ class RandAugment_dct(torch.nn.Module):
         # the kernel chains two operations per pass (cfg.TRAIN.NUMOPS default 2); longer chains run as further passes over the int16
         # result -- the entry clamp of a later pass is the identity on what the previous pass's per-op clamp left
         n = max([len(c) for c in chosen] + [1])
-        for k in range(0, n, 2):
-            Y, C = _run_chain(Y, C, S, [_whole(Y)] * B, None, [c[k:k + 2] for c in chosen], 1, torch.int16)
+        if not any(o[0] in DFT_OPS for c in chosen for o in c):
+            for k in range(0, n, 2):
+                Y, C = _run_chain(Y, C, S, [_whole(Y)] * B, None, [c[k:k + 2] for c in chosen], 1, torch.int16)
+            return _pack(Y, C, single, batched)
+        # a DFT-plane op somewhere: one op per pass.  Pass k runs the kernel ops of position k (the entry clamp belongs to the first
+        # pass only: the reference clamps once, custom_transforms.py:1106-1107); samples whose op k is Rotate / ShearX / ShearY sit
+        # the pass out and go through dct_ops.rotate_block / shear_block (Y and CbCr with the same magnitude, :949-968)
+        for k in range(n):
+            kern = [[c[k]] if k < len(c) and c[k][0] not in DFT_OPS else [] for c in chosen]
+            if k == 0 or any(kern):
+                Y, C = _run_chain(Y, C, S, [_whole(Y)] * B, None, kern, 1 if k == 0 else 0, torch.int16)
+            for b, c in enumerate(chosen):
+                if k < len(c) and c[k][0] in DFT_OPS:
+                    name, mag = c[k][0], c[k][1]
+                    if name == "Rotate":
+                        f = lambda t: dops.rotate_block(t, degrees=mag, pad=self.pad)          # noqa: E731
+                    elif name == "ShearX":
+                        f = lambda t: dops.shear_block(t, deg_x=mag, pad=self.pad)             # noqa: E731
+                    else:
+                        f = lambda t: dops.shear_block(t, deg_y=mag, pad=self.pad)             # noqa: E731
+                    Y[b] = f(Y[b])
+                    if C is not None:
+                        C[b] = f(C[b])
         return _pack(Y, C, single, batched)
 
 
@@ -480,6 +511,10 @@ class TrainTransform_DCT(torch.nn.Module):
         self.size, self.flip_p, self.num_ops, self.magnitude = size, flip_p, num_ops, magnitude
         self.num_magnitude_bins = num_magnitude_bins
         self.ops_list = list(VITTI_OPS if ops_list is None else ops_list)
+        bad = [o for o in self.ops_list if o not in OPS]
+        if bad:
+            raise NotImplementedError(f"operations {bad} are not in the fused transform's kernels (the DFT-plane Rotate / ShearX / "
+                                      "ShearY run through the per-transform class RandAugment_dct)")
         self.out_dtype = out_dtype
         self.eval_mode = eval_mode
         self.rrc = RandomResizedCrop_DCT(size, scale=scale, ratio=(1, 1))

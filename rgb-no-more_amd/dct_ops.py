@@ -49,3 +49,155 @@ def midfreq_filter(intensity, KH=8, KW=8):
     if intensity >= 0:
         F = 1 / F
     return torch.roll(F, shifts=(-(KH // 2), -(KW // 2)), dims=(0, 1)).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# DFT-plane Rotate / ShearX / ShearY of RandAugment_dct (utils/dct_ops.py:210-232, 303-434, 957-1013,
+# utils/dct_torch_utils.py:232-321).  In no DCT op list of utils/configs.py, so not on the timed path: device TENSOR ops (complex
+# matrix products through the library, index arithmetic for the nearest-neighbour resampling), no kernel of this repo.  The
+# reference resamples with torchvision's rotate / affine; torchvision is not installed here, so the sampling below restates its
+# published tensor path (affine grid in fp32 + grid_sample nearest / zeros / align_corners=False) and the row is PARITY UNPINNED
+# (oracle/dft_np.py says the same; tests compare the two restatements and pin what can be pinned structurally).
+# ----------------------------------------------------------------------------------------------------------------
+_DFT_CONV = {}
+
+
+def generate_fourier_basis(length=8, scale=True, device="cpu"):
+    """utils/dct_ops.py:135-146."""
+    t = torch.arange(length, device=device, dtype=torch.float32)
+    basis = (t.unsqueeze(1).mm(t.unsqueeze(0)) * (-1j * 2 * torch.pi / length)).exp()
+    return basis / (length ** 0.5) if scale else basis
+
+
+def generate_conversion_matrix_dft(length_small=2, mult=2, device="cpu"):
+    """utils/dct_ops.py:210-232 (scale=True): small DCT blocks -> one large DFT; cached per (size, device)."""
+    key = (length_small, mult, str(device))
+    if key not in _DFT_CONV:
+        small = generate_basis_matrix(length_small, device=device)
+        blocks = torch.block_diag(*([small] * mult))
+        _DFT_CONV[key] = generate_fourier_basis(length_small * mult, device=device).mm(blocks.T.to(torch.complex64))
+    return _DFT_CONV[key]
+
+
+def combine_blocks_dft(coeff):
+    """utils/dct_ops.py:303-332 on (C,H,W,KH,KW)."""
+    C, H, W, KH, KW = coeff.shape
+    Lm = generate_conversion_matrix_dft(KH, H, coeff.device)
+    Mm = Lm if (H == W and KH == KW) else generate_conversion_matrix_dft(KW, W, coeff.device)
+    x = coeff.to(torch.complex64).permute(0, 1, 3, 2, 4).reshape(C, H * KH, W * KW)
+    y = torch.einsum("ho,cow->chw", Lm, x) * ((KH * H) ** 0.5)
+    y = torch.einsum("cho,ow->chw", y, torch.conj(Mm.T)) / ((KW * W) ** 0.5)
+    return y, Lm, Mm
+
+
+def decompose_block_dft(coeff, H, W, KH, KW, Lm, Mm):
+    """utils/dct_ops.py:334-364."""
+    y = torch.einsum("ho,cow->chw", torch.conj(Lm.T), coeff.to(torch.complex64)) / ((KH * H) ** 0.5)
+    y = torch.einsum("cho,ow->chw", y, Mm) * ((KW * W) ** 0.5)
+    return y.reshape(y.shape[0], H, KH, W, KW).permute(0, 1, 3, 2, 4).real
+
+
+def blockshift(x, dim=(1, 2)):
+    return torch.roll(torch.roll(x, x.shape[dim[0]] // 2, dim[0]), x.shape[dim[1]] // 2, dim[1])
+
+
+def iblockshift(x, dim=(1, 2)):
+    h, w = x.shape[dim[0]], x.shape[dim[1]]
+    return torch.roll(torch.roll(x, h - h // 2, dim[0]), w - w // 2, dim[1])
+
+
+def rotate_dct_90deg(coeff, rotate=0):
+    """utils/dct_ops.py:99-130: exact quarter turns (counter-clockwise count) of (C,H,W,KH,KW) by index and sign work."""
+    rotate = int(rotate)
+    sign = (rotate / abs(rotate)) if rotate != 0 else 1
+    r = abs(rotate) % 4
+    out = coeff.clone()
+    if r == 0:
+        return out
+    if sign * r == 3 or sign * r == -1:          # clockwise
+        out = torch.rot90(out, k=-1, dims=(1, 2)).transpose(-2, -1).contiguous()
+        out[..., 1::2] *= -1
+        return out
+    if r == 2:
+        out = torch.flip(out, dims=(1, 2)).contiguous()
+        out[..., 1::2, :] *= -1
+        out[..., 1::2] *= -1
+        return out
+    out = torch.rot90(out, k=1, dims=(1, 2)).transpose(-2, -1).contiguous()
+    out[..., 1::2, :] *= -1
+    return out
+
+
+def _inverse_affine_matrix(angle, shear):
+    """torchvision.transforms.functional._get_inverse_affine_matrix(center=[0,0], angle, translate=[0,0], scale=1, shear)."""
+    rot, sx, sy = math.radians(angle), math.radians(shear[0]), math.radians(shear[1])
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    return [d, -b, 0.0, -c, a, 0.0]
+
+
+def _resample_nearest(plane, matrix):
+    """torchvision's tensor path for rotate / affine with NEAREST, expand=False, fill 0 on a (C,H,W) fp32 plane: affine grid in
+    fp32 (_gen_affine_grid), then grid_sample(mode='nearest', padding_mode='zeros', align_corners=False) as explicit index math
+    (source index = round-half-even(((g + 1) * size - 1) / 2))."""
+    C, H, W = plane.shape
+    dev = plane.device
+    theta = torch.tensor(matrix, dtype=torch.float32, device=dev).reshape(2, 3)
+    base = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+    base[..., 0] = torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W, device=dev)
+    base[..., 1] = torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H, device=dev).unsqueeze(-1)
+    base[..., 2] = 1
+    rescaled = theta.T / torch.tensor([0.5 * W, 0.5 * H], dtype=torch.float32, device=dev)
+    grid = base.view(-1, 3).mm(rescaled).view(H, W, 2)
+    ix = torch.round(((grid[..., 0] + 1) * W - 1) / 2).long()
+    iy = torch.round(((grid[..., 1] + 1) * H - 1) / 2).long()
+    ok = (ix >= 0) & (ix < W) & (iy >= 0) & (iy < H)
+    src = (iy.clamp(0, H - 1) * W + ix.clamp(0, W - 1)).view(-1)
+    out = plane.reshape(C, -1)[:, src].view(C, H, W)
+    return out * ok.to(plane.dtype)
+
+
+def _dft_plane_op(coeff, matrix, pad, rot90s=0):
+    """The common part of rotate_block / shear_block (window=False): pad, [exact quarter turns of the PADDED grid -- its margins
+    differ by one block when the padded size is odd --], block shift, combine, fftshift, resample real and imaginary parts, inverse
+    shifts, decompose, crop, round for integer dtypes."""
+    C, H, W, KH, KW = coeff.shape
+    dt = coeff.dtype
+    x, hm, wm = coeff, 0, 0
+    if pad:
+        assert pad >= 1, "Padding should be larger than 1"
+        Hp, Wp = int(H * pad // 1), int(W * pad // 1)
+        hm, wm = (Hp - H) // 2, (Wp - W) // 2
+        x = torch.zeros(C, Hp, Wp, KH, KW, dtype=dt, device=coeff.device)
+        x[:, hm:hm + H, wm:wm + W] = coeff
+    if rot90s:
+        x = rotate_dct_90deg(x, rotate=rot90s)
+    Hp, Wp = x.shape[1], x.shape[2]
+    comp, Lm, Mm = combine_blocks_dft(blockshift(x))
+    sh = torch.fft.fftshift(comp, dim=(-2, -1))
+    res = torch.complex(_resample_nearest(sh.real.contiguous(), matrix), _resample_nearest(sh.imag.contiguous(), matrix))
+    dec = iblockshift(decompose_block_dft(torch.fft.ifftshift(res, dim=(-2, -1)), Hp, Wp, KH, KW, Lm, Mm))
+    if pad:
+        dec = dec[:, hm:hm + H, wm:wm + W]
+    if not dt.is_floating_point:
+        dec = torch.round(dec)
+    return dec.to(dt)
+
+
+def rotate_block(coeff, degrees=45, pad=False):
+    """utils/dct_ops.py:367-434 on a device tensor (C,H,W,KH,KW): counter-clockwise; quarter turns exactly, the remainder in
+    (-45, 45] on the DFT plane."""
+    sign = degrees / abs(degrees) if degrees != 0 else 1
+    rem = sign * (abs(degrees) % 360)
+    shifted = (rem + 360 + 45) % 360
+    rot90s = shifted // 90
+    left = -((rot90s * 90) - (shifted - 45))
+    # dct_torch_utils.py:247 negates the angle, torchvision's rotate negates it again for its inverse matrix: +left here
+    return _dft_plane_op(coeff, _inverse_affine_matrix(left, [0.0, 0.0]), pad, rot90s=int(rot90s))
+
+
+def shear_block(coeff, deg_x=0, deg_y=0, pad=False):
+    """utils/dct_ops.py:957-1013 on a device tensor."""
+    return _dft_plane_op(coeff, _inverse_affine_matrix(0.0, [deg_x, deg_y]), pad)

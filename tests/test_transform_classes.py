@@ -133,7 +133,53 @@ def test_randaugment_class_vs_oracle_ops():
     sy, sc = ra((dev(Y), dev(C)))
     assert sy.dtype == torch.int16 and sy.shape == (2, 1, 28, 28, 8, 8) and int(sy.max()) <= 1016 and int(sy.min()) >= -1024
     with pytest.raises(NotImplementedError):
-        CT.RandAugment_dct(ops_list=["Rotate"])
+        CT.RandAugment_dct(ops_list=["Warp"])
+    with pytest.raises(NotImplementedError):
+        CT.TrainTransform_DCT(size=28, ops_list=["Rotate"])          # the fused transform has no DFT-plane ops
+
+
+def test_dft_plane_rotate_and_shear_vs_oracle():
+    """Rotate / ShearX / ShearY of RandAugment_dct (custom_transforms.py:949-968, dct_ops.py:367-434, 957-1013) against
+    oracle/dft_np.py -- PARITY UNPINNED (both restate torchvision's nearest-neighbour rotate / affine, which could not be run next
+    to the reference); chained with kernel ops on either side, per-sample magnitudes, the reference's sqrt(2) padding.  The complex
+    matrix products are summed in another order on the device: <= 1 LSB on a handful of rounding ties (3e-4 of the coefficients
+    after one such op, 5e-3 after two)."""
+    from oracle import dft_np as D
+    Y, C = coeffs(2, 28, 28, 77)
+    meta = CT.magnitude_table(11, (28, 28))
+    assert float(meta["Rotate"][0][10]) == 30.0 and float(meta["ShearX"][0][10]) == 17.0 and meta["ShearY"][1]
+    ra = CT.RandAugment_dct(num_ops=2, magnitude=3)
+    assert "Rotate" in ra.ops_list and "ShearX" in ra.ops_list and "ShearY" in ra.ops_list      # the reference's default list
+    cases = [[("Rotate", 9.0, None), ("Brightness", 0.27, None)],
+             [("Contrast", -0.27, None), ("ShearX", float(meta["ShearX"][0][3]), None)],
+             [("ShearY", -float(meta["ShearY"][0][3]), None), ("Rotate", -100.0, None)],
+             [("Rotate", 90.0, None), ("TranslateX", float(meta["TranslateX"][0][3]), None)]]
+    for ops in cases:
+        oy, oc = ra((dev(Y), dev(C)), ops=ops)
+        assert oy.dtype == torch.int16 and oc.shape == (2, 2, 14, 14, 8, 8)
+        for b in range(2):
+            ry, rc = np.clip(Y[b], -1024, 1016), np.clip(C[b], -1024, 1016)
+            for name, mag, aux in ops:
+                if name in CT.DFT_OPS:
+                    ry, rc = D.apply_dft_op(ry, rc, name, mag, pad=2 ** 0.5)
+                else:
+                    ry, rc = O.apply_op(ry, rc, name, mag, aux)
+            for got, ref in ((oy[b].cpu().numpy(), ry), (oc[b].cpu().numpy(), rc)):
+                d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+                # (a second DFT-plane op spreads every 1-LSB difference of its input over its whole output: more ties flip)
+                bound = 2e-3 if sum(o[0] in CT.DFT_OPS for o in ops) < 2 else 2e-2
+                assert d.max() <= 1 and (d > 0).mean() < bound, (ops, d.max(), (d > 0).mean())
+    # quarter turns are exact index work: the same bits as the oracle (which, like the reference, turns the PADDED grid -- 39 blocks,
+    # margins 5 and 6 -- so the result is the exact Rotate90 only where the padded size is even), and exactly Rotate90 without padding
+    oy, oc = ra((dev(Y), dev(C)), ops=[("Rotate", 90.0, None)])
+    assert np.array_equal(oy[0].cpu().numpy(), D.rotate_block(np.clip(Y[0], -1024, 1016), 90.0, 2 ** 0.5))
+    oy, oc = CT.RandAugment_dct(num_ops=1, pad=False)((dev(Y), dev(C)), ops=[("Rotate", -90.0, None)])
+    assert np.array_equal(oy[1].cpu().numpy(), O.rotate90(np.clip(Y[1], -1024, 1016), -1))
+    assert np.array_equal(oc[1].cpu().numpy(), O.rotate90(np.clip(C[1], -1024, 1016), -1))
+    # sampled path with the default list: runs, int16, per-sample ops
+    torch.manual_seed(5)
+    sy, sc = CT.RandAugment_dct(num_ops=2, magnitude=5, ops_list=["Rotate", "ShearX", "ShearY", "Color"])((dev(Y), dev(C)))
+    assert sy.dtype == torch.int16 and sy.shape == (2, 1, 28, 28, 8, 8) and sc.dtype == torch.int16
 
 
 def test_get_transform_chain_equals_fused_transform_bitwise():
