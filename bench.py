@@ -138,13 +138,7 @@ def cpu_baseline(arch, n_images, batch=8):
     from rgb_no_more_amd import custom_transforms as CT
     emb, heads = ARCH[arch]
     depth = 12
-    ncpu = os.cpu_count() or 1
-    try:                                   # honour a cgroup CPU quota (the GPU box: 16 of 256 hardware threads)
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            ncpu = max(1, min(ncpu, int(int(q) / int(per))))
-    except (OSError, ValueError):
-        pass
+    ncpu = min(os.cpu_count() or 1, _cgroup_cpu_quota() or (os.cpu_count() or 1))      # honour a cgroup CPU quota (the GPU box: 16 of 256 hardware threads)
     torch.set_num_threads(min(32, ncpu))   # batch-8 fp32 GEMMs stop scaling well before 128 threads
     swin = arch == "swinv2t"
     size = 32 if swin else 28
@@ -309,10 +303,39 @@ def decode_leg(n=16):
     return (time.perf_counter() - t0) / n
 
 
+def _cgroup_cpu_quota():
+    """CPUs the cgroup grants (cpu.max), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        return None
+
+
+def _cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this cgroup so far."""
+    try:
+        d = dict(ln.split() for ln in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return 0, 0
+
+
 def main():
     a = parse()
+    # The GPU box shows 256 hardware threads and grants 16 (cgroup cpu.max).  Left alone, torch / OpenMP size their pools by the 256:
+    # one parallel CPU op (the parity check in front of the timed region has several) leaves hundreds of spinning workers, the
+    # cgroup burns its quota in a few milliseconds and EVERY thread of the process -- the one that feeds the GPU included -- is
+    # frozen for the rest of the 100 ms period: the 16-step queue drains and the step time jumps by 5 - 20 % from run to run with
+    # unchanged kernel times (profiles/r04_host_throttle.txt).  Size the pools by the quota, and let idle workers sleep.
+    quota = _cgroup_cpu_quota()
+    nthr = max(1, min(os.cpu_count() or 1, quota or (os.cpu_count() or 1), 16))
+    os.environ.setdefault("OMP_NUM_THREADS", str(nthr))
+    os.environ.setdefault("MKL_NUM_THREADS", str(nthr))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import numpy as np
     import torch
+    torch.set_num_threads(nthr)
     import torch.distributed as dist
     import rgb_no_more_amd as rg
     from rgb_no_more_amd import lib as L
@@ -593,8 +616,20 @@ def main():
               (1, "gemm_nt", "gemm_nt family (gemm_nt_wres / gemm_nt_kpipe / gemm_nt / fused MLP: nn.Linear forward + dX GEMMs with their fused epilogues)"))
     TRACE_MASK = sum(1 << t for t, _, _ in TRACED)
     trace_on = (not a.no_trace) and rank == 0
+    # The set-up above left a few hundred thousand long-lived Python objects (modules, golden vectors, ctypes tables).  A full
+    # collection of that heap takes the interpreter 70 - 100 ms, and the allocation count of the eager steps triggered one at a fixed
+    # step of the timed region (step 64 of 80: faulthandler showed the main thread inside a plain attribute loop) -- longer than the
+    # 16 queued steps last, so the GPU ran dry: +0.1 - 0.4 ms per step over an 80-step region, differing from run to run.  Collect
+    # now and move the survivors to the permanent generation: later collections only look at what the loop itself allocates.
+    import gc
+    gc.collect()
+    gc.freeze()
+    if trace_on:
+        # every event the traced steps of the timed region will record exists before it starts (rgbnm.h rgbnm_trace_reserve: a
+        # signal-pool growth inside a traced step froze the host for 70 - 85 ms and the GPU ran dry)
+        L.check(lib.rgbnm_trace_reserve((a.steps // 8 + 2) * 64), "trace_reserve")
     for i in range(a.warmup):
-        if trace_on and i == 0:            # fill the library's event pool outside the timed region
+        if trace_on and i == 0:            # one traced step outside the timed region (first-use costs of the bracketing itself)
             lib.rgbnm_set_option(b"trace", TRACE_MASK)
         step(eager=trace_on and i == 0)
         if trace_on and i == 0:
@@ -602,7 +637,10 @@ def main():
             for t_, _, _ in TRACED:
                 lib.rgbnm_trace_collect(t_, None, None, None, None)
     traced_steps = 0
+    step_times = [] if os.environ.get("RGBNM_BENCH_STEPTIMES") else None      # debug: host time of every timed step
     barrier()
+    L.HOST_WAIT["sec"] = 0.0
+    thr0, cpu0 = _cgroup_throttle(), time.process_time()
     t0 = time.perf_counter()
     for i in range(a.steps):
         # HIP-event brackets around the dominant kernel class on every 8th timed step (keeps the probe's own cost,
@@ -611,17 +649,33 @@ def main():
         if tr:
             lib.rgbnm_set_option(b"trace", TRACE_MASK)
             traced_steps += 1
+        if step_times is not None:
+            ts0, hw0 = time.perf_counter(), L.HOST_WAIT["sec"]
+            if tr:
+                import faulthandler
+                faulthandler.dump_traceback_later(0.03, exit=False)       # a traced step that takes > 30 ms shows where it sits
         loss = step(eager=tr)
+        if step_times is not None and tr:
+            faulthandler.cancel_dump_traceback_later()
         if tr:
             lib.rgbnm_set_option(b"trace", 0)
+        if step_times is not None:
+            step_times.append((time.perf_counter() - ts0 - (L.HOST_WAIT["sec"] - hw0), i, tr))
+    t_enq = time.perf_counter() - t0          # the host has enqueued every step (it may be up to 16 steps ahead of the GPU)
+    host_wait = L.HOST_WAIT["sec"]
     barrier()
     dt = time.perf_counter() - t0
+    thr1, cpu1 = _cgroup_throttle(), time.process_time()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     ms = dt / a.steps * 1e3
     value = world * B * a.steps / dt
+    if rank == 0 and step_times:
+        worst = sorted(step_times, reverse=True)[:6]
+        print("[bench] slowest steps on the host (ms, index, traced): " + ", ".join(f"({1e3 * t:.2f}, {i}, {int(tr)})" for t, i, tr in worst)
+              + f"; median {1e3 * sorted(step_times)[len(step_times) // 2][0]:.2f}", file=sys.stderr)
     if rank == 0:
         lib.rgbnm_set_option(b"trace", 0)
         peak = MFMA_PEAK[a.dtype]
@@ -683,6 +737,14 @@ def main():
                             "the reference deviates 6e-3); the fp32 strict mode (--dtype fp32) carries the 1e-3 north-star "
                             "tolerance (tests/test_fastpath_model.py)") if a.dtype == "bf16" else "fp32 strict mode: logits within 1e-3 of the reference",
             "parity_check": pcheck,
+            # host side of the timed loop: time to enqueue all steps minus the time blocked on the 16-slot rings = what the host
+            # needs per step; when that approaches ms_per_step the host, not the GPU, paces the loop
+            "host_ms_per_step": round((t_enq - host_wait) / a.steps * 1e3, 3),
+            "host_blocked_on_rings_ms_per_step": round(host_wait / a.steps * 1e3, 3),
+            # CPU side of the timed region: cores this process kept busy, and how often / how long the cgroup was frozen for
+            # exceeding its quota (any freeze longer than the queued work idles the GPU)
+            "host_cpu": {"threads": nthr, "cgroup_quota_cpus": quota, "process_cores_busy": round((cpu1 - cpu0) / dt, 2),
+                         "cgroup_throttled_periods": thr1[0] - thr0[0], "cgroup_throttled_ms": round((thr1[1] - thr0[1]) / 1e3, 1)},
             "mfma_pct_whole_step": round(100 * step_tflops / peak, 2),
             "step_tflops_per_gpu": round(step_tflops, 1),
             "roofline": roof,

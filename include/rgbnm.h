@@ -55,9 +55,13 @@ int rgbnm_abi_version(void);
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
 /* With option "trace" = (1 << tag) the launchers bracket kernels of that class with HIP events recorded on the launch
- * stream (tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd).  collect() synchronises those events and
+ * stream (tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd, 5 one-launch encoder forward, 6 one-launch encoder backward).  collect() synchronises those events and
  * returns their summed elapsed ms plus the algorithmic FLOPs / bytes of the bracketed launches, then forgets them. */
 int rgbnm_trace_collect(int tag, double* ms_total, double* flops_total, double* bytes_total, int* count);
+/* Create the events of the next n_events / 2 bracketed launches NOW (call outside a timed region: the runtime grows its signal
+ * pool in chunks, and the chunk that a traced step happens to trigger costs the host tens of milliseconds -- 70 - 85 ms measured in
+ * the 9th traced step of bench.py, enough to drain a 16-step queue). */
+int rgbnm_trace_reserve(int n_events);
 /* human readable text for a negative return code */
 const char* rgbnm_strerror(int code);
 

@@ -1,5 +1,6 @@
 """Mirror of the reference `utils/cls_transforms.py::RandomMixup_DCT` (:100-193) on device tensors, plus the
 soft-label cross entropy used on its output (pipeline_utils.py:535)."""
+import time
 from typing import Tuple
 
 import torch
@@ -39,7 +40,9 @@ class RandomMixup_DCT(torch.nn.Module):
         i = st["i"]
         st["i"] = (i + 1) % self._SLOTS
         if st["ev"][i] is not None:
+            t0 = time.perf_counter()
             st["ev"][i].synchronize()          # the copy that last used this pinned slot (16 steps ago) has long completed
+            L.HOST_WAIT["sec"] += time.perf_counter() - t0
         st["host"][i].copy_(lam)
         st["dev"][i].copy_(st["host"][i], non_blocking=True)
         ev = torch.cuda.Event()

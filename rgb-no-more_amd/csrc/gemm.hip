@@ -548,10 +548,13 @@ int tn_flush(hipStream_t st) {
     const GemmTN& p = g_tn_q[i].p;
     jobs[i].dY = p.dY; jobs[i].X = p.X; jobs[i].part = p.part; jobs[i].bpart = g_tn_q[i].db ? p.bpart : nullptr;
     jobs[i].ldy = p.ldy; jobs[i].ldx = p.ldx; jobs[i].M = p.M; jobs[i].No = p.No; jobs[i].Ki = p.Ki;
+    jobs[i].dW = g_tn_q[i].dW; jobs[i].db = g_tn_q[i].db; jobs[i].perm_heads = g_tn_q[i].perm_heads;
+    jobs[i].accumulate = g_tn_q[i].accumulate;
   }
-  int S = 0;
-  const int rc = rgbnm_launch_tn_pipe_group(jobs, n, &S, st);
+  int S = 0, direct = 0;
+  const int rc = rgbnm_launch_tn_pipe_group(jobs, n, &S, st, rgbnm_get_option("tn_direct") ? &direct : nullptr);
   if (rc != RGBNM_OK) return rc < 0 ? rc : RGBNM_EINVAL;     // eligibility was checked when the jobs were queued
+  if (direct) return RGBNM_OK;                               // no token split: the kernel wrote dW / db itself
   for (int i = 0; i < n; ++i) {
     const int rr = submit_tn_reduce(g_tn_q[i].p, g_tn_q[i].dW, g_tn_q[i].db, S, g_tn_q[i].perm_heads,
                                     g_tn_q[i].accumulate, st);

@@ -46,6 +46,7 @@ constexpr int TN_MAXJOBS = 48;
 struct TnJobK {                   // per job, in the kernel argument segment
   const bf16* dY; const bf16* X; float* part; float* bpart;
   int ldy, ldx, No, Ki, ctiles, tile_end;       // tile_end: running sum of rtiles * ctiles
+  int perm;                                     // > 0: output rows leave permuted (qkv de-interleave, reduce.hip qkv_row_r) -- direct writes only
 };
 struct TnGroup {
   TnJobK j[TN_MAXJOBS];
@@ -94,10 +95,12 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   while (tile >= grp.j[job].tile_end) ++job;          // (uniform: scalar loads from the argument segment)
   if (job) tile -= grp.j[job - 1].tile_end;
   TnPipe p;
+  int perm;
   {
     const TnJobK& q = grp.j[job];
     p.dY = q.dY; p.X = q.X; p.part = q.part; p.bpart = q.bpart; p.ldy = q.ldy; p.ldx = q.ldx; p.No = q.No; p.Ki = q.Ki;
     p.ctiles = q.ctiles; p.M = grp.M; p.S = grp.S; p.kt_per_split = grp.kt_per_split; p.rtiles = 0;
+    perm = q.perm;
   }
   const int rt = tile / p.ctiles, ct = tile % p.ctiles;
   const int r0 = rt * 128, c0 = ct * 192;
@@ -194,22 +197,31 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
 #undef CHUNK
   }
 
+  // (perm > 0 only in a launch without a token split, where part / bpart ARE the gradient tensors: the rows leave in the order
+  // the reduction would have given them)
   float* part = p.part + (size_t)s * p.No * p.Ki;
+  int orow[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = r0 + wm * 32 + acc_row(r, lane);
+    int o = row;
+    if (perm > 0) {
+      const int inner = perm * 64, s3 = row / inner, rem = row % inner;
+      o = (rem / 64) * 192 + (rem % 64) * 3 + s3;
+    }
+    orow[r] = row < p.No ? o : -1;
+  }
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     const int col = c0 + wn * 96 + b * 32 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = r0 + wm * 32 + acc_row(r, lane);
-      if (row < p.No) part[(size_t)row * p.Ki + col] = acc[b][r];
-    }
+    for (int r = 0; r < 16; ++r)
+      if (orow[r] >= 0) part[(size_t)orow[r] * p.Ki + col] = acc[b][r];
   }
   if (do_bias && l31 == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = r0 + wm * 32 + acc_row(r, lane);
-      if (row < p.No) p.bpart[(size_t)s * p.No + row] = accb[r];
-    }
+    for (int r = 0; r < 16; ++r)
+      if (orow[r] >= 0) p.bpart[(size_t)s * p.No + orow[r]] = accb[r];
   }
 }
 
@@ -388,7 +400,8 @@ int tn_fill(TnPipe& p, const void* dY, int ldy, const void* X, int ldx, float* p
 }  // namespace
 
 // jobs[0..n): same M; returns 1 when a job is not eligible (nothing launched), S (common split count) through S_out
-int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st) {
+int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st, int* direct_out) {
+  if (direct_out) *direct_out = 0;
   if (n < 1 || n > TN_MAXJOBS) return RGBNM_EINVAL;
   static DevOnce attr_set;
   if (attr_set.need()) {
@@ -407,7 +420,7 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
     tiles += t.rtiles * t.ctiles;
     TnJobK& q = g.j[i];
     q.dY = t.dY; q.X = t.X; q.part = t.part; q.bpart = t.bpart; q.ldy = t.ldy; q.ldx = t.ldx; q.No = t.No; q.Ki = t.Ki;
-    q.ctiles = t.ctiles; q.tile_end = tiles;
+    q.ctiles = t.ctiles; q.tile_end = tiles; q.perm = 0;
     flops += 2.0 * j.M * (double)j.No * j.Ki;
     bytes += ((double)j.M * j.No + (double)j.M * j.Ki) * 2.0 + (double)j.No * j.Ki * 4.0;
   }
@@ -422,6 +435,24 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   S = cdiv(ktiles, kt_per);
   g.njobs = n; g.S = S; g.tiles = tiles; g.M = jobs[0].M; g.kt_per_split = kt_per;
   *S_out = S;
+  if (S == 1 && direct_out) {
+    // no token split: the "partials" are the result.  Write the gradient tensors from the kernel (row permutation included) and
+    // spare the reduction launch its copy of every weight gradient (22.6 MB read + written per JPEG-Ti step)
+    bool ok = true;
+    for (int i = 0; i < n; ++i)
+      ok = ok && jobs[i].dW && !jobs[i].accumulate && (jobs[i].bpart == nullptr || jobs[i].db) &&
+           (jobs[i].perm_heads <= 0 || jobs[i].No == 3 * jobs[i].perm_heads * 64);
+    if (ok) {
+      for (int i = 0; i < n; ++i) {
+        g.j[i].part = jobs[i].dW;
+        g.j[i].bpart = jobs[i].bpart ? jobs[i].db : nullptr;
+        g.j[i].perm = jobs[i].perm_heads > 0 ? jobs[i].perm_heads : 0;
+      }
+      for (int i = n; i < TN_MAXJOBS; ++i) g.j[i] = g.j[0];
+      for (int i = n; i < TN_MAXJOBS; ++i) g.j[i].tile_end = tiles;
+      *direct_out = 1;
+    }
+  }
   const int slot = rgbnm_trace_begin(TR_TN, flops, bytes, st);
   hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(256), dim3(512), SMEM, st, g);
   rgbnm_trace_end(slot, st);
@@ -435,6 +466,7 @@ int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float*
   if (!square) {
     RgbnmTnJob j;
     j.dY = dY; j.X = X; j.part = part; j.bpart = bpart; j.ldy = ldy; j.ldx = ldx; j.M = M; j.No = No; j.Ki = Ki;
+    j.dW = nullptr; j.db = nullptr; j.perm_heads = 0; j.accumulate = 0;
     return rgbnm_launch_tn_pipe_group(&j, 1, S_out, st);
   }
   TnPipe p;

@@ -9,8 +9,13 @@ constexpr int RGBNM_TN_MAX_SPLIT = 128;   // token-axis splits of a weight-gradi
 struct RgbnmTnJob {
   const void* dY; const void* X; float* part; float* bpart;
   int ldy, ldx, M, No, Ki;
+  // where the reduced result goes (may be null: always through part / bpart): when the launch ends up WITHOUT a token split
+  // (S == 1) and accumulate == 0 the kernel writes dW / db itself -- rows permuted as the reduction would (perm_heads) -- instead
+  // of partials that a reduction launch only copies
+  float* dW; float* db; int perm_heads, accumulate;
 };
-int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st);
+// *direct_out (may be null) = 1 when the kernel wrote dW / db of every job itself: the caller submits no reductions
+int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st, int* direct_out = nullptr);
 // Queue the eligible bf16 rgbnm_gemm_tn calls that follow and run them as one grouped launch at flush (or when 4 are
 // queued); their partial reductions are submitted at flush.  Used by rgbnm_vit_block_bwd to pair fc2/fc1 and proj/qkv.
 void rgbnm_tn_defer_begin();

@@ -32,7 +32,7 @@ hipEvent_t take_event() {
 // process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
 // they select between parity-tested kernels and are meant to be set before work is enqueued
 struct Opt { const char* name; std::atomic<int> value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"attn_proj", 0}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}, {"bwd_chain", 1}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"attn_proj", 0}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}, {"bwd_chain", 1}, {"tn_direct", 1}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -68,6 +68,17 @@ int rgbnm_get_option(const char* name) {
   for (auto& o : g_opts)
     if (name && !strcmp(o.name, name)) return o.value.load(std::memory_order_relaxed);
   return -1;
+}
+
+int rgbnm_trace_reserve(int n_events) {
+  if (n_events < 0 || n_events > (1 << 16)) return RGBNM_EINVAL;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  while ((int)g_event_pool.size() < n_events) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return RGBNM_ELAUNCH;
+    g_event_pool.push_back(e);
+  }
+  return RGBNM_OK;
 }
 
 int rgbnm_trace_collect(int tag, double* ms_total, double* flops_total, double* bytes_total, int* count) {

@@ -12,6 +12,7 @@ Here the same chain runs as two HIP kernels per batch (csrc/augment.hip) on the 
 """
 import ctypes as C
 import itertools
+import time
 import math
 
 import numpy as np
@@ -730,7 +731,9 @@ def _params_to_device(t, host, dev):
     i = ring["i"]
     ring["i"] = (i + 1) % _PARAM_SLOTS
     if ring["ev"][i] is not None:
+        t0 = time.perf_counter()
         ring["ev"][i].synchronize()
+        L.HOST_WAIT["sec"] += time.perf_counter() - t0
     slot = ring["host"][i, :nbytes]
     slot.numpy()[:] = host.view(np.uint8).reshape(-1)
     pdev = torch.empty(nbytes, device=dev, dtype=torch.uint8)

@@ -12,6 +12,9 @@ DT_F32, DT_BF16 = 0, 1
 EPI_NONE, EPI_RES, EPI_GELU, EPI_POS, EPI_DGELU, EPI_TANH, EPI_DTANH = range(7)
 
 _vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+# seconds the host spent blocked on the pinned-slot rings of the per-step records (augment parameters, mixup lambda): the host runs
+# up to 16 steps ahead of the GPU and waits HERE; a value near zero over a timed loop means the host, not the GPU, paces the loop
+HOST_WAIT = {"sec": 0.0}
 
 
 class LinearDesc(C.Structure):
@@ -78,6 +81,7 @@ PROTOTYPES = {
     "rgbnm_gemm_tn_group_end": (_i, [_vp]),
     "rgbnm_get_option": (_i, [C.c_char_p]),
     "rgbnm_trace_collect": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "rgbnm_trace_reserve": (_i, [_i]),
     "rgbnm_gemm_nt": (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbnm_gemm_tn_workspace": (_sz, [_i, _i, _i]),
     "rgbnm_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

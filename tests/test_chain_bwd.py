@@ -68,7 +68,7 @@ def test_data_path_same_bits():
     assert torch.equal(a["dx"], b["dx"][0]) or torch.equal(a["dx"], b["dx"][1])
 
 
-@pytest.mark.parametrize("depth,B", [(1, 3), (3, 5), (12, 64)])
+@pytest.mark.parametrize("depth,B", [(1, 3), (3, 5), (12, 64), (2, 300)])       # 300: more workgroups than CUs (a second round)
 def test_other_batches(depth, B):
     m, y, c, tgt = build(depth, B)
     gc = step(m, y, c, tgt, True)
@@ -94,3 +94,19 @@ def test_bit_reproducible():
     b = step(m, y, c, tgt, True)
     for n in a:
         np.testing.assert_array_equal(a[n], b[n])
+
+
+def test_direct_weight_gradient_writes_equal_the_reduced_ones():
+    """All 48 weight-gradient GEMMs in one launch leave no token split: the kernel then writes dW / db itself (qkv rows permuted as
+    the reduction would, option tn_direct) instead of partials that a reduction launch only copies -- the same bits."""
+    m, y, c, tgt = build(12, 256)
+    lib = L.lib()
+    try:
+        lib.rgbnm_set_option(b"tn_direct", 1)
+        a = step(m, y, c, tgt, True)
+        lib.rgbnm_set_option(b"tn_direct", 0)
+        b = step(m, y, c, tgt, True)
+    finally:
+        lib.rgbnm_set_option(b"tn_direct", 1)
+    for n in a:
+        assert np.array_equal(a[n], b[n]), n

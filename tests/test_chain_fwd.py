@@ -73,7 +73,7 @@ def test_chain_is_selected():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("depth,B", [(1, 4), (2, 5), (12, 64)])
+@pytest.mark.parametrize("depth,B", [(1, 4), (2, 5), (12, 64), (2, 300)])      # 300: more workgroups than CUs (a second round)
 def test_saved_tensors_match_the_per_operation_path(depth, B):
     m, y, c, tgt = build(depth, B)
     lo_c, g_c, (sv_c, x_c) = step(m, y, c, tgt, True, keep_saved=True)

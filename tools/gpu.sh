@@ -20,7 +20,7 @@
 #   tools/winattn_prof.py [shift] [fwd]      cycle stamps inside the window-attention kernels (build with RGBNM_HIPCC_FLAGS=-DWIN_PROF[=2])
 export TMPDIR=/tmp
 CMD=$1; shift
-line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('$1', d['value'], d['ms_per_step'], r.get('avg_launch_us'), (d.get('parity_check') or {}).get('max_abs_dlogit'))"; }
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('$1', d['value'], d['ms_per_step'], r.get('avg_launch_us'), (d.get('parity_check') or {}).get('max_abs_dlogit'), 'host', d.get('host_ms_per_step'), 'blocked', d.get('host_blocked_on_rings_ms_per_step'), d.get('host_cpu'))"; }
 kstats() {   # kstats <outdir> <bench args...>
   local OUT=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python bench.py --steps 24 --warmup 4 --prewarm-sec 1 --no-cpu-baseline --no-trace "$@" > $OUT/kt.log 2>&1
