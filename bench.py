@@ -329,7 +329,8 @@ def main():
     # frozen for the rest of the 100 ms period: the 16-step queue drains and the step time jumps by 5 - 20 % from run to run with
     # unchanged kernel times (profiles/r04_host_throttle.txt).  Size the pools by the quota, and let idle workers sleep.
     quota = _cgroup_cpu_quota()
-    nthr = max(1, min(os.cpu_count() or 1, quota or (os.cpu_count() or 1), 16))
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))      # the ranks of this node share the quota
+    nthr = max(1, min(os.cpu_count() or 1, (quota or (os.cpu_count() or 1)) // ranks_here or 1, 16))
     os.environ.setdefault("OMP_NUM_THREADS", str(nthr))
     os.environ.setdefault("MKL_NUM_THREADS", str(nthr))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
