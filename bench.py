@@ -352,11 +352,11 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    # Graph mode (one GPU, ViT): the whole run uses ONE non-default stream -- a HIP graph cannot be captured on the legacy
+    # Graph mode (one GPU): the whole run uses ONE non-default stream -- a HIP graph cannot be captured on the legacy
     # default stream, and autograd ties every parameter's AccumulateGrad node to the stream of its first use: capturing on a
     # side stream while the eager steps run on the default one costs ~150 cross-stream event waits per eager backward
     work_stream = None
-    if a.arch != "swinv2t" and not a.no_graph:
+    if not a.no_graph:
         work_stream = torch.cuda.Stream()
         torch.cuda.set_stream(work_stream)
     if world > 1:
@@ -469,7 +469,9 @@ def main():
     # 5 ms of GPU time) is captured ONCE into a HIP graph and replayed; sampling, augment, mixup and the optimizer stay eager
     # (their arguments change every step).  Same kernels, same order, same bits (checked below against an eager pass); what it
     # buys is that a busy host cannot make the step launch-bound.  Steps whose kernels are bracketed with HIP events for the
-    # roofline figure run eagerly.  N > 1 (collectives, calibration) and SwinV2 stay eager.
+    # roofline figure run eagerly.  N > 1 with collectives inside the backward stays eager.  SwinV2 is captured too (round 4): its ~600
+    # launches per step cost the host 25 ms, as long as the GPU needs to run them; DropPath's masks come from captured Philox offsets that
+    # advance with every replay, so its replay is checked against the eager pass's scale, not its bits.
     graph = None
     use_graph = world == 1          # N > 1: decided by the schedule calibration below (replay + ONE all-reduce after it)
     fs_saved = model._grad_sync
@@ -494,7 +496,13 @@ def main():
             g.replay()
             torch.cuda.synchronize()
             got_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
-            if model.flat_grad_base() is None or not torch.equal(gloss.detach(), ref_loss) or not torch.equal(got_grad, ref_grad):
+            if swin:
+                # DropPath draws new masks in every pass (captured Philox offsets advance with the replays), so the replay is held to
+                # the eager pass's scale, not to its bits
+                if not (torch.isfinite(got_grad).all() and abs(float(gloss) - float(ref_loss)) < 0.2
+                        and 0.5 < float(got_grad.norm() / ref_grad.norm()) < 2.0):
+                    raise RuntimeError("graph replay does not resemble the eager pass")
+            elif model.flat_grad_base() is None or not torch.equal(gloss.detach(), ref_loss) or not torch.equal(got_grad, ref_grad):
                 raise RuntimeError("graph replay does not reproduce the eager pass")
             graph = (g, gloss, static)
         except Exception as e:          # noqa: BLE001
