@@ -53,7 +53,8 @@ static_assert(P_SLOT0 + SLOT <= SMEM && P_TILES + NCW * TILE <= P_SLOT0, "LDS");
 // ---- A: the layout of attn3_bwd_kernel
 constexpr int A_Q = 0, A_K = ARR, A_V = 2 * ARR, A_G = 3 * ARR, A_L2 = 4 * ARR, A_D = A_L2 + NPAD * 4, A_STG = A_D + NPAD * 4;
 constexpr int STG_PITCH = 144, STG_WAVE = 32 * STG_PITCH;
-static_assert(A_STG + NCW * STG_WAVE <= SMEM, "LDS");
+constexpr int A_SIDE = A_STG + NCW * STG_WAVE;      // 1 KB per wave: rows 0..7 of the wave's own next Q tile (see load_own_q)
+static_assert(A_SIDE + NCW * 1024 <= SMEM, "LDS");
 // ---- X: three weight slots | three sets of d(qkv) row tiles
 // chunks 0, 1 over the K, V arrays (fetched during the last head's second phase), chunk 2 over Q; the tile sets fill the rest
 constexpr int X_SLOT0 = A_K, X_SLOT1 = A_K + SLOT, X_SLOT2 = 0, X_TILES = A_K + 2 * SLOT, X_TSET = NCW * TILE;
@@ -618,15 +619,31 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       const bf16* qkv0 = b.qkv + (size_t)img * NTOK * LDQ;
       const bf16* do0 = p.dattn + (size_t)img * NTOK * INNER;
       const bf16* o0 = b.attn + (size_t)img * NTOK * INNER;
-      auto load_own_qg = [&](int h) {
+      // (two requests: with dK and dV still in their accumulators all eight vectors do not fit -- the register allocator parked the
+      // first one in scratch, i.e. WAITED for it right behind its own load: the prefetch became a blocking load per head, block and wave)
+      auto load_own_g = [&](int h) {
         const int lane_ = lane_id_here();
         const int seg = lane_ & 7;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           int r = row0 + i * 8 + (lane_ >> 3);
           r = r < NTOK ? r : NTOK - 1;
-          qraw[i] = *reinterpret_cast<const u32x4*>(qkv0 + (size_t)r * LDQ + h * HD + seg * 8);
           graw[i] = *reinterpret_cast<const u32x4*>(do0 + (size_t)r * INNER + h * HD + seg * 8);
+        }
+      };
+      // ... and even then one vector too many is live: the first Q vector travels by LDS-DMA into a 1 KB side buffer of the wave (lane
+      // l's 16 bytes at +16 l) and becomes a register only where it is used
+      unsigned char* qside = smem + A_SIDE + w * 1024;
+      auto load_own_q = [&](int h) {
+        const int lane_ = lane_id_here();
+        const int seg = lane_ & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int r = row0 + i * 8 + (lane_ >> 3);
+          r = r < NTOK ? r : NTOK - 1;
+          const bf16* src = qkv0 + (size_t)r * LDQ + h * HD + seg * 8;
+          if (i == 0) __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)qside, 16, 0, 0);
+          else qraw[i] = *reinterpret_cast<const u32x4*>(src);
         }
       };
       auto load_own_o = [&](int h) {
@@ -642,7 +659,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
         rq_ = rq_ < NTOK ? rq_ : NTOK - 1;
         lq = b.lse[((size_t)img * HEADS + h) * NTOK + rq_];
       };
-      load_own_qg(0);
+      load_own_g(0);
+      load_own_q(0);
       load_own_o(0);
       BAR(B_A);                                                   // start: K, V of head 0 are in LDS
       for (int h = 0; h < HEADS; ++h) {
@@ -665,6 +683,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
             d += lane_xor4(d);
             if (seg == 0) D_s[row0 + i * 8 + rl] = d;
           }
+          qraw[0] = *reinterpret_cast<const u32x4*>(qside + lane_id_here() * 16);        // (landed: vmcnt(0) above)
 #pragma unroll
           for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = qraw[i];
           wait_lds();
@@ -781,8 +800,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
             mma(dk[0], gg[2], f);
             mma(dk[1], gg[3], f);
           });
-          if (more) load_own_qg(h + 1);
+          if (more) load_own_g(h + 1);
           tile_park_private(stg, dk, p.scale, L);
+          if (more) load_own_q(h + 1);                            // (dK's 32 registers are free now)
           wait_lds();
           BAR(B_A + 3 + 4 * h);                                   // end
           tile_park_rows(Gs, w, dv, 1.0f);
