@@ -11,6 +11,7 @@
 //     B: seg ^ ((row>>1)&1)) so the 4-row x 64-byte footprint of a 32-lane transpose read is bank-conflict free;
 //   * bias gradient (column sums of dY) rides on the MFMA pipe: one extra MFMA per chunk against a ones fragment.
 #include "common.h"
+#include <string.h>
 #include "internal.h"
 #include "../../include/rgbnm.h"
 
@@ -51,6 +52,11 @@ struct TnJobK {                   // per job, in the kernel argument segment
 struct TnGroup {
   TnJobK j[TN_MAXJOBS];
   int njobs, S, tiles, M, kt_per_split;
+  // packed != 0 (launches without a token split): unit u runs tile unit_tile[u] of job unit_job[u] (255 = idle).  The tiles of one
+  // job read the same operand rows, and the 32 units of an XCD share an L2: the host places every job inside ONE XCD's 32 units
+  // (first fit, largest first) instead of letting jobs straddle the boundaries of a dense numbering
+  int packed;
+  unsigned char unit_job[256], unit_tile[256];
 };
 
 __device__ __forceinline__ bf16x8 pack8(u32x2 lo, u32x2 hi) {
@@ -89,11 +95,19 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   // 256 workgroups, block b runs on XCD b % 8: unit u = (b % 8) * 32 + b / 8 keeps consecutive units -- the tiles of one
   // token range s, which read the same operand rows -- on one XCD's L2
   const int u = (blockIdx.x & 7) * 32 + (blockIdx.x >> 3);
-  if (u >= grp.S * grp.tiles) return;
-  const int s = u / grp.tiles;
-  int tile = u % grp.tiles, job = 0;
-  while (tile >= grp.j[job].tile_end) ++job;          // (uniform: scalar loads from the argument segment)
-  if (job) tile -= grp.j[job - 1].tile_end;
+  int s, tile, job = 0;
+  if (grp.packed) {
+    job = grp.unit_job[u];
+    if (job == 255) return;
+    tile = grp.unit_tile[u];
+    s = 0;
+  } else {
+    if (u >= grp.S * grp.tiles) return;
+    s = u / grp.tiles;
+    tile = u % grp.tiles;
+    while (tile >= grp.j[job].tile_end) ++job;          // (uniform: scalar loads from the argument segment)
+    if (job) tile -= grp.j[job - 1].tile_end;
+  }
   TnPipe p;
   int perm;
   {
@@ -434,7 +448,30 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   const int kt_per = cdiv(ktiles, S);
   S = cdiv(ktiles, kt_per);
   g.njobs = n; g.S = S; g.tiles = tiles; g.M = jobs[0].M; g.kt_per_split = kt_per;
+  g.packed = 0;
   *S_out = S;
+  if (S == 1 && n > 1 && rgbnm_get_option("tn_pack")) {
+    // first fit, largest job first, into the eight XCDs' 32 units each; keep the dense numbering when something does not fit
+    int order[TN_MAXJOBS], cnt[TN_MAXJOBS], fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) { order[i] = i; cnt[i] = g.j[i].tile_end - (i ? g.j[i - 1].tile_end : 0); }
+    for (int i = 1; i < n; ++i)
+      for (int k = i; k > 0 && cnt[order[k]] > cnt[order[k - 1]]; --k) { const int t = order[k]; order[k] = order[k - 1]; order[k - 1] = t; }
+    memset(g.unit_job, 255, sizeof(g.unit_job));
+    memset(g.unit_tile, 0, sizeof(g.unit_tile));
+    bool ok = true;
+    for (int oi = 0; oi < n && ok; ++oi) {
+      const int i = order[oi];
+      int x = 0;
+      while (x < 8 && fill[x] + cnt[i] > 32) ++x;
+      if (x == 8) { ok = false; break; }
+      for (int t = 0; t < cnt[i]; ++t) {
+        g.unit_job[x * 32 + fill[x] + t] = (unsigned char)i;
+        g.unit_tile[x * 32 + fill[x] + t] = (unsigned char)t;
+      }
+      fill[x] += cnt[i];
+    }
+    g.packed = ok ? 1 : 0;
+  }
   if (S == 1 && direct_out) {
     // no token split: the "partials" are the result.  Write the gradient tensors from the kernel (row permutation included) and
     // spare the reduction launch its copy of every weight gradient (22.6 MB read + written per JPEG-Ti step)
