@@ -266,7 +266,9 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+#ifndef X_NOSAVE      // (experiments only: the kernel without its global stores -- what the saved tensors cost)
     if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v;
+#endif
   }
   wait_lds();
 }
@@ -419,8 +421,10 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             const int row = trow + 8 * i;
             if (row < lr) {
               const size_t go = ((size_t)img * NTOK + 32 * (4 + q) + row) * HID + chunk * 64 + tvec * 8;
+#ifndef X_NOSAVE
               *reinterpret_cast<u32x4*>(b.gl + go) = tv[q][0][i];
               *reinterpret_cast<u32x4*>(b.gp + go) = tv[q][1][i];
+#endif
             }
           }
         }
@@ -638,7 +642,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+#ifndef X_NOSAVE
             if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v;
+#endif
           }
           wait_lds();
         }
@@ -823,8 +829,10 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(smem + so);
             const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(smem + so + tpoff);
             const size_t go = (grow0 + row) * HID + chunk * 64 + vec * 8;
+#ifndef X_NOSAVE
             *reinterpret_cast<bf16x8*>(b.gl + go) = v0;
             *reinterpret_cast<bf16x8*>(b.gp + go) = v1;
+#endif
           }
         }
         wait_lds();
