@@ -545,6 +545,82 @@ class _BlockFn(torch.autograd.Function):
         return (dx, None, None) + tuple(by_name[n] for n in m._block_param_order[idx])
 
 
+class _EncoderFn(torch.autograd.Function):
+    """All encoder blocks as ONE autograd node (the default when the one-launch forward is switched on): the forward is one C call
+    (rgbnm_vit_chain_fwd), the backward one (rgbnm_vit_chain_bwd) plus the grouped weight-gradient launch(es) -- instead of twelve
+    pass-through nodes whose Python / autograd bookkeeping was 1.3 ms of the 2.5 ms an eager step costs the host.  Should a kernel
+    turn out not to be eligible (an option switched off, no usable GELU table), the per-block C entries run inside this node."""
+
+    @staticmethod
+    def forward(ctx, x, st, *params):
+        m, a = st.model, st.arena
+        assert x.data_ptr() == a.xbuf(0).data_ptr()
+        st.chain_fwd = m._chain_forward(a)
+        if not st.chain_fwd:
+            chain = st.ln_chain
+            for idx in range(m.depth):
+                last = idx + 1 >= m.depth
+                nxt_p = C.byref(m._bparams[idx + 1]) if chain and not last else None
+                nxt_a = C.byref(a.acts[idx + 1]) if chain and not last else None
+                L.check(L.lib().rgbnm_vit_block_fwd_chain(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
+                                                          1 if (chain and idx > 0) else 0, nxt_p, nxt_a, L.stream()), "vit_block_fwd")
+        ctx.st = st
+        return a.xbuf(m.depth).detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        m, a = st.model, st.arena
+        D = m.depth
+        dy = dy.contiguous()
+        grads = [[m._gview(st.gbuf, n) for n in m._block_names[i]] for i in range(D)]
+        gs = [L.BlockGrads(*[t.data_ptr() for t in grads[i]]) for i in range(D)]
+        try:
+            if m._chain_backward(a, dy):
+                # weight gradients: all blocks in one grouped launch, or groups of dw_group_overlapped blocks while gradient slices
+                # are exchanged during the backward (a group's gradients are handed to the exchange as soon as it has run)
+                group = D if (m._grad_sync is None or st.holding) else m.dw_group_overlapped
+                idx = D - 1
+                while idx >= 0:
+                    pend = list(range(idx, max(idx - group, -1), -1))
+                    n = len(pend)
+                    scs = [L.BlockScratch(a.du_blk[i].data_ptr(), a.dxn.data_ptr(), a.dxmid_blk[i].data_ptr(), a.dattn_chain.data_ptr(),
+                                          a.dqkv_blk[i].data_ptr(), a.ws_chain.data_ptr() + i * a.ws_bytes, a.ws_bytes) for i in pend]
+                    pa = (C.POINTER(L.BlockActs) * n)(*[C.pointer(a.acts[i]) for i in pend])
+                    pg = (C.POINTER(L.BlockGrads) * n)(*[C.pointer(gs[i]) for i in pend])
+                    ps = (C.POINTER(L.BlockScratch) * n)(*[C.pointer(x) for x in scs])
+                    pdy = (C.c_void_p * n)(*[dy.data_ptr() if i == D - 1 else a.dx_blk[i + 1].data_ptr() for i in pend])
+                    p2 = (C.c_void_p * n)(*[a.lnpart[i, 0].data_ptr() for i in pend])
+                    p1 = (C.c_void_p * n)(*[a.lnpart[i, 1].data_ptr() for i in pend])
+                    L.check(L.lib().rgbnm_vit_blocks_bwd_dw(C.byref(a.cfg), n, pa, pg, ps, pdy, p2, p1, L.stream()), "vit_blocks_bwd_dw")
+                    if m._grad_sync is not None:
+                        for i in pend:
+                            m._grad_sync.ready(st.gbuf, m._block_names[i])
+                    idx -= n
+                dx = a.dx_blk[0]
+            else:
+                cur = dy
+                for idx in range(D - 1, -1, -1):
+                    dx = a.dx[idx & 1]
+                    if dx.data_ptr() == cur.data_ptr():
+                        dx = a.dx[(idx + 1) & 1]
+                    scratch = a.scratch_blk[idx] if st.holding else a.scratch
+                    L.check(L.lib().rgbnm_vit_block_bwd(C.byref(a.cfg), C.byref(m._bparams[idx]), C.byref(a.acts[idx]),
+                                                        C.byref(gs[idx]), C.byref(scratch), cur.data_ptr(), dx.data_ptr(),
+                                                        L.stream()), "vit_block_bwd")
+                    if m._grad_sync is not None:
+                        m._grad_sync.ready(st.gbuf, m._block_names[idx])
+                    cur = dx
+        except BaseException:
+            st.cancel_hold()                    # never leave the autograd thread's bracket open behind an exception
+            raise
+        out = []
+        for i in range(D):
+            by_name = dict(zip(m._block_names[i], grads[i]))
+            out += [by_name[n] for n in m._block_param_order[i]]
+        return (dx, None) + tuple(out)
+
+
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, st, *params):
@@ -608,6 +684,7 @@ class ViT(FlatParamModule):
     `.grad` during the backward (leave it False there)."""
     defer_grad_reduction = False
     dw_group_overlapped = 4        # blocks per grouped weight-gradient launch while gradient slices are exchanged during the backward
+    single_encoder_node = True     # all blocks as one autograd node when the one-launch forward is on (_EncoderFn); False: one node per block
 
     def __init__(self, in_channels: int = 3, patch_size: int = 16, emb_size: int = 768, input_embed: int = -1,
                  depth: int = 12, n_classes: int = 1000, drop_p=0.1, pixel_space="RGB", ver=1, use_subblock=True,
@@ -950,6 +1027,17 @@ class ViT(FlatParamModule):
             h = _PatchEmbedSepFn.apply(x, cbcr, st, *[named[n] for n in _PES_NAMES])
         else:
             h = _PatchEmbedConcatFn.apply(x, cbcr, st, *[named[n] for n in _PE3_NAMES])
-        for i in range(self.depth):
-            h = _BlockFn.apply(h, st, i, *[named[n] for n in self._block_param_order[i]])
+        if (self.single_encoder_node and cdtype == torch.bfloat16 and self._chain_idx is not None
+                and L.lib().rgbnm_get_option(b"fwd_chain")):
+            h = _EncoderFn.apply(h, st, *self._all_block_params())
+        else:
+            for i in range(self.depth):
+                h = _BlockFn.apply(h, st, i, *[named[n] for n in self._block_param_order[i]])
         return _HeadFn.apply(h, st, *[named[n] for n in self._head_param_order])
+
+    def _all_block_params(self):
+        named = self._named
+        key = id(named)
+        if getattr(self, "_abp_key", None) != key:
+            self._abp_key, self._abp = key, [named[n] for i in range(self.depth) for n in self._block_param_order[i]]
+        return self._abp
