@@ -285,9 +285,14 @@ __device__ __forceinline__ void rows_out(unsigned char* smem, unsigned stg, cons
 __device__ __forceinline__ void gemm_k192(f32x16& acc, const unsigned char* sW, int ht, const Rows& x, const Geo& L) {
   int wbase = L.l31 * (E * 2) + ((L.g ^ L.fl) << 4) + ht * 32 * (E * 2);
   asm volatile("" : "+v"(wbase));
+  Frag<bf16> fb;
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
-    Frag<bf16> fb, fx;
+    Frag<bf16> fx;
+#ifdef X_HALFW      // (experiments only, wrong numbers: every weight fragment read from LDS serves two MFMAs -- what a wave that owned
+                    // 64 rows would save on the LDS port)
+    if ((c & 1) == 0)
+#endif
     fb.v = *reinterpret_cast<const bf16x8*>(sW + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
     fx.v = as_bf16x8(x.v[c]);
     mma(acc, fb, fx);
@@ -666,6 +671,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         Frag<bf16> fw[6];
 #pragma unroll
         for (int bt = 0; bt < 6; ++bt)
+#ifdef X_HALFW
+          if (bt & 1) fw[bt].v = fw[bt - 1].v; else
+#endif
           fw[bt].v = *reinterpret_cast<const bf16x8*>(smem + (wo ^ (unsigned)(s << 5)) + bt * 32 * ROWB);
 #pragma unroll
         for (int bt = 0; bt < 6; ++bt) mma(accp[bt], fw[bt], of[h][s]);
@@ -744,9 +752,13 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         for (int r = 0; r < 16; ++r) a1[r] = 0.f;
         int wbase = woff0 + ht * 32 * (E * 2);
         asm volatile("" : "+v"(wbase));
+        Frag<bf16> fb;
 #pragma unroll
         for (int c = 0; c < 12; ++c) {
-          Frag<bf16> fb, fx;
+          Frag<bf16> fx;
+#ifdef X_HALFW
+          if ((c & 1) == 0)
+#endif
           fb.v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
           fx.v = as_bf16x8(fa.v[c]);
           mma(a1, fb, fx);
@@ -812,6 +824,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
           Frag<bf16> fw[6];
 #pragma unroll
           for (int bt = 0; bt < 6; ++bt)
+#ifdef X_HALFW
+            if (bt & 1) fw[bt].v = fw[bt - 1].v; else
+#endif
             fw[bt].v = *reinterpret_cast<const bf16x8*>(smem + (w2o ^ (unsigned)(s << 5)) + bt * 32 * ROWB);
 #pragma unroll
           for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw[bt], pg[hs]);
