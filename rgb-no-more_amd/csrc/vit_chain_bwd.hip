@@ -392,9 +392,11 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
       auto issue_xt = [&](int j) { dma_row_tiles(dq0 + j * 64, LDQ, smem + X_TILES + (j % 3) * X_TSET, lane); };
       wait_vm<0>();                                       // chunk 0 (fetched during the epilogue) has landed long ago
       BAR(B_P);                                           // the staging tile is dead
+      BAR(B_P + 1);                                       // step 0 starts at once (its chunk landed long ago): the 80 DMA instructions
+                                                          // below take this wave 4.4 k cycles to ISSUE, which the compute waves used to
+                                                          // spend waiting at this barrier (profiles/r04_chain_bwd_stamps.txt, "P:frags")
       dma_linear<24>(wimg + (size_t)NCHUNK * STAGE + SLOT, smem + P_SLOT1, lane);
       issue_kv(0);
-      BAR(B_P + 1);
       wait_vm<56>(); BAR(B_P + 2);                        // chunk 1; step 0 is over: slot 0 takes chunk 2
       dma_linear<24>(wimg + (size_t)NCHUNK * STAGE + 2 * SLOT, smem + P_SLOT0, lane);
       wait_vm<0>(); BAR(B_P + 3);                         // chunk 2; step 1 is over: Q of head 0 over slot 1
