@@ -15,64 +15,70 @@ namespace {
 // X[8*pdh + p1][8*pdw + p2] = y[b,0,2*ph+pdh,2*pw+pdw,p1,p2].  Output row layout 'b h w (c i j)':
 // [0,256) = Z row-major, [256,320) = Cb, [320,384) = Cr.
 // ------------------------------------------------------------------------------------------------
+// The two 16 x 16 x 16 products run on the matrix pipe in exact fp32 (v_mfma_f32_16x16x4_f32: 8 instructions per patch instead of
+// 160 scalar LDS reads + 128 FMAs per lane -- the scalar version was instruction-bound at 2 TB/s).  With g = lane / 16, c = lane % 16:
+//   T^T = X^T . A^T :  A-operand X[4 kk + g][c] (from the wave's LDS copy of the patch), B-operand A[c][4 kk + g]
+//                      -> the lane holds T[c][4 g + r], r = 0..3
+//   Z^T = A . T^T   :  reduction index taken in the order o = 4 g + kk, so that the B-operand of step kk IS register r = kk;
+//                      A-operand A[c][4 g + kk]  -> the lane holds Z[c][4 g + r]: four consecutive outputs of row c
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void subblock_embed_kernel(const TI* __restrict__ y, const TI* __restrict__ cbcr,
                                                              const float* __restrict__ A, T* __restrict__ feat,
                                                              int B, int Hb, int Wb, int transpose_a) {
-  __shared__ float As[16][17];
   __shared__ float Xs[4][16][17];
-  __shared__ float Ts[4][16][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  {
-    const int i = tid >> 4, j = tid & 15;
-    As[i][j] = transpose_a ? A[j * 16 + i] : A[i * 16 + j];
+  const int g = lane >> 4, c = lane & 15;
+  float a1[4], a2[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    a1[kk] = transpose_a ? A[(4 * kk + g) * 16 + c] : A[c * 16 + 4 * kk + g];
+    a2[kk] = transpose_a ? A[(4 * g + kk) * 16 + c] : A[c * 16 + 4 * g + kk];
   }
   const int ph_n = Hb / 2, pw_n = Wb / 2;
   const long long npatch = (long long)B * ph_n * pw_n;
-  const long long patch = (long long)blockIdx.x * 4 + w;
-  const bool valid = patch < npatch;
-  int b = 0, ph = 0, pw = 0;
-  if (valid) {
-    b = (int)(patch / (ph_n * pw_n));
+  // a wave walks patches with the grid's stride (the launcher caps the grid): the eight A operands are loaded once per wave, not
+  // once per patch (50 k waves x 8 table loads were 4 x the payload in L2 traffic)
+  const int pdh = lane >> 5, pdw = (lane >> 4) & 1, l16 = lane & 15;
+  const int p1 = l16 >> 1, p2 = (l16 & 1) * 4;
+  const int e0 = lane * 2, cc = e0 >> 6, k = e0 & 63;
+  // luma: 4 values per lane; chroma: 128 values, 2 per lane (identity sub-block conversion for 8x8 chroma patches)
+  auto fetch = [&](long long patch, f32x4& v, float& c0, float& c1) {
+    const int b = (int)(patch / (ph_n * pw_n));
     const int rem = (int)(patch % (ph_n * pw_n));
-    ph = rem / pw_n;
-    pw = rem % pw_n;
-    const int pdh = lane >> 5, pdw = (lane >> 4) & 1, l16 = lane & 15;
-    const TI* src = y + ((((size_t)b * Hb + 2 * ph + pdh) * Wb) + 2 * pw + pdw) * 64 + l16 * 4;
-    const f32x4 v = load4<TI>(src);
-    const int p1 = l16 >> 1, p2 = (l16 & 1) * 4;
+    const int ph = rem / pw_n, pw = rem % pw_n;
+    v = load4<TI>(y + ((((size_t)b * Hb + 2 * ph + pdh) * Wb) + 2 * pw + pdw) * 64 + l16 * 4);
+    const TI* cs = cbcr + ((((size_t)b * 2 + cc) * ph_n + ph) * pw_n + pw) * 64 + k;
+    c0 = to_f32(cs[0]);
+    c1 = to_f32(cs[1]);
+  };
+  const long long stride = (long long)gridDim.x * 4;
+  long long patch = (long long)blockIdx.x * 4 + w;
+  if (patch >= npatch) return;
+  f32x4 v, vn = {0.f, 0.f, 0.f, 0.f};
+  float c0, c1, c0n = 0.f, c1n = 0.f;
+  fetch(patch, v, c0, c1);
+  for (; patch < npatch; patch += stride) {
+    if (patch + stride < npatch) fetch(patch + stride, vn, c0n, c1n);      // the next patch's values fly during this one's products
 #pragma unroll
     for (int e = 0; e < 4; ++e) Xs[w][8 * pdh + p1][8 * pdw + p2 + e] = v[e];
-  }
-  __syncthreads();
-  const int i = lane >> 2, j0 = (lane & 3) * 4;
-  if (valid) {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the wave's own LDS rows (no other wave touches Xs[w])
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
-      const float a = As[i][o];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = fmaf(a, Xs[w][o][j0 + e], t[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) Ts[w][i][j0 + e] = t[e];
-  }
-  __syncthreads();
-  if (valid) {
+    for (int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[w][4 * kk + g][c], a1[kk], t, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the next patch's rows overwrite Xs[w] only after these reads)
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
-      const float tv = Ts[w][i][o];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) z[e] = fmaf(tv, As[j0 + e][o], z[e]);
-    }
+    for (int kk = 0; kk < 4; ++kk) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kk], t[kk], z, 0, 0, 0);
     T* dst = feat + (size_t)patch * 384;
-    store4<T>(dst + i * 16 + j0, z);
-    // chroma: 128 values, 2 per lane (identity sub-block conversion for 8x8 chroma patches)
-    const int e0 = lane * 2, c = e0 >> 6, k = e0 & 63;
-    const TI* cs = cbcr + ((((size_t)b * 2 + c) * ph_n + ph) * pw_n + pw) * 64 + k;
-    dst[256 + e0] = from_f32<T>(to_f32(cs[0]));
-    dst[256 + e0 + 1] = from_f32<T>(to_f32(cs[1]));
+    store4<T>(dst + c * 16 + 4 * g, z);
+    {                                                            // the lane's two chroma values as ONE store
+      struct alignas(2 * sizeof(T)) Pair { T a, b; };
+      Pair pr;
+      pr.a = from_f32<T>(c0);
+      pr.b = from_f32<T>(c1);
+      *reinterpret_cast<Pair*>(dst + 256 + e0) = pr;
+    }
+    v = vn; c0 = c0n; c1 = c1n;
   }
 }
 
@@ -219,7 +225,7 @@ int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void*
                          void* feat, int B, int Hb, int Wb, int transpose_a, void* stream) {
   if (!y || !cbcr || !conv16 || !feat || B <= 0 || Hb <= 0 || Wb <= 0 || (Hb & 1) || (Wb & 1)) return RGBNM_EINVAL;
   const long long npatch = (long long)B * (Hb / 2) * (Wb / 2);
-  const dim3 grid((unsigned)cdivl(npatch, 4)), blk(256);
+  const dim3 grid((unsigned)min(cdivl(npatch, 4), 2048LL)), blk(256);      // 256 CUs x 8 workgroups: one round, waves loop
   hipStream_t st = (hipStream_t)stream;
 #define SB(TI, TO) hipLaunchKernelGGL((subblock_embed_kernel<TI, TO>), grid, blk, 0, st, (const TI*)y, (const TI*)cbcr, conv16, (TO*)feat, B, Hb, Wb, transpose_a)
   if (in_dtype == DT_F32 && out_dtype == DT_F32) SB(float, float);
