@@ -327,13 +327,14 @@ def main():
     # one parallel CPU op (the parity check in front of the timed region has several) leaves hundreds of spinning workers, the
     # cgroup burns its quota in a few milliseconds and EVERY thread of the process -- the one that feeds the GPU included -- is
     # frozen for the rest of the 100 ms period: the 16-step queue drains and the step time jumps by 5 - 20 % from run to run with
-    # unchanged kernel times (profiles/r04_host_throttle.txt).  Size the pools by the quota, and let idle workers sleep.
+    # unchanged kernel times (profiles/r04_host_throttle.txt).  Size the pools by the quota.
     quota = _cgroup_cpu_quota()
     ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))      # the ranks of this node share the quota
     nthr = max(1, min(os.cpu_count() or 1, (quota or (os.cpu_count() or 1)) // ranks_here or 1, 16))
     os.environ.setdefault("OMP_NUM_THREADS", str(nthr))
     os.environ.setdefault("MKL_NUM_THREADS", str(nthr))
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    if os.environ.get("RGBNM_BENCH_OMP_PASSIVE", "0") == "1":          # (experiment switch; the default keeps OpenMP's own policy so that
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")            #  the cpu_baseline leg is not slowed by sleeping workers)
     import numpy as np
     import torch
     torch.set_num_threads(nthr)
