@@ -300,7 +300,23 @@ def decode_leg(n=16):
     t0 = time.perf_counter()
     for p in paths:
         dm.read_coefficients(p)
-    return (time.perf_counter() - t0) / n
+    prod = (time.perf_counter() - t0) / n
+    # ... and the REFERENCE's own reader (oracle/_ref: its dct_manip.cpp compiled by oracle/build_ref.py; the prebuilt .so travels
+    # with the snapshot for exactly this leg) on the same files, same thread count: the a1 row's CPU figure is the reference's code
+    ref = None
+    try:
+        from oracle import build_ref
+        rmod = build_ref.load_ref()
+        if rmod is not None:
+            for p in paths[:2]:
+                rmod.read_coefficients(p)
+            t0 = time.perf_counter()
+            for p in paths:
+                rmod.read_coefficients(p)
+            ref = (time.perf_counter() - t0) / n
+    except Exception:       # noqa: BLE001  (the checker is optional on the box)
+        ref = None
+    return prod, ref
 
 
 def _cgroup_cpu_quota():
@@ -484,6 +500,32 @@ def main():
             smt = torch.empty(B, 1000, device=dev, dtype=torch.float32)
             static = (sy, sc, smt)
             data_part(out=static)
+            if swin:
+                # DropPath draws new masks in every pass (captured Philox offsets advance with the replays), so a train-mode replay
+                # cannot be compared bit for bit.  The capture is therefore validated FIRST with DropPath off (eval mode: same ~600
+                # launches, same buffers, same order): loss and every gradient element of the replay must equal the eager pass;
+                # only then is the train-mode graph captured for timing (and held to the eager pass's scale below).
+                model.eval()
+                try:
+                    opt.zero_grad(set_to_none=True)
+                    v_loss = model_part(sy, sc, smt).detach().clone()
+                    v_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+                    for _ in range(2):
+                        opt.zero_grad(set_to_none=True)
+                        model_part(sy, sc, smt)
+                    opt.zero_grad(set_to_none=True)
+                    gv = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gv, stream=work_stream):
+                        gv_loss = model_part(sy, sc, smt)
+                    gv.replay()
+                    torch.cuda.synchronize()
+                    gv_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+                    if not torch.equal(gv_loss.detach(), v_loss) or not torch.equal(gv_grad, v_grad):
+                        raise RuntimeError("graph replay (DropPath off) does not reproduce the eager pass bit for bit: max |d grad| "
+                                           f"{(gv_grad - v_grad).abs().max().item():.3e}")
+                    del gv, gv_loss, gv_grad, v_grad
+                finally:
+                    model.train()
             opt.zero_grad(set_to_none=True)
             ref_loss = model_part(sy, sc, smt).detach().clone()
             ref_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
@@ -692,6 +734,7 @@ def main():
         step_tflops = value / world * FLOP_PER_IMG[a.arch] / 1e12
         roof = None
         roof_all = []
+        whole = None
         if not a.no_trace:
             # HBM bytes per launch from the PMC counters cannot be read inside this process: they come from separate
             # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools/gpu.sh pass, corrected as
@@ -701,8 +744,10 @@ def main():
                 tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             tjs = json.load(open(tpath)) if os.path.exists(tpath) else {}
             # attainable peaks measured on an MI355X box by tools/calib.py (nominal peaks are what `frac` is priced against)
+            mpath = os.path.join(ROOT, "profiles", "pmc_mfma.json" if a.arch == "vitti" else f"pmc_mfma_{a.arch}.json")
+            mjs = (json.load(open(mpath)).get("classes") or {}) if os.path.exists(mpath) else {}
             attain = None
-            for cal in ("r04_calibration.json", "r01_calibration.json"):
+            for cal in ("calibration.json", "r04_calibration.json", "r01_calibration.json"):
                 cpath = os.path.join(ROOT, "profiles", cal)
                 if os.path.exists(cpath):
                     cj = json.load(open(cpath))
@@ -710,6 +755,7 @@ def main():
                               "hbm_write_GBs": cj.get("hbm_write_GBps[1 GiB]"),
                               "mfma_bf16_TFLOPs": cj.get("mfma_bf16_tflops[1 workgroup (4 waves) per CU]"), "source": "profiles/" + cal}
                     break
+            byts_step = {}
             for tag, key, desc in TRACED:
                 tms, fl, by, cnt = C.c_double(), C.c_double(), C.c_double(), C.c_int()
                 L.check(lib.rgbnm_trace_collect(tag, C.byref(tms), C.byref(fl), C.byref(by), C.byref(cnt)))
@@ -727,9 +773,31 @@ def main():
                                  "algorithmic_bytes_per_launch": round(by.value / cnt.value),
                                  "algorithmic_flops_per_launch": round(fl.value / cnt.value),
                                  "kernel_tflops": round(tfs, 1), "kernel_mfma_frac": round(tfs / peak, 4),
+                                 # the SAME kernel against the matrix-pipe roof (SURVEY 8d / north_star name it for the model step):
+                                 # useful FLOPs of the timed launches / dense peak, and the hardware-counter figure (MFMA ops issued,
+                                 # padding rows included) from the committed --pmc pass of this command
+                                 "mfma": {"bound": "mfma", "achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s",
+                                          "frac": round(tfs / peak, 4),
+                                          "counter_frac": (mjs.get(key) or {}).get("mfma_util_vs_2.5PF"),
+                                          "counter_source": (os.path.relpath(mpath, ROOT) + " (file-sourced: separate --pmc pass)") if key in mjs else None},
                                  "attainable_peaks_measured": attain})
+                byts_step[key] = by.value / max(1, traced_steps)
             roof_all.sort(key=lambda r: -r["us_per_step"])
             roof = roof_all[0] if roof_all else None       # the dominant kernel (largest share of the step)
+            # the whole step against both roofs: algorithmic bytes = the traced kernel classes (their C entries state them) + the
+            # data stage, patch embedding and optimizer from SURVEY 8d's per-image figures; counter bytes = every dispatch of a step in
+            # the committed FETCH / WRITE passes (file-sourced, like roofline.traffic)
+            nparam = sum(p.numel() for p in model.parameters())
+            small = (0 if a.no_augment else B * 0.73e6) + nparam * 28.0
+            if not swin:
+                small += B * 0.30e6 + B * 196 * (384 + 2 * emb) * 2.0
+            alg = sum(byts_step.values()) + small
+            cnt_b = tjs.get("whole_step_bytes")
+            whole = {"algorithmic_bytes": round(alg), "counter_bytes": cnt_b,
+                     "counter_source": (os.path.relpath(tpath, ROOT) + " (file-sourced)") if cnt_b else None,
+                     "frac_hbm": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "frac_hbm_counter": round(cnt_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if cnt_b else None,
+                     "frac_mfma": round(step_tflops / peak, 4)}
         out = {
             "metric": f"images/sec {NAMES[a.arch]} DCT 512x512 train step",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -758,11 +826,15 @@ def main():
             "mfma_pct_whole_step": round(100 * step_tflops / peak, 2),
             "step_tflops_per_gpu": round(step_tflops, 1),
             "roofline": roof,
+            "whole_step": whole,
             "roofline_kernels": roof_all[1:],            # the other traced kernel classes, by time per step
         }
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(a.arch, a.cpu_baseline_images)
-            dsec = decode_leg()
+            dleg = decode_leg()
+            dsec, dref = dleg if dleg is not None else (None, None)
+            if dref is not None:
+                cb["decode_ms_per_img_1thread_reference_reader"] = round(1e3 * dref, 3)      # oracle/_ref (kind "reference" for row a1)
             if dsec is not None and cb.get("value"):
                 cb["decode_ms_per_img_1thread"] = round(1e3 * dsec, 3)
                 cb["value_incl_entropy_decode"] = round(1.0 / (1.0 / cb["value"] + dsec), 2)

@@ -475,6 +475,12 @@ int rgbnm_calib_l2(const void* buf, size_t slice_bytes, int iters, int mode, int
 int rgbnm_calib_pipes(const int* role_dev, int waves, int iters, int workgroups, unsigned long long* out, float* sink,
                       void* stream);
 
+/* Stand-in for a collective's channels: `workgroups` x 256 threads, each holding `lds_bytes` of LDS, stay resident for `ticks`
+ * s_memtime ticks (or until *stop != 0; stop may be NULL), re-reading their 4 KB-multiple slice of buf meanwhile (mode 1) or sleeping
+ * (mode 0).  Measurement / test perturber only (tools/cu_steal_probe.py, tests/test_chain_soak.py). */
+int rgbnm_calib_occupy(const void* buf, size_t slice_bytes, int workgroups, int lds_bytes, long long ticks, int mode,
+                       const int* stop, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

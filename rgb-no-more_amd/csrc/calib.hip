@@ -234,3 +234,48 @@ extern "C" int rgbnm_calib_pipes(const int* role_dev, int waves, int iters, int 
     hipLaunchKernelGGL(rgbnm::calib_pipes_kernel, dim3(workgroups), dim3(64 * waves), 0, (hipStream_t)stream, role_dev, iters, out, sink);
     return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
 }
+
+// ---- the stand-in for an RCCL channel: `workgroups` workgroups of 256 threads that each hold `lds_bytes` of LDS (so that a
+// one-workgroup-per-CU kernel cannot be placed next to them when lds_bytes is large, and can when it is small) and stay resident
+// until `ticks` s_memtime ticks have passed or *stop becomes non-zero, re-reading an L2-sized slice of `buf` meanwhile (mode 1) or
+// just sleeping (mode 0).  tools/cu_steal_probe.py times the chain kernels next to it; tests/test_chain_soak.py uses it as the timing
+// perturber under which the one race of round 4 showed.
+namespace rgbnm {
+__global__ __launch_bounds__(256) void calib_occupy_kernel(const unsigned char* __restrict__ buf, size_t slice_bytes, long long ticks,
+                                                           int mode, const volatile int* stop, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    unsigned acc = 0;
+    const unsigned char* base = buf + (size_t)blockIdx.x * slice_bytes;
+    size_t off = (size_t)threadIdx.x * 16;
+    if (threadIdx.x == 0) smem[0] = 1;                       // (the allocation is real even if nobody reads it)
+    for (;;) {
+        if (mode == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u4 v = *reinterpret_cast<const u4*>(base + off);
+                acc += v[0] ^ v[3];
+                off += 4096;
+                if (off >= slice_bytes) off = (size_t)threadIdx.x * 16;
+            }
+        } else {
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if ((long long)(__builtin_amdgcn_s_memtime() - t0) >= ticks) break;
+        if (stop && *stop) break;
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc + smem[0];
+}
+}  // namespace rgbnm
+
+extern "C" int rgbnm_calib_occupy(const void* buf, size_t slice_bytes, int workgroups, int lds_bytes, long long ticks, int mode,
+                                  const int* stop, void* sink, void* stream) {
+    if (workgroups <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024 || ticks <= 0 || mode < 0 || mode > 1 || !sink) return RGBNM_EINVAL;
+    if (mode == 1 && (!buf || slice_bytes < 4096 || slice_bytes % 4096)) return RGBNM_EINVAL;
+    if (hipFuncSetAttribute((const void*)rgbnm::calib_occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return RGBNM_ELAUNCH;
+    hipLaunchKernelGGL(rgbnm::calib_occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                       (const unsigned char*)buf, slice_bytes, ticks, mode, (const volatile int*)stop, (unsigned*)sink);
+    return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
+}

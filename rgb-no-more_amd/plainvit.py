@@ -510,8 +510,15 @@ class _BlockFn(torch.autograd.Function):
                 st.dw_pending.append((idx, g, dy.data_ptr()))       # (no reference to the gradient views: autograd must be able to adopt them)
                 if st.gbuf.data_ptr() != m._gflat.data_ptr():
                     group = 1          # a side buffer that autograd ADDS to attached gradients when this node returns: no deferring
+                elif st.holding:
+                    group = m.depth    # held reductions: by contract nobody reads a block gradient before backward() returns
+                elif m._grad_sync is not None:
+                    group = m.dw_group_overlapped      # the flat exchange owns the gradients and is told (ready) when a group has run
                 else:
-                    group = m.depth if (m._grad_sync is None or st.holding) else m.dw_group_overlapped
+                    # plain autograd / torch DDP: AccumulateGrad, DDP's bucket hooks and any param hook read the gradient as soon as
+                    # THIS node returns, so its weight-gradient GEMMs must have been launched by then (deferring them to
+                    # block 0's node handed DDP stale buffers)
+                    group = 1
                 if len(st.dw_pending) >= group or idx == 0:
                     pend, st.dw_pending = st.dw_pending, []
                     n = len(pend)
@@ -918,6 +925,16 @@ class ViT(FlatParamModule):
         if self._ncls_pad != self.n_classes:
             self._b2pad[:self.n_classes].copy_(self._named["classhead.ch_linear2.bias"].detach())
 
+    def _warn_chain_refused(self, which):
+        """The library refused the one-launch encoder kernel for a model that looks eligible from here (E = 192, 3 heads, bf16,
+        option on): depth > 12 or no usable GELU table.  The per-operation kernels run instead -- same results, about half the
+        speed -- so say it once instead of silently."""
+        key = "_warned_chain_" + which
+        if not getattr(self, key, False):
+            setattr(self, key, True)
+            warnings.warn(f"rgb-no-more_amd: the one-launch encoder {which} kernel refused this model (depth {self.depth} > 12 or no "
+                          f"GELU table); running the per-operation kernels (about 2x slower)", RuntimeWarning, stacklevel=3)
+
     def _chain_forward(self, a):
         """Run all encoder blocks as one launch into arena `a` (rgbnm_vit_chain_fwd); False = not eligible (per-block path)."""
         if a.cdtype != torch.bfloat16 or self._chain_idx is None or not L.lib().rgbnm_get_option(b"fwd_chain"):
@@ -934,6 +951,7 @@ class ViT(FlatParamModule):
             a.chain_table = blocks        # host array: the library copies it into the kernel's argument segment
         rc = L.lib().rgbnm_vit_chain_fwd(C.byref(a.cfg), a.chain_table, self.depth, a.xbuf(0).data_ptr(), L.stream())
         if rc == 1:
+            self._warn_chain_refused("forward")
             return False
         L.check(rc, "vit_chain_fwd")
         return True
@@ -970,6 +988,7 @@ class ViT(FlatParamModule):
             a.chain_bwd_dy = dy.data_ptr()
         rc = L.lib().rgbnm_vit_chain_bwd(C.byref(a.cfg), a.chain_bwd_table, D, a.dattn_chain.data_ptr(), L.stream())
         if rc == 1:
+            self._warn_chain_refused("backward")
             return False
         L.check(rc, "vit_chain_bwd")
         return True

@@ -110,3 +110,30 @@ def test_direct_weight_gradient_writes_equal_the_reduced_ones():
         lib.rgbnm_set_option(b"tn_direct", 1)
     for n in a:
         assert np.array_equal(a[n], b[n]), n
+
+
+def test_one_node_per_block_hands_out_final_gradients():
+    """ViT.single_encoder_node = False with the one-launch backward and no gradient exchange (= what torch DDP wraps): a hook on a
+    parameter of block 7 runs while blocks 6 .. 0 are still to come and must already see that block's FINAL gradient -- DDP's bucket
+    hooks read it at exactly that point.  Compared with the one-node encoder's gradients (same kernels, another grouping of the
+    weight-gradient launch: fp32 sums in another order)."""
+    m, y, c, tgt = build(12, 64)
+    ref = step(m, y, c, tgt, True)
+    seen = {}
+    names = ["encoder.7.0.fn.eb_mha.qkv.weight", "encoder.7.1.fn.eb_ffb.3.weight", "encoder.11.1.fn.eb_ffb.0.bias",
+             "encoder.3.0.fn.eb_lrnorm1.weight"]
+    named = dict(m.named_parameters())
+    handles = [named[n].register_post_accumulate_grad_hook(lambda p, n=n: seen.__setitem__(n, p.grad.detach().float().cpu().numpy().copy()))
+               for n in names]
+    m.single_encoder_node = False
+    try:
+        got = step(m, y, c, tgt, True)
+    finally:
+        m.single_encoder_node = True
+        for h in handles:
+            h.remove()
+    assert sorted(seen) == sorted(names)
+    for n in names:
+        assert np.array_equal(seen[n], got[n]), f"{n}: the hook saw a gradient that changed afterwards"
+    for n in ref:
+        assert np.abs(got[n] - ref[n]).max() <= 1e-5 * np.abs(ref[n]).max() + 1e-30, n

@@ -168,3 +168,19 @@ def test_bit_reproducibility_at_the_bench_batch():
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
     assert torch.equal(outs[0], ref[0])
+
+
+def test_depth_13_falls_back_to_the_per_operation_kernels_with_a_warning():
+    """The chain kernels carry at most twelve blocks in their argument segment: a deeper encoder must run -- on the per-operation
+    kernels, same bits as with the option off -- and say so once (ViT._warn_chain_refused), forward and backward."""
+    m, y, c, tgt = build(13, 3)
+    with pytest.warns(RuntimeWarning, match="one-launch encoder"):
+        lo_c, g_c, _ = step(m, y, c, tgt, True)
+    L.lib().rgbnm_set_option(b"bwd_chain", 0)
+    try:
+        lo_p, g_p, _ = step(m, y, c, tgt, False)
+    finally:
+        L.lib().rgbnm_set_option(b"bwd_chain", 1)
+    assert np.array_equal(lo_c, lo_p)
+    for n in g_p:
+        assert np.array_equal(g_c[n], g_p[n]), n

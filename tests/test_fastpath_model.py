@@ -1,4 +1,6 @@
-"""Model-level parity of the FAST-PATH kernel mix -- the code bench.py actually times.
+"""Model-level parity of the PER-OPERATION fast-path kernel mix (bf16, large batch) -- what bench.py times for JPEG-S and for any
+ViT the one-launch encoder kernels refuse; the JPEG-Ti step bench.py times runs the chain kernels, which tests/test_chain_fwd.py,
+test_chain_bwd.py, test_chain_soak.py and the LAST test of this file (chain options switched back on) cover.
 
 The small-batch goldens (g11, B = 2/4 -> 392/784 tokens) only reach the generic kernels.  Here the batch is 64 and 256
 (12 544 / 50 176 tokens), which makes the bf16 step eligible for the weight-resident GEMM (`gemm_nt_wres`), the row-panel
@@ -39,6 +41,7 @@ DEV = "cuda"
 CASES = {"ti_d2_b64": (192, 3, 2, 64, False), "ti_d12_b64": (192, 3, 12, 64, False), "s_d2_b64": (384, 6, 2, 64, False),
          "ti_d12_b256": (192, 3, 12, 256, True), "s_d12_b64": (384, 6, 12, 64, False)}
 BF16_LOGIT_TOL = 1e-2        # bf16 operands, fp32 accumulate, vs the fp32 reference (bench.py's parity_check uses the same bar)
+GRADNORM_MEDIAN_BAR, GRADNORM_MAX_BAR = 2e-2, 0.15      # bf16 gradient norms vs the reference (tightened below where measured)
 FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe", "mlp_fuse", "mlp_bwd")
 
 
@@ -392,22 +395,26 @@ def test_jpeg_s_at_the_timed_batch_256_vs_reference_golden(golden, compute):
 
 
 def test_bf16_gradient_slices_per_tensor_at_the_bench_configuration(golden):
-    """JPEG-Ti, B = 256, depth 12, bf16, chain kernels on (the default = what bench.py times): the three gradient slices g20 holds,
-    per-tensor relative error <= 3e-2, next to the logit / loss / gradient-norm checks above."""
+    """JPEG-Ti, B = 256, depth 12, bf16, chain kernels on (the default = what bench.py times): the FOURTEEN gradient slices of golden
+    g22 (make_golden_r5.py: patch embedding, head, and qkv / projection / fc1 / LayerNorm-2 of blocks 0, 5, 11), per-tensor relative
+    error <= 3e-2, next to the logit / loss / gradient-norm checks."""
     lib = L.lib()
     lib.rgbnm_set_option(b"fwd_chain", 1)
     lib.rgbnm_set_option(b"bwd_chain", 1)
-    g = golden("g20_fullsize.npz")
+    g, g22 = golden("g20_fullsize.npz"), golden("g22_ti_b256_grads.npz")
     tag = "ti_d12_b256"
     m, sd, y, c, tgt = build(tag, torch.bfloat16)
     logits, loss, gn = run(m, y, c, tgt, torch.bfloat16)
     assert np.abs(logits - g[tag + "_logits"]).max() <= BF16_LOGIT_TOL
     rel = np.abs(gn - g[tag + "_gradnorms"]) / (g[tag + "_gradnorms"] + 1e-12)
-    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+    print(f"gradient norms vs the reference: median {np.median(rel):.3e} max {rel.max():.3e}")
+    assert np.median(rel) < GRADNORM_MEDIAN_BAR and rel.max() < GRADNORM_MAX_BAR
     named = dict(m.named_parameters())
-    for nm in ("encoder.0.0.fn.eb_mha.qkv.weight", "encoder.11.1.fn.eb_ffb.0.weight", "patchembed.projection.0.weight"):
+    names = [str(n) for n in g22[tag + "_slice_names"]]
+    assert len(names) >= 12
+    for nm in names:
         got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
-        want = g[tag + "_grad_" + nm].astype(np.float64)
+        want = g22[tag + "_grad_" + nm].astype(np.float64)
         r = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
         print(nm, "bf16 gradient slice rel", f"{r:.3e}")
         assert r < 3e-2, (nm, r)

@@ -209,3 +209,19 @@ def test_g16_out_of_list_ops_invert_solarize_freqenhance(golden):
     for k in range(int(g["ncases"])):
         oy, oc = O.apply_op(g["Y"], g["C"], str(g[f"case{k}_name"]), float(g[f"case{k}_mag"]))
         assert np.array_equal(oy, g[f"case{k}_Y"]) and np.array_equal(oc, g[f"case{k}_C"]), k
+
+
+def test_g22_agrees_with_g20(golden):
+    """g22 (make_golden_r5.py) re-ran the reference JPEG-Ti at B = 256 for more gradient slices: everything it shares with g20
+    (make_golden_r3.py, same seeds) must be the same numbers -- the two files pin each other."""
+    g20, g22 = golden("g20_fullsize.npz"), golden("g22_ti_b256_grads.npz")
+    tag = "ti_d12_b256"
+    assert abs(float(g20[tag + "_loss"]) - float(g22[tag + "_loss"])) < 1e-6
+    np.testing.assert_allclose(g22[tag + "_gradnorms"], g20[tag + "_gradnorms"], rtol=1e-5)
+    np.testing.assert_allclose(g22[tag + "_logits_every8"], g20[tag + "_logits"][:, ::8], atol=1e-5)
+    names = [str(n) for n in g22[tag + "_slice_names"]]
+    assert len(names) == 14
+    shared = [n for n in names if tag + "_grad_" + n in g20.files]
+    assert len(shared) >= 2
+    for n in shared:
+        np.testing.assert_allclose(g22[tag + "_grad_" + n], g20[tag + "_grad_" + n], rtol=1e-4, atol=1e-9)

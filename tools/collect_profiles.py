@@ -5,7 +5,7 @@
     python tools/collect_profiles.py <tag>/vits <name>     for the per-arch directories of `archs`
 
 Writes profiles/<name>_{bench_line.json,kernel_stats.csv,pmc_mfma.json,pmc_traffic.json} (those that exist) and refreshes
-profiles/pmc_traffic[_<arch>].json, the file bench.py reads `roofline.traffic` from."""
+profiles/{pmc_traffic,pmc_mfma,calibration}[_<arch>].json, the files bench.py quotes its file-sourced fields from."""
 import json
 import os
 import shutil
@@ -28,11 +28,12 @@ def main(tag, name):
                     arch = {"JPEG-Ti": "vitti", "JPEG-S": "vits", "SwinV2-T": "swinv2t"}[json.load(open(p))["metric"].split()[1]]
                 except Exception:       # noqa: BLE001
                     pass
-    t = os.path.join(src, "pmc_traffic.json")
-    if os.path.exists(t):
-        out = "pmc_traffic.json" if arch == "vitti" else f"pmc_traffic_{arch}.json"
-        shutil.copy(t, os.path.join(dst, out))
-        print("profiles/" + out)
+    for stem in ("pmc_traffic", "pmc_mfma", "calibration"):        # the files bench.py quotes (labelled file-sourced on its line)
+        t = os.path.join(src, stem + ".json")
+        if os.path.exists(t) and os.path.getsize(t) > 0:
+            out = f"{stem}.json" if arch == "vitti" else f"{stem}_{arch}.json"
+            shutil.copy(t, os.path.join(dst, out))
+            print("profiles/" + out)
 
 
 if __name__ == "__main__":
