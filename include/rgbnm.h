@@ -480,6 +480,10 @@ int rgbnm_calib_pipes(const int* role_dev, int waves, int iters, int workgroups,
  * (mode 0).  Measurement / test perturber only (tools/cu_steal_probe.py, tests/test_chain_soak.py). */
 int rgbnm_calib_occupy(const void* buf, size_t slice_bytes, int workgroups, int lds_bytes, long long ticks, int mode,
                        const int* stop, void* sink, void* stream);
+/* the same with a residency log (device memory, 3 x workgroups 64-bit words): [3 wg] = s_memrealtime (100 MHz) at the workgroup's
+ * start, [3 wg + 1] at its end, [3 wg + 2] = (XCC id << 32) | HW_ID */
+int rgbnm_calib_occupy_log(const void* buf, size_t slice_bytes, int workgroups, int lds_bytes, long long ticks, int mode,
+                           const int* stop, void* sink, unsigned long long* log, void* stream);
 
 #ifdef __cplusplus
 }

@@ -242,9 +242,16 @@ extern "C" int rgbnm_calib_pipes(const int* role_dev, int waves, int iters, int 
 // perturber under which the one race of round 4 showed.
 namespace rgbnm {
 __global__ __launch_bounds__(256) void calib_occupy_kernel(const unsigned char* __restrict__ buf, size_t slice_bytes, long long ticks,
-                                                           int mode, const volatile int* stop, unsigned* sink) {
+                                                           int mode, const volatile int* stop, unsigned* sink,
+                                                           unsigned long long* log) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (log && threadIdx.x == 0) {      // residency record of this workgroup: start (100 MHz), [end], hardware id (XCC, SE, CU)
+        log[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID, all 32 bits
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));       // HW_REG_XCC_ID, bits 0..3
+        log[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     unsigned acc = 0;
     const unsigned char* base = buf + (size_t)blockIdx.x * slice_bytes;
@@ -266,16 +273,25 @@ __global__ __launch_bounds__(256) void calib_occupy_kernel(const unsigned char* 
         if (stop && *stop) break;
     }
     if (acc == 0x9e3779b9u) sink[0] = acc + smem[0];
+    if (log && threadIdx.x == 0) log[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 }  // namespace rgbnm
 
+extern "C" int rgbnm_calib_occupy_log(const void* buf, size_t slice_bytes, int workgroups, int lds_bytes, long long ticks, int mode,
+                                      const int* stop, void* sink, unsigned long long* log, void* stream);
 extern "C" int rgbnm_calib_occupy(const void* buf, size_t slice_bytes, int workgroups, int lds_bytes, long long ticks, int mode,
                                   const int* stop, void* sink, void* stream) {
+    return rgbnm_calib_occupy_log(buf, slice_bytes, workgroups, lds_bytes, ticks, mode, stop, sink, nullptr, stream);
+}
+// the same with a residency log: log[3 wg] = s_memrealtime (100 MHz) at the workgroup's start, [3 wg + 1] at its end,
+// [3 wg + 2] = (XCC id << 32) | HW_ID -- so that a probe can tell WHERE and WHEN the stand-ins really were resident
+extern "C" int rgbnm_calib_occupy_log(const void* buf, size_t slice_bytes, int workgroups, int lds_bytes, long long ticks, int mode,
+                                      const int* stop, void* sink, unsigned long long* log, void* stream) {
     if (workgroups <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024 || ticks <= 0 || mode < 0 || mode > 1 || !sink) return RGBNM_EINVAL;
     if (mode == 1 && (!buf || slice_bytes < 4096 || slice_bytes % 4096)) return RGBNM_EINVAL;
     if (hipFuncSetAttribute((const void*)rgbnm::calib_occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return RGBNM_ELAUNCH;
     hipLaunchKernelGGL(rgbnm::calib_occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
-                       (const unsigned char*)buf, slice_bytes, ticks, mode, (const volatile int*)stop, (unsigned*)sink);
+                       (const unsigned char*)buf, slice_bytes, ticks, mode, (const volatile int*)stop, (unsigned*)sink, log);
     return hipGetLastError() == hipSuccess ? RGBNM_OK : RGBNM_ELAUNCH;
 }

@@ -69,6 +69,18 @@ constexpr int FLAG_OFF = B2_OFF + E * 4;           // 73088: the last hidden chu
 constexpr int ST0_OFF = K_OFF;                    // even hidden chunks (over K, V: dead by then)
 constexpr int TB_OFF = ST0_OFF + STAGE;           // 122880: gelu | gelu' tiles of waves 0..4
 constexpr int SMEM = 163840;
+#ifndef PIPE_QKV
+#define PIPE_QKV 6
+#endif
+#ifndef PIPE_P
+#define PIPE_P 6
+#endif
+#ifndef PIPE_M1
+#define PIPE_M1 5
+#endif
+#ifndef PIPE_M2
+#define PIPE_M2 6
+#endif
 static_assert(BQKV_OFF + 3 * INNER * 4 <= SMEM, "LDS");
 static_assert(TB_OFF + 10 * STG_TILE <= SMEM, "LDS");
 static_assert(FLAG_OFF + 16 <= ST0_OFF, "LDS");
@@ -103,6 +115,20 @@ struct Geo {
 __device__ __forceinline__ Geo make_geo() {
   Geo L;
   L.lane = threadIdx.x & 63;
+  L.l31 = L.lane & 31;
+  L.g = L.lane >> 5;
+  L.fl = fswz(L.l31);
+  const int k = (L.lane >> 2) & 3, G1 = (L.lane >> 4) & 1, l3 = L.lane & 3;
+  const int pc = (2 * G1 + (l3 >> 1)) ^ (((k >> 1) << 2) | L.g);
+  L.tr0 = (unsigned)((4 * L.g + k) * ROWB + pc * 16 + 8 * (l3 & 1));
+  return L;
+}
+
+// The same from a lane id the optimiser cannot trace (common.h lane_id_here): every phase derives its per-lane constants anew, so
+// none of them is live -- or spilled -- across the register-heavy phases in between
+__device__ __forceinline__ Geo fresh_geo() {
+  Geo L;
+  L.lane = lane_id_here();
   L.l31 = L.lane & 31;
   L.g = L.lane >> 5;
   L.fl = fswz(L.l31);
@@ -149,6 +175,21 @@ __device__ __forceinline__ void tfrag4(unsigned a0, Frag<bf16> (&f)[4]) {
   f[1].v = pack8(r2, r3);   // fi=0, dt=1
   f[2].v = pack8(r4, r5);   // fi=1, dt=0
   f[3].v = pack8(r6, r7);   // fi=1, dt=1
+}
+// The same through the compiler's builtin: the reads are ordinary DS loads to the scheduler (they can be requested ahead and
+// waited for where they are used; the asm form above waits on the spot)
+typedef bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4v* lds_b64_ptr;
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* smem, unsigned off) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_ptr)(smem + off)));
+}
+template <int T>
+__device__ __forceinline__ void tfrag4_b(const unsigned char* smem, unsigned a0, Frag<bf16> (&f)[4]) {
+  const unsigned a00 = a0, a01 = (a0 ^ 32u) + 1024u, a10 = a0 ^ 64u, a11 = (a0 ^ 96u) + 1024u;
+  f[0].v = pack8(tr_read(smem, a00 + T * 4096), tr_read(smem, a01 + T * 4096));
+  f[1].v = pack8(tr_read(smem, a10 + T * 4096), tr_read(smem, a11 + T * 4096));
+  f[2].v = pack8(tr_read(smem, a00 + T * 4096 + 2048), tr_read(smem, a01 + T * 4096 + 2048));
+  f[3].v = pack8(tr_read(smem, a10 + T * 4096 + 2048), tr_read(smem, a11 + T * 4096 + 2048));
 }
 __device__ __forceinline__ Frag<bf16> pfrag(const float (&p)[16], int fi) {
   Frag<bf16> f;
@@ -297,6 +338,37 @@ __device__ __forceinline__ void gemm_k192(f32x16& acc, const unsigned char* sW, 
     fx.v = as_bf16x8(x.v[c]);
     mma(acc, fb, fx);
   }
+}
+
+// Both 32-row halves (ht = 0, 1) of a 64 x 192 chunk times x as ONE stream of 24 MFMAs with the weight fragments requested
+// DEPTH MFMAs ahead.  Left to itself the scheduler (256 registers: "minimum pressure" everywhere) emits read -> wait -> MFMA with a
+// single fragment buffer, i.e. one exposed LDS latency (100+ cycles under load) per 32-cycle MFMA; two waves per SIMD hide half
+// of it at best.  The order is pinned with sched_group_barrier, the compiler counts the lgkmcnt values.
+template <int DEPTH>
+__device__ __forceinline__ void gemm_k192x2(f32x16& a0, f32x16& a1, const unsigned char* sW, const Rows& x, const Geo& L) {
+  int wb0 = L.l31 * (E * 2) + ((L.g ^ L.fl) << 4);
+  asm volatile("" : "+v"(wb0));
+  const int wb1 = wb0 + 32 * (E * 2);
+  Frag<bf16> fb[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    const int c = i >> 1;
+    fb[i].v = *reinterpret_cast<const bf16x8*>(sW + ((((i & 1) ? wb1 : wb0) ^ ((c % 4) << 5)) + 128 * (c / 4)));
+  }
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    Frag<bf16> fx;
+    fx.v = as_bf16x8(x.v[i >> 1]);
+    mma((i & 1) ? a1 : a0, fb[i], fx);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
+#pragma unroll
+  for (int i = 0; i < 24 - DEPTH; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 }
 
 #ifdef CHAIN_PROF
@@ -500,6 +572,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
     Frag<bf16> of[HEADS][4];                                      // attention output of the three heads as projection operands
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) {
+      const Geo L = fresh_geo();
       Rows xn;
       __builtin_amdgcn_sched_barrier(0);
       ln_apply(xr, mu1, rs1, ln1p, L.g, xn);                      // LN1 output, recomputed per head (48 registers not held)
@@ -513,11 +586,15 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         const unsigned char* sW = smem + A_SLOT0 + m * SLOT;
         f32x16 acc[2];
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
+        for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[ht][r] = 0.f;
-          gemm_k192(acc[ht], sW, ht, xn, L);
-        }
+#ifdef X_NOPIPE
+        gemm_k192(acc[0], sW, 0, xn, L);
+        gemm_k192(acc[1], sW, 1, xn, L);
+#else
+        gemm_k192x2<PIPE_QKV>(acc[0], acc[1], sW, xn, L);
+#endif
         u32x4 pc[4];
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
@@ -547,10 +624,12 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
       // ---------------- attention of head h (the forward of attention_v2.hip: scores recomputed in the second pass)
       BAR(4 * h + 3);                             // step 4 h + 3: every K, V row is written
       {
+        const Geo L = fresh_geo();
         const unsigned char* Ks = smem + K_OFF;
         unsigned rb = (unsigned)(L.l31 * ROWB + ((L.g ^ L.fl) << 4)), tr = L.tr0;
         asm volatile("" : "+v"(rb), "+v"(tr));
         float mx = -INFINITY;
+#if defined(X_NOPIPE) || defined(X_NOATTN)
 #ifdef X_NOATTN
         TileLoop<0>::run([&](auto tc) {
 #else
@@ -573,6 +652,43 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             mx = fmaxf(mx, v);
           }
         });
+#else
+        // software-pipelined by hand, one fence per key tile: the K fragments of tile t + 1 are requested, then the 4 MFMAs of tile t
+        // are issued and the maxima of tile t - 1 run under them (two score tiles live)
+        {
+          Frag<bf16> kc[4], kn[4];
+          f32x16 prev;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) kc[c].v = *reinterpret_cast<const bf16x8*>(Ks + (rb ^ (unsigned)(c << 5)));
+          TileLoop<NTILE + 1>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            f32x16 acc;
+            if (t + 1 < NTILE) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                kn[c].v = *reinterpret_cast<const bf16x8*>(Ks + (rb ^ (unsigned)(c << 5)) + (t + 1) * 32 * ROWB);
+            }
+            if (t < NTILE) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) mma(acc, kc[c], qf[c]);
+            }
+            if (t >= 1) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float v = prev[r];
+                if (t * 32 > NTOK && (t - 1) * 32 + acc_row(r, L.lane) >= NTOK) v = -INFINITY;
+                mx = fmaxf(mx, v);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            prev = acc;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kc[c] = kn[c];
+          });
+        }
+#endif
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mc2 = mx * c2;
         float sum = 0.f;
@@ -582,6 +698,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
         const unsigned vt = (unsigned)V_OFF + tr;
+#if defined(X_NOPIPE) || defined(X_NOATTN)
 #ifdef X_NOATTN
         TileLoop<0>::run([&](auto tc) {
 #else
@@ -613,6 +730,51 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
           mma(o[0], vv[2], pf);
           mma(o[1], vv[3], pf);
         });
+#else
+        // one fenced region per key tile: S_t (K fragments requested in the previous region), then the V fragments of this tile and
+        // the K fragments of the next one are requested and travel under the exponentials, P.V_t
+        {
+          Frag<bf16> kc[4], kn[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) kc[c].v = *reinterpret_cast<const bf16x8*>(Ks + (rb ^ (unsigned)(c << 5)));
+          __builtin_amdgcn_sched_barrier(0);
+          TileLoop<NTILE>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mma(acc, kc[c], qf[c]);
+            Frag<bf16> vv[4];
+            tfrag4_b<t>(smem, vt, vv);
+            if (t + 1 < NTILE) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                kn[c].v = *reinterpret_cast<const bf16x8*>(Ks + (rb ^ (unsigned)(c << 5)) + (t + 1) * 32 * ROWB);
+            }
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              pr[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mc2));
+              if (t * 32 + 32 > NTOK && t * 32 + acc_row(r, L.lane) >= NTOK) pr[r] = 0.f;
+              sum += pr[r];
+            }
+            Frag<bf16> pf = pfrag(pr, 0);
+            mma(o[0], vv[0], pf);
+            mma(o[1], vv[1], pf);
+            pf = pfrag(pr, 1);
+            mma(o[0], vv[2], pf);
+            mma(o[1], vv[3], pf);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (t + 1 < NTILE) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kc[c] = kn[c];
+          });
+        }
+#endif
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
         if (L.g == 0 && L.l31 < live) b.lse[((size_t)img * HEADS + h) * NTOK + row0 + L.l31] = mx * p.scale + __logf(sum);
@@ -656,6 +818,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
       }
     }
     // ---------------- output projection: 3 steps of 24 MFMAs (k = the 64 dims of head h), then residual + LN2
+    const Geo L = fresh_geo();
     f32x16 accp[6];
 #pragma unroll
     for (int bt = 0; bt < 6; ++bt)
@@ -678,6 +841,18 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #pragma unroll
         for (int bt = 0; bt < 6; ++bt) mma(accp[bt], fw[bt], of[h][s]);
       }
+#ifndef X_NOPIPE
+      // the 24 weight fragments of the step PIPE_P MFMAs ahead of their use
+      __builtin_amdgcn_sched_group_barrier(0x100, PIPE_P, 0);
+#pragma unroll
+      for (int i = 0; i < 24 - PIPE_P; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < PIPE_P; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     BAR(15);                                                      // step 14b: the chunk slots are free (fc1-bias ring lives there)
     float mu2, rs2;
@@ -752,6 +927,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         for (int r = 0; r < 16; ++r) a1[r] = 0.f;
         int wbase = woff0 + ht * 32 * (E * 2);
         asm volatile("" : "+v"(wbase));
+#ifdef X_NOPIPE
         Frag<bf16> fb;
 #pragma unroll
         for (int c = 0; c < 12; ++c) {
@@ -763,6 +939,35 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
           fx.v = as_bf16x8(fa.v[c]);
           mma(a1, fb, fx);
         }
+#else
+        {
+          Frag<bf16> fb[12];
+#pragma unroll
+          for (int c = 0; c < 12; ++c)
+            fb[c].v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+#pragma unroll
+          for (int c = 0; c < 12; ++c) {
+            Frag<bf16> fx;
+            fx.v = as_bf16x8(fa.v[c]);
+            mma(a1, fb[c], fx);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, PIPE_M1, 0);
+#pragma unroll
+          for (int i = 0; i < 12 - PIPE_M1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < PIPE_M1; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the six W2 fragments of the first 16 hidden columns travel under the GELU arithmetic
+        Frag<bf16> fw2[12];
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt)
+          fw2[bt].v = *reinterpret_cast<const bf16x8*>(smem + (w2o ^ (unsigned)((2 * ht) << 5)) + bt * 32 * ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         Frag<bf16> pg[2];
         if (handed && ht == 0 && chunk > 0) {                      // the DMA wave has taken the previous chunk's tiles (normally long ago)
           while (__builtin_amdgcn_readfirstlane(*flag) < chunk) __builtin_amdgcn_s_sleep(1);
@@ -818,6 +1023,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             *reinterpret_cast<bf16x8*>(smem + to + tpoff) = dv;
           }
         }
+#ifdef X_NOPIPE
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) {
           const int s = 2 * ht + hs;
@@ -831,6 +1037,24 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #pragma unroll
           for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw[bt], pg[hs]);
         }
+#else
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt)
+          fw2[6 + bt].v = *reinterpret_cast<const bf16x8*>(smem + (w2o ^ (unsigned)((2 * ht + 1) << 5)) + bt * 32 * ROWB);
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw2[bt], pg[0]);
+#pragma unroll
+        for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw2[6 + bt], pg[1]);
+        // (hs = 0's fragments landed under the GELU; hs = 1's are requested one per MFMA)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       // the chunk's gelu / gelu' tiles out as whole 128-byte row pieces
       wait_lds();

@@ -40,6 +40,15 @@ constexpr int NCW = 7, NTHREADS = 64 * (NCW + 1), CTHREADS = 64 * NCW, BM = 32 *
 constexpr int ROWB = 128, ARR = NPAD * ROWB, SLOT = 24576, STAGE = 2 * SLOT, CH = 64, NCHUNK = HID / CH;
 constexpr int CP = E + 4;                           // pitch (elements) of the LayerNorm-backward staging tile
 constexpr int SMEM = 163840;
+#ifndef PIPE_P
+#define PIPE_P 6
+#endif
+#ifndef PIPE_M1
+#define PIPE_M1 5
+#endif
+#ifndef PIPE_X
+#define PIPE_X 7
+#endif
 // ---- M: two weight stages | per wave: gelu' tile, du tile
 constexpr int M_STG = 2 * STAGE;                    // 98304
 constexpr int TILE = 32 * ROWB;                     // 4096
@@ -234,6 +243,51 @@ __device__ __forceinline__ void gemm_k192(f32x16& acc, const unsigned char* sW, 
     fx.v = as_bf16x8(x.v[c]);
     mma(acc, fb, fx);
   }
+}
+
+// Both 32-row halves (ht = 0, 1) of a 64 x 192 chunk times x as ONE stream of 24 MFMAs with the weight fragments requested DEPTH
+// MFMAs ahead (vit_chain.hip gemm_k192x2: left to itself the scheduler emits read -> wait -> MFMA with one fragment buffer, i.e.
+// an exposed LDS latency per MFMA)
+template <int DEPTH>
+__device__ __forceinline__ void gemm_k192x2(f32x16& a0, f32x16& a1, const unsigned char* sW, const Rows& x, const Geo& L) {
+  int wb0 = L.l31 * (E * 2) + ((L.g ^ L.fl) << 4);
+  asm volatile("" : "+v"(wb0));
+  const int wb1 = wb0 + 32 * (E * 2);
+  Frag<bf16> fb[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    const int c = i >> 1;
+    fb[i].v = *reinterpret_cast<const bf16x8*>(sW + ((((i & 1) ? wb1 : wb0) ^ ((c % 4) << 5)) + 128 * (c / 4)));
+  }
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    Frag<bf16> fx;
+    fx.v = as_bf16x8(x.v[i >> 1]);
+    mma((i & 1) ? a1 : a0, fb[i], fx);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
+#pragma unroll
+  for (int i = 0; i < 24 - DEPTH; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// transpose reads through the compiler's builtin: ordinary DS loads to the scheduler (requested ahead, waited for at the use)
+typedef bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4v* lds_b64_ptr;
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* smem, unsigned off) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_ptr)(smem + off)));
+}
+template <int T>
+__device__ __forceinline__ void tfrag4_b(const unsigned char* smem, unsigned a0, Frag<bf16> (&f)[4]) {
+  const unsigned a00 = a0, a01 = (a0 ^ 32u) + 1024u, a10 = a0 ^ 64u, a11 = (a0 ^ 96u) + 1024u;
+  f[0].v = pack8(tr_read(smem, a00 + T * 4096), tr_read(smem, a01 + T * 4096));
+  f[1].v = pack8(tr_read(smem, a10 + T * 4096), tr_read(smem, a11 + T * 4096));
+  f[2].v = pack8(tr_read(smem, a00 + T * 4096 + 2048), tr_read(smem, a01 + T * 4096 + 2048));
+  f[3].v = pack8(tr_read(smem, a10 + T * 4096 + 2048), tr_read(smem, a11 + T * 4096 + 2048));
 }
 
 // ---- gradient tiles of the attention backward (attention_v2.hip)
@@ -530,6 +584,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
           for (int r = 0; r < 16; ++r) a1[r] = 0.f;
           int wbase = woff0 + ht * 32 * (E * 2);
           asm volatile("" : "+v"(wbase));
+#ifdef X_NOPIPE
 #pragma unroll
           for (int c = 0; c < 12; ++c) {
             Frag<bf16> fb, fx;
@@ -537,6 +592,35 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
             fx.v = as_bf16x8(dyf.v[c]);
             mma(a1, fb, fx);                               // D rows = hidden (rows stored swap23-ed), D cols = tokens
           }
+#else
+          {
+            Frag<bf16> fb[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c)
+              fb[c].v = *reinterpret_cast<const bf16x8*>(sW1 + ((wbase ^ ((c % 4) << 5)) + 128 * (c / 4)));
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+              Frag<bf16> fx;
+              fx.v = as_bf16x8(dyf.v[c]);
+              mma(a1, fb[c], fx);                          // D rows = hidden (rows stored swap23-ed), D cols = tokens
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PIPE_M1, 0);
+#pragma unroll
+            for (int i = 0; i < 12 - PIPE_M1; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < PIPE_M1; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // the six W1 fragments of the first 16 hidden columns travel under the gelu' product
+          Frag<bf16> fw2[12];
+#pragma unroll
+          for (int bt = 0; bt < 6; ++bt)
+            fw2[bt].v = *reinterpret_cast<const bf16x8*>(smem + (w2o ^ (unsigned)((2 * ht) << 5)) + bt * 32 * ROWB);
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           Frag<bf16> pg[2];
 #pragma unroll
           for (int hs = 0; hs < 2; ++hs) {
@@ -548,6 +632,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
             pg[hs].v = dv;
             *reinterpret_cast<bf16x8*>(smem + to + TILE) = dv;
           }
+#ifdef X_NOPIPE
 #pragma unroll
           for (int hs = 0; hs < 2; ++hs) {
             const int s = 2 * ht + hs;
@@ -558,6 +643,23 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
 #pragma unroll
             for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw[bt], pg[hs]);   // D rows = input features, D cols = tokens
           }
+#else
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int bt = 0; bt < 6; ++bt)
+            fw2[6 + bt].v = *reinterpret_cast<const bf16x8*>(smem + (w2o ^ (unsigned)((2 * ht + 1) << 5)) + bt * 32 * ROWB);
+#pragma unroll
+          for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw2[bt], pg[0]);     // D rows = input features, D cols = tokens
+#pragma unroll
+          for (int bt = 0; bt < 6; ++bt) mma(acc2[bt], fw2[6 + bt], pg[1]);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         // the chunk's du tile out as whole row pieces
         wait_lds();
@@ -586,11 +688,15 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
         const unsigned char* sW = smem + (h == 1 ? P_SLOT1 : P_SLOT0);
         f32x16 acc[2];
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
+        for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[ht][r] = 0.f;
-          gemm_k192(acc[ht], sW, ht, dxf, L);
-        }
+#ifdef X_NOPIPE
+        gemm_k192(acc[0], sW, 0, dxf, L);
+        gemm_k192(acc[1], sW, 1, dxf, L);
+#else
+        gemm_k192x2<PIPE_P>(acc[0], acc[1], sW, dxf, L);
+#endif
         u32x4 pc[4];
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
@@ -837,6 +943,16 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
 #pragma unroll
         for (int bt = 0; bt < 6; ++bt) mma(accx[bt], fw[bt], fx);
       }
+#ifndef X_NOPIPE
+      // the 28 fragments of the step (4 x (own rows + 6 weight fragments)) PIPE_X reads ahead of the 24 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, PIPE_X, 0);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 28 - PIPE_X) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     // ================================================================ dx = d(x_mid) + LN1'(dxn1); the next block's dy
     // (requesting the operand rows of this epilogue three steps earlier would hide their latency, but 104 more live registers in

@@ -133,6 +133,7 @@ PROTOTYPES = {
     "rgbnm_calib_l2": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _vp]),
     "rgbnm_calib_pipes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rgbnm_calib_occupy": (_i, [_vp, _sz, _i, _i, C.c_longlong, _i, _vp, _vp, _vp]),
+    "rgbnm_calib_occupy_log": (_i, [_vp, _sz, _i, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "rgbnm_chain_block_bytes": (_sz, []),
     "rgbnm_chain_image_elems": (_ll, []),
     "rgbnm_chain_gather": (_i, [_vp, _vp, _vp, _ll, _vp]),
