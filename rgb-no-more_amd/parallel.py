@@ -113,6 +113,64 @@ class FlatGradSync:
         self.module._grad_sync = None
 
 
+class DeferredFlatExchange:
+    """ONE all-reduce (average) of a whole flat gradient buffer per step, ISSUED right behind the backward and WAITED FOR only in
+    front of the optimizer -- with the NEXT step's data stage queued in between (reference loop: train.py:145-176; there the
+    sample / augment / mixup of batch i + 1 is the DataLoader's business and also independent of optimizer step i).
+
+    Why: with the one-launch encoder kernels the backward of JPEG-Ti is two big launches, so there is little left to overlap an
+    exchange with INSIDE the backward; but sampling, DCT augment, mixup (and, eagerly, the sub-block embed) of the next batch read
+    neither the weights nor the gradients.  The collective runs on the process group's own stream (torch: async_op = True), the
+    compute stream goes on with the data stage and waits for the collective only where the optimizer needs the gradients:
+
+        ex = DeferredFlatExchange(lambda: model._gflat)
+        for batch in ...:
+            x = data_stage(batch)          # queued while the previous step's all-reduce is in flight
+            ex.finish(optimizer_step)      # wait for it, then optimizer step of the PREVIOUS backward (no-op in the first step)
+            forward_backward(x)            # writes the flat gradient buffer
+            ex.issue()                     # all-reduce of this step's gradients starts
+        ex.finish(optimizer_step)          # drain
+
+    Same arithmetic in the same order as the blocking schedule (data stage, forward / backward, all-reduce, optimizer): only the
+    QUEUEING order of two independent things -- next data stage, this optimizer step -- is swapped, so parameters and gradients
+    are bit-identical to it (tests/test_deferred_exchange_gloo_cpu.py, world 2 on gloo)."""
+
+    def __init__(self, flat_grad, process_group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._flat_grad = flat_grad if callable(flat_grad) else (lambda: flat_grad)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self._avg = dist.get_backend(process_group) == "nccl"         # RCCL has ReduceOp.AVG; gloo sums and we scale
+        self._handle, self._buf = None, None
+        self.collectives = 0
+
+    @property
+    def pending(self):
+        return self._handle is not None
+
+    def issue(self):
+        if self._handle is not None:
+            raise RuntimeError("DeferredFlatExchange: the previous step's exchange has not been finished (one backward per step)")
+        self._buf = self._flat_grad()
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._handle = dist.all_reduce(self._buf, op=op, group=self.pg, async_op=True)
+        self.collectives += 1
+
+    def finish(self, optimizer_step=None):
+        """Make the current stream wait for the outstanding all-reduce (if any), then run optimizer_step().  Returns whether there
+        was one: the first step of a run has no gradients yet and skips the optimizer."""
+        if self._handle is None:
+            return False
+        self._handle.wait()
+        if not self._avg:
+            self._buf.mul_(1.0 / self.world)
+        self._handle, self._buf = None, None
+        if optimizer_step is not None:
+            optimizer_step()
+        return True
+
+
 class GatheredFlatGradSync:
     """The same exchange for a FlatParamModule whose backward hands autograd SEPARATE gradient tensors (SwinV2: 221 of them,
     models/swinv2.py:578-711; reference wrap: torch DDP, train.py:137).

@@ -25,9 +25,9 @@ def _free_port():
     return p
 
 
-def _run(extra, timeout=900):
+def _run(extra, timeout=900, **more_env):
     env = dict(os.environ, RGBNM_BENCH_SAME_DEVICE="1", RGBNM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **more_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--prewarm-sec", "0.2", "--no-cpu-baseline"] + extra
@@ -49,10 +49,25 @@ def test_bench_two_ranks_flat_exchange_with_calibration():
     assert cfg["global_batch"] == 2 * cfg["per_gpu_batch"] == 512 and cfg["parallelism"] == "dp2"
     assert cfg["grad_sync"].startswith("flat"), cfg["grad_sync"]        # the self-check passed: no fallback to torch DDP
     cal = cfg["grad_sync_calibration_ms_per_step"]
-    assert len(cal) == 4 and all(v > 0 for v in cal.values()), cal     # incl. "HIP graph replay, then one all-reduce"
+    # incl. "HIP graph replay, then one all-reduce" and the two "all-reduce under the next step's data stage" schedules
+    assert len(cal) == 6 and all(v > 0 for v in cal.values()), cal
+    assert sum("next step's data stage" in k for k in cal) == 2, cal
     assert cfg["grad_sync"].split(": ", 1)[1] in cal
     assert d["parity_check"]["ok"] is True
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] / 1e3)) < 0.01 * d["value"]
+    loss = cfg["loss"]
+    assert loss == loss and 0 < loss < 20
+
+
+def test_bench_two_ranks_exchange_under_the_next_data_stage():
+    """The schedule of VERDICT r4 item 4 (ii), pinned: HIP-graph replay of forward + backward, ONE all-reduce issued behind it and
+    waited for only in front of the optimizer step, which is queued behind the NEXT step's data stage
+    (parallel.DeferredFlatExchange; bit equality with the blocking schedule: tests/test_deferred_exchange_gloo_cpu.py)."""
+    d = _run([], RGBNM_BENCH_SCHEDULE="HIP graph replay, all-reduce under the next step's data stage")
+    cfg = d["config"]
+    assert "all-reduce under the next step's data stage" in cfg["grad_sync"] and cfg["grad_sync"].startswith("flat"), cfg["grad_sync"]
+    assert cfg["launch"].startswith("HIP graph replay"), cfg["launch"]
+    assert d["parity_check"]["ok"] is True
     loss = cfg["loss"]
     assert loss == loss and 0 < loss < 20
 
