@@ -406,6 +406,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
   CP_RT(126);
 
   if (w == NCW) {
+#ifdef X_DMAPRIO
+    __builtin_amdgcn_s_setprio(X_DMAPRIO);
+#endif
     // ================================================================ DMA wave: the static weight schedule
     const int lane = L.lane;
     auto chunkA = [&](const ChainBlk& b, int idx, int slot) {
@@ -536,6 +539,11 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
   }
 
   // ==================================================================== compute waves
+#if defined(X_PRIO) && X_PRIO == 1      // experiments: static issue priority for the younger wave of every SIMD pair
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(X_PRIO) && X_PRIO == 2    // ... for the older one
+  if (w < 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int row0 = 32 * w;
   const int live = NTOK - row0 < 32 ? NTOK - row0 : 32;          // 32, or 4 for the seventh wave
   const int tok = row0 + L.l31 < NTOK ? row0 + L.l31 : NTOK - 1; // this lane's token (clamped: finite data in the pad rows)

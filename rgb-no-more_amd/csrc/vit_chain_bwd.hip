@@ -414,6 +414,9 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
   const int depth = p.depth;
 
   if (w == NCW) {
+#ifdef X_DMAPRIO
+    __builtin_amdgcn_s_setprio(X_DMAPRIO);
+#endif
     // ================================================================ DMA wave
     const int lane = threadIdx.x & 63;
     for (int ib = depth - 1; ib >= 0; --ib) {
@@ -521,6 +524,11 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
   }
 
   // ==================================================================== compute waves
+#if defined(X_PRIO) && X_PRIO == 1      // experiments: static issue priority for the younger wave of every SIMD pair
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(X_PRIO) && X_PRIO == 2    // ... for the older one
+  if (w < 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int row0 = 32 * w;
   const int live = NTOK - row0 < 32 ? NTOK - row0 : 32;
   const size_t grow0 = (size_t)img * NTOK + row0;
