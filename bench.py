@@ -409,6 +409,8 @@ def main():
     # DDP the model ignores / must not get the flag)
     if not swin and not a.no_defer_reduce:
         model.defer_grad_reduction = True
+    if swin and world == 1 and not a.no_defer_reduce:
+        model.group_dw_backward = True          # SwinTransformerV2: the weight-gradient GEMMs of the whole backward in one bracket
     net = model
     grad_sync = "none"
     if world > 1:

@@ -90,6 +90,12 @@ int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, fl
  * Linear's weight gradient as its own GEMM (torch.nn.Linear backward). */
 void rgbnm_gemm_tn_group_begin(void);
 int rgbnm_gemm_tn_group_end(void* stream);
+/* The same with room for up to max_jobs (<= 48) queued GEMMs: a caller that brackets a whole backward pass (swinv2.py: every
+ * Linear of a stage has the same row count) gets launches of up to 256 output tiles -- what is queued runs when the next job
+ * would pass 256 tiles, when the row count changes, when max_jobs are queued, and at _end.  With no token split left the kernel
+ * writes dW / db itself: no partial sums, no reduction.  The operands of a queued call must stay alive and unmodified, and its
+ * dW / db hold nothing, until _end returns. */
+void rgbnm_gemm_tn_group_begin_n(int max_jobs);
 
 /* One nn.Linear in the flat fp32 master buffer and where its shadows go (offsets in elements). */
 typedef struct rgbnm_linear_desc {

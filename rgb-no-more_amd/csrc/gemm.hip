@@ -538,10 +538,12 @@ thread_local bool g_tn_defer = false;     // per host thread, like the reduction
 constexpr int TN_QMAX = 48;
 thread_local TnPending g_tn_q[TN_QMAX];
 thread_local int g_tn_n = 0, g_tn_cap = 4;
+thread_local int g_tn_tiles = 0;          // output tiles of the queued jobs (gemm_tn_pipe.hip: 128 x 192 tiles, one workgroup each)
 
 int tn_flush(hipStream_t st) {
   const int n = g_tn_n;
   g_tn_n = 0;
+  g_tn_tiles = 0;
   if (!n) return RGBNM_OK;
   RgbnmTnJob jobs[TN_QMAX];
   for (int i = 0; i < n; ++i) {
@@ -555,12 +557,16 @@ int tn_flush(hipStream_t st) {
   const int rc = rgbnm_launch_tn_pipe_group(jobs, n, &S, st, rgbnm_get_option("tn_direct") ? &direct : nullptr);
   if (rc != RGBNM_OK) return rc < 0 ? rc : RGBNM_EINVAL;     // eligibility was checked when the jobs were queued
   if (direct) return RGBNM_OK;                               // no token split: the kernel wrote dW / db itself
-  for (int i = 0; i < n; ++i) {
-    const int rr = submit_tn_reduce(g_tn_q[i].p, g_tn_q[i].dW, g_tn_q[i].db, S, g_tn_q[i].perm_heads,
-                                    g_tn_q[i].accumulate, st);
-    if (rr != RGBNM_OK) return rr;
+  const bool own = !rgbnm_reduce_defer_active();             // the reductions of one grouped launch: one launch (also when the
+  if (own) rgbnm_reduce_defer_begin();                       // queue runs by itself in the middle of a long bracket)
+  int rr = RGBNM_OK;
+  for (int i = 0; i < n && rr == RGBNM_OK; ++i)
+    rr = submit_tn_reduce(g_tn_q[i].p, g_tn_q[i].dW, g_tn_q[i].db, S, g_tn_q[i].perm_heads, g_tn_q[i].accumulate, st);
+  if (own) {
+    const int rf = rgbnm_reduce_defer_flush(st);
+    if (rr == RGBNM_OK) rr = rf;
   }
-  return RGBNM_OK;
+  return rr;
 }
 
 bool tn_groupable(const GemmTN& p) {
@@ -579,8 +585,13 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   const int tiles = p.rtiles * p.ctiles;
   if constexpr (sizeof(T) == 2) {
     if (g_tn_defer && tn_groupable(p)) {
-      if (g_tn_n && g_tn_q[0].p.M != p.M) { const int rf = tn_flush(st); if (rf != RGBNM_OK) return rf; }
+      // a grouped launch has one workgroup per output tile and at most 256 of them (rgbnm_launch_tn_pipe_group): what is queued
+      // runs before a job that would take the queue past that, or that has another row count (the queue used to fail
+      // with RGBNM_EINVAL for widths whose blocks have more than 256 / n tiles)
+      const int jt = cdiv(p.No, 128) * (p.Ki / 192);
+      if (g_tn_n && (g_tn_q[0].p.M != p.M || g_tn_tiles + jt > 256)) { const int rf = tn_flush(st); if (rf != RGBNM_OK) return rf; }
       g_tn_q[g_tn_n++] = TnPending{p, dW, db, perm_heads, accumulate};
+      g_tn_tiles += jt;
       return g_tn_n == g_tn_cap ? tn_flush(st) : RGBNM_OK;
     }
     if (rgbnm_get_option("tn_pipe")) {
@@ -725,6 +736,7 @@ int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, fl
 }
 
 void rgbnm_gemm_tn_group_begin(void) { rgbnm_tn_defer_begin(); }
+void rgbnm_gemm_tn_group_begin_n(int max_jobs) { rgbnm_tn_defer_begin_n(max_jobs); }
 
 int rgbnm_gemm_tn_group_end(void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -78,6 +78,7 @@ PROTOTYPES = {
     "rgbnm_strerror": (C.c_char_p, [_i]),
     "rgbnm_set_option": (_i, [C.c_char_p, _i]),
     "rgbnm_gemm_tn_group_begin": (None, []),
+    "rgbnm_gemm_tn_group_begin_n": (None, [_i]),
     "rgbnm_gemm_tn_group_end": (_i, [_vp]),
     "rgbnm_get_option": (_i, [C.c_char_p]),
     "rgbnm_trace_collect": (_i, [_i, _vp, _vp, _vp, _vp]),

@@ -47,13 +47,57 @@ def _gemm_nt(epi, A, W, bias=None, R=None, want_c2=False):
     return out, c2
 
 
-def _gemm_tn(dY, X, want_bias, slot=0):
+class _DwBracket:
+    """ONE rgbnm_gemm_tn_group bracket around a whole backward pass (grouped weight-gradient GEMMs across a stage's
+    blocks, reference: every nn.Linear's weight gradient is its own GEMM under autograd, models/swinv2.py:70-199).
+
+    Every Linear of a stage has the same row count, so with the bracket open the library queues their weight-gradient GEMMs and
+    runs them as launches of up to 256 output tiles (rgbnm.h rgbnm_gemm_tn_group_begin_n): at stages 3 / 4 that is three blocks /
+    most of a block per launch with NO token split -- the kernel writes dW / db itself, no fp32 partial sums and no reduction
+    launch -- where the per-Linear launches split the tokens 5 - 128 ways.  Opened by the backward of the classification head
+    (the first node of the pass), closed by the patch embedding's (the last); until then the queued operands and workspaces are
+    kept alive here and the dW / db tensors handed to autograd hold nothing -- which nobody reads before the pass is over
+    (AccumulateGrad adopts them; an exchange that copies gradients DURING the pass, parallel.GatheredFlatGradSync, switches the
+    bracket off).  Row-paired layers (stage 1) finish their gradients with tensor arithmetic on the spot: what is queued runs
+    first, they run the old way."""
+
+    def __init__(self):
+        self.active = False
+        self.keep = []
+
+    def begin(self):
+        if not self.active:
+            L.lib().rgbnm_gemm_tn_group_begin_n(48)
+            self.active, self.keep = True, []
+
+    def end(self):
+        if self.active:
+            self.active = False
+            rc = L.lib().rgbnm_gemm_tn_group_end(L.stream())
+            self.keep = []
+            L.check(rc, "gemm_tn_group_end")
+
+    def pause(self):
+        L.check(L.lib().rgbnm_gemm_tn_group_end(L.stream()), "gemm_tn_group_end")
+
+    def resume(self):
+        L.lib().rgbnm_gemm_tn_group_begin_n(48)
+
+
+_ACTIVE = [None]        # the bracket of the backward pass that is running (its nodes run one after the other on one autograd thread)
+
+
+def _gemm_tn(dY, X, want_bias, slot=0, keep=None):
     M, No = dY.shape
     Ki = X.shape[1]
     dW = torch.empty(No, Ki, device=dY.device, dtype=torch.float32)
     db = torch.empty(No, device=dY.device, dtype=torch.float32) if want_bias else None
     wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
-    ws = _ws(dY.device, wsb, slot)
+    if keep is None:
+        ws = _ws(dY.device, wsb, slot)
+    else:                               # queued: the call's own workspace and its operands live until the bracket closes
+        ws = torch.empty(wsb, device=dY.device, dtype=torch.uint8)
+        keep.append((dY, X, ws))
     L.check(L.lib().rgbnm_gemm_tn(L.dt_of(dY.dtype), dY.data_ptr(), No, X.data_ptr(), Ki, dW.data_ptr(), L.ptr(db), M, No,
                                   Ki, 0, 0, ws.data_ptr(), ws.numel(), L.stream()), "gemm_tn")
     return dW, db
@@ -81,8 +125,10 @@ def _nt(epi, x, Wsh, pair, bias=None, R=None, want_c2=False):
 def _tn_issue(dy, x, want_bias, pair, slot=0):
     """Launch (or, inside a rgbnm_gemm_tn_group bracket, queue) one weight-gradient GEMM; _tn_finish turns what it returns into
     (dW, db) once the results exist."""
+    br = _ACTIVE[0]
     if not pair:
-        return _gemm_tn(dy, x, want_bias, slot) + (0, 0)
+        queued = br is not None and br.active and dy.dtype == torch.bfloat16
+        return _gemm_tn(dy, x, want_bias, slot, br.keep if queued else None) + (0, 0)
     M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
     return _gemm_tn(dy.view(M // 2, 2 * N), x.view(M // 2, 2 * K), want_bias, slot) + (N, K)   # [[e.e, e.o], [o.e, o.o]] row parities
 
@@ -95,6 +141,13 @@ def _tn_finish(t):
 
 
 def _tn(dy, x, want_bias, pair):
+    br = _ACTIVE[0]
+    if pair and br is not None and br.active:       # finished with tensor arithmetic at once: not a job for the open bracket
+        br.pause()
+        try:
+            return _tn_finish(_tn_issue(dy, x, want_bias, pair))
+        finally:
+            br.resume()
     return _tn_finish(_tn_issue(dy, x, want_bias, pair))
 
 
@@ -107,25 +160,41 @@ class _LinearFn(torch.autograd.Function):
     compute dtype from the per-step shadow buffer (rgbnm_prep_weights): no per-layer cast / transpose kernels."""
 
     @staticmethod
-    def forward(ctx, x, W, b, sh, fork=False):
+    def forward(ctx, x, W, b, sh, fork=False, role=None):
         """fork: also hand x back as a second output for the block's shortcut -- its gradient then arrives HERE and rides the
-        dX GEMM's residual epilogue instead of costing autograd an [M,C] add kernel at the fork (24 per SwinV2-T step)."""
+        dX GEMM's residual epilogue instead of costing autograd an [M,C] add kernel at the fork (24 per SwinV2-T step).
+        role: ("open", bracket) for the classification head, ("close", bracket) for the patch embedding (_DwBracket)."""
         pair = _paired(sh, W)
         y, _ = _nt(L.EPI_NONE, x, sh[0], pair, _fbias(b))
         ctx.save_for_backward(x)
-        ctx.sh, ctx.has_b, ctx.pair = sh, b is not None, pair
+        ctx.sh, ctx.has_b, ctx.pair, ctx.role = sh, b is not None, pair, role
         return (y, x) if fork else y
 
     @staticmethod
     def backward(ctx, dy, dxs=None):
         (x,) = ctx.saved_tensors
         dy = dy.contiguous()
-        dW, db = _tn(dy, x, ctx.has_b, ctx.pair)
+        role = ctx.role
+        if role is not None and role[0] == "open" and all(p.grad is None for p in role[2]):
+            # (gradients still attached -- accumulation over several passes -- would be ADDED TO by AccumulateGrad as each node
+            # returns, i.e. before a queued GEMM has run: such a pass runs the old way)
+            role[1].begin()
+            _ACTIVE[0] = role[1]
+        try:
+            dW, db = _tn(dy, x, ctx.has_b, ctx.pair)
+        except BaseException:
+            if _ACTIVE[0] is not None:
+                br, _ACTIVE[0] = _ACTIVE[0], None
+                br.end()
+            raise
+        if role is not None and role[0] == "close" and _ACTIVE[0] is role[1]:    # the last node: what is still queued runs now
+            _ACTIVE[0] = None
+            role[1].end()
         if dxs is None:
             dx, _ = _nt(L.EPI_NONE, dy, ctx.sh[1], ctx.pair)
         else:
             dx, _ = _nt(L.EPI_RES, dy, ctx.sh[1], ctx.pair, None, R=dxs.contiguous())
-        return dx, dW, db, None, None
+        return dx, dW, db, None, None, None
 
 
 class _MlpFn(torch.autograd.Function):
@@ -148,14 +217,24 @@ class _MlpFn(torch.autograd.Function):
         du, _ = _nt(L.EPI_DGELU, dy, ctx.sh2[1], ctx.p2, None, R=gp)
         # both weight gradients in one launch (rgbnm.h: rgbnm_gemm_tn_group_*): half the split count, one reduction
         grouped = dy.dtype == torch.bfloat16
-        if grouped:
-            L.lib().rgbnm_gemm_tn_group_begin()
-        try:
-            t2 = _tn_issue(dy, g, True, ctx.p2, 0)
-            t1 = _tn_issue(du, x, True, ctx.p1, 1)
-        finally:
+        br = _ACTIVE[0]
+        if br is not None and br.active and grouped and not (ctx.p1 or ctx.p2):
+            # inside the backward-wide bracket (_DwBracket): both GEMMs join the queue of their stage
+            t2 = _tn_issue(dy, g, True, False, 0)
+            t1 = _tn_issue(du, x, True, False, 1)
+        else:
+            if br is not None and br.active:
+                br.pause()                     # row-paired (stage 1) or fp32: what is queued runs first
             if grouped:
-                L.check(L.lib().rgbnm_gemm_tn_group_end(L.stream()), "gemm_tn_group_end")
+                L.lib().rgbnm_gemm_tn_group_begin()
+            try:
+                t2 = _tn_issue(dy, g, True, ctx.p2, 0)
+                t1 = _tn_issue(du, x, True, ctx.p1, 1)
+            finally:
+                if grouped:
+                    L.check(L.lib().rgbnm_gemm_tn_group_end(L.stream()), "gemm_tn_group_end")
+                if br is not None and br.active:
+                    br.resume()
         (dW2, db2), (dW1, db1) = _tn_finish(t2), _tn_finish(t1)
         if dxs is None:
             dx, _ = _nt(L.EPI_NONE, du, ctx.sh1[1], ctx.p1)
@@ -485,6 +564,9 @@ class SwinTransformerV2(FlatParamModule):
                     nn.init.constant_(n.bias, 0)
                     nn.init.constant_(n.weight, 0)
         self.compute_dtype = None                   # None: follow autocast; or torch.float32 / torch.bfloat16
+        # one weight-gradient bracket around the backward pass (_DwBracket).  Default off, like ViT.defer_grad_reduction: the
+        # weight gradients then exist only when backward() has returned, which torch DDP's reducer hooks do not wait for
+        self.group_dw_backward = False
         self._conv = None
 
     @staticmethod
@@ -530,7 +612,17 @@ class SwinTransformerV2(FlatParamModule):
         if self._grad_sync is not None and torch.is_grad_enabled():
             self._grad_sync.begin_step()          # parallel.GatheredFlatGradSync: bucket counts start over
         pe = self.patch_embed
-        x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias, sh["patch_embed.projection.0"])
+        # the weight-gradient GEMMs of the whole backward in one bracket (_DwBracket): only when nobody reads a gradient before the
+        # pass is over, and when its first and last nodes will both run
+        br = None
+        if (self.group_dw_backward and torch.is_grad_enabled() and cdt == torch.bfloat16 and self._grad_sync is None
+                and self.head.weight.requires_grad and pe.projection[0].weight.requires_grad):
+            br = self.__dict__.setdefault("_dw_bracket", _DwBracket())
+            if br.active:                       # a backward pass that never reached the patch embedding
+                _ACTIVE[0] = None
+                br.end()
+        x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias, sh["patch_embed.projection.0"], False,
+                            None if br is None else ("close", br))
         x = _LNFn.apply(x, pe.norm.weight, pe.norm.bias, None, None, 1)
         drops = self._drop_scales(B, dev)
         k = 0
@@ -544,7 +636,7 @@ class SwinTransformerV2(FlatParamModule):
                 res //= 2
         x = _LNFn.apply(x, self.norm.weight, self.norm.bias, None, None, 1)
         x = _MeanFn.apply(x, B, res * res, self.num_features)
-        return _LinearFn.apply(x, self.head.weight, self.head.bias, sh["head"])
+        return _LinearFn.apply(x, self.head.weight, self.head.bias, sh["head"], False, None if br is None else ("open", br, [p for p in self.parameters() if p.requires_grad]))
 
     def _drop_scales(self, B, dev):
         """timm DropPath (per-sample Bernoulli(keep) / keep) for every residual branch of the model from ONE uniform draw:

@@ -362,3 +362,49 @@ def test_swin_step_is_bit_reproducible(golden, dt):
         assert torch.equal(runs[0][0], runs[k][0])
         bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[k][1][n])]
         assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [8, 64])
+def test_backward_wide_weight_gradient_bracket_equals_per_linear_launches(B):
+    """SwinTransformerV2.group_dw_backward (swinv2._DwBracket, VERDICT r4: weight-gradient GEMMs grouped across a stage's blocks):
+    with the whole backward in ONE rgbnm_gemm_tn_group bracket every gradient must equal the per-Linear launches' -- same products,
+    fp32 sums in another split of the token axis (rel 2e-5 of the tensor's scale; row-paired stage-1 layers and the fp32 CPB tables
+    run the old way: same bits) -- the logits the same bits.  A second backward onto ATTACHED gradients (accumulation) must fall
+    back to the old path and still be right; the bracket must be closed when backward() returns."""
+    from rgb_no_more_amd import swinv2 as SW
+    m, img, depths, heads, _ = _model("swt", DEV)
+    nb = img // 8
+    y = torch.from_numpy(detfill.normalish((B, 1, nb, nb, 8, 8), 271)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, nb // 2, nb // 2, 8, 8), 272)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 273, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    m.eval()                    # no DropPath draws: both passes see the same network
+    m.compute_dtype = torch.bfloat16
+
+    def run(flag, zero=True):
+        m.group_dw_backward = flag
+        if zero:
+            m.zero_grad(set_to_none=True)
+        logits = m(y, c)
+        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
+        torch.cuda.synchronize()
+        assert SW._ACTIVE[0] is None and not getattr(m, "_dw_bracket", SW._DwBracket()).active
+        return logits.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert torch.equal(l0, l1)
+    worst = ("", 0.0)
+    for n in g0:
+        scale = g0[n].abs().max().item() + 1e-30
+        d = (g0[n] - g1[n]).abs().max().item() / scale
+        if d > worst[1]:
+            worst = (n, d)
+    print(f"[dW bracket B={B}] worst gradient difference {worst[1]:.2e} of the tensor's scale ({worst[0]})")
+    assert worst[1] < 2e-5, worst
+    # accumulation onto attached gradients: the pass must not defer anything (AccumulateGrad adds as each node returns)
+    _, g2 = run(True, zero=False)
+    for n in g0:
+        scale = g0[n].abs().max().item() + 1e-30
+        assert (g2[n] - 2 * g1[n]).abs().max().item() / scale < 1e-4, n
