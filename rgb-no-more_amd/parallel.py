@@ -217,6 +217,7 @@ class GatheredFlatGradSync:
                 self._of[n] = b
         self._handles = []
         self.collectives = 0
+        self._cb_queued = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(n)) for n, p in module._named.items()]
         module._grad_sync = self
 
@@ -228,13 +229,25 @@ class GatheredFlatGradSync:
             if b["done"]:
                 raise RuntimeError("GatheredFlatGradSync: a second backward reached an exchanged bucket (gradient accumulation "
                                    "is not supported by the flat exchange; use torch DDP)")
+            if not self._cb_queued:
+                # gradients are final whenever backward() returns, also when a parameter got no gradient in this pass and its bucket
+                # never completed: the engine calls wait() at the end of the pass, as DDP's reducer finalises there.  All
+                # ranks must leave the same parameters unused (the buckets' collectives are issued in completion order).
+                self._cb_queued = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
             b["left"] -= 1
             if b["left"] == 0:
                 self._flush(b)
         return hook
 
+    def _end_of_backward(self):
+        self._cb_queued = False
+        if self.module._grad_sync is self:
+            self.wait()
+
     def begin_step(self):
         """At the start of a differentiated forward: nothing of an earlier backward may be in flight, counts start over."""
+        self._cb_queued = False
         for h, _ in self._handles:
             h.wait()
         self._handles.clear()

@@ -500,6 +500,7 @@ class _BlockFn(torch.autograd.Function):
         # the data path of EVERY block's backward as one launch (rgbnm.h rgbnm_vit_chain_bwd), issued by the first block node
         # that runs (the last block); each node then only launches its weight-gradient GEMMs and reductions
         if idx == m.depth - 1:
+            m._check_prep_gen(st)
             st.chain_bwd = m._chain_backward(a, dy)
             st.dw_pending = []
         try:
@@ -582,6 +583,7 @@ class _EncoderFn(torch.autograd.Function):
         dy = dy.contiguous()
         grads = [[m._gview(st.gbuf, n) for n in m._block_names[i]] for i in range(D)]
         gs = [L.BlockGrads(*[t.data_ptr() for t in grads[i]]) for i in range(D)]
+        m._check_prep_gen(st)
         try:
             if m._chain_backward(a, dy):
                 # weight gradients: all blocks in one grouped launch, or groups of dw_group_overlapped blocks while gradient slices
@@ -888,6 +890,7 @@ class ViT(FlatParamModule):
         if cdtype not in self._shadow:
             self._shadow[cdtype] = torch.zeros(self._sh_total, device=self._flat.device, dtype=cdtype)
         self._cur_dtype = cdtype
+        self._prep_gen = getattr(self, "_prep_gen", 0) + 1        # (the shadows and the chain images are model-global: see _check_prep_gen)
         L.check(L.lib().rgbnm_prep_weights(L.dt_of(cdtype), self._descs_dev.data_ptr(), self._ndesc,
                                            self._flat.data_ptr(), self._shadow[cdtype].data_ptr(),
                                            self._bias_perm.data_ptr(), L.stream()), "prep_weights")
@@ -924,6 +927,16 @@ class ViT(FlatParamModule):
         self._bparams, self._hparams = self._bparams_by_dtype[cdtype]
         if self._ncls_pad != self.n_classes:
             self._b2pad[:self.n_classes].copy_(self._named["classhead.ch_linear2.bias"].detach())
+
+    def _check_prep_gen(self, st):
+        """The operand shadows / chain images a backward reads are the ones of the LATEST forward (one set per model, rewritten by
+        every forward).  A forward between a training forward and its backward is harmless while the weights are the same, but
+        after an optimizer step (or swapped-in weights) that backward would run against the newer weights: say so."""
+        if getattr(st, "prep_gen", None) != getattr(self, "_prep_gen", None) and not getattr(self, "_warned_prep_gen", False):
+            self._warned_prep_gen = True
+            warnings.warn("rgb-no-more_amd: another forward of this model ran between a forward and its backward; the backward uses the "
+                          "weight operands of the LATEST forward (identical unless the parameters changed in between)", RuntimeWarning,
+                          stacklevel=3)
 
     def _warn_chain_refused(self, which):
         """The library refused the one-launch encoder kernel for a model that looks eligible from here (E = 192, 3 heads, bf16,
@@ -1035,6 +1048,7 @@ class ViT(FlatParamModule):
         self._prep(cdtype)
         arena = self._acquire_arena(B, cdtype, need_grad)
         st = _FwdState(self, arena, self._grad_buffer() if need_grad else None)
+        st.prep_gen = self._prep_gen
         st.ln_chain = bool(L.lib().rgbnm_vit_ln_chain(C.byref(arena.cfg)))
         named = self._named
         if self.embed_kind == "group":

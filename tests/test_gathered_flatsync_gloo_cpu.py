@@ -69,8 +69,9 @@ def _worker(rank, world, port):
             x = torch.randn(6, 7)
             before = sync.collectives
             m(x).square().mean().backward()
-            # the bucket holding `unused` cannot complete during the backward; everything else is exchanged and final
-            sync.wait()
+            # the bucket holding `unused` cannot complete during the backward: the end-of-backward callback flushes it, so the
+            # gradients are final when backward() returns -- no wait() needed (what GradScaler.unscale_ /
+            # clip_grad_norm_ between backward and step, train.py:159-166, rely on)
             assert sync.collectives - before == len(sync._buckets)
             assert not sync._handles
             assert m.flat_grad_base() == m._gflat.data_ptr()   # one flat buffer: the fused optimizer's zero-copy path
