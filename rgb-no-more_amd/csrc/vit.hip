@@ -398,9 +398,19 @@ int rgbnm_head_bwd(const rgbnm_vit_cfg* c, const rgbnm_head_params* p, const rgb
   char* w2 = apart ? w1 + s1 : w1;
   char* w3 = apart ? w2 + s2 : w1;
   const size_t b1 = apart ? s1 : ws_bytes, b2 = apart ? s2 : ws_bytes, b3 = apart ? ws_bytes - s1 - s2 : ws_bytes;
-  TRY(rgbnm_gemm_tn(dt, dlogits, C, a->h1, E, g->dw2, g->db2, B, C, E, 0, 0, w1, b1, st));
-  TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DTANH, dlogits, C, p->w2_t, C, da, E, 0, a->h1, E, 0, 0, 0, 0, B, E, C, 0, st));
-  TRY(rgbnm_gemm_tn(dt, da, E, a->pooled, E, g->dw1, g->db1, B, E, E, 0, 0, w2, b2, st));
+  // both weight-gradient GEMMs (same row count) as ONE grouped launch behind the dtanh product that makes the second one's operand
+  // -- when their partial sums have regions of their own (a shared region would be overwritten by the second job)
+  const bool grouped = apart && rgbnm_get_option("tn_group") != 0;
+  if (grouped) rgbnm_tn_defer_begin();
+  const int rc = [&]() -> int {
+    TRY(rgbnm_gemm_tn(dt, dlogits, C, a->h1, E, g->dw2, g->db2, B, C, E, 0, 0, w1, b1, st));
+    TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DTANH, dlogits, C, p->w2_t, C, da, E, 0, a->h1, E, 0, 0, 0, 0, B, E, C, 0, st));
+    TRY(rgbnm_gemm_tn(dt, da, E, a->pooled, E, g->dw1, g->db1, B, E, E, 0, 0, w2, b2, st));
+    return RGBNM_OK;
+  }();
+  const int rt = grouped ? rgbnm_tn_defer_flush((hipStream_t)st) : RGBNM_OK;
+  if (rc != RGBNM_OK) return rc;
+  if (rt != RGBNM_OK) return rt;
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, da, E, p->w1_t, E, dpooled, E, 0, 0, 0, 0, 0, 0, 0, B, E, E, 0, st));
   TRY(rgbnm_head_pool_bwd(dt, dpooled, a->x, p->ln_g, a->mean, a->rstd, dx, g->dln_g, g->dln_b, B, c->N, E, 0, w3, b3, st));
   return RGBNM_OK;

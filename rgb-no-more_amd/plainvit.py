@@ -133,6 +133,9 @@ def sincos_table(h, w, e, device="cpu"):
 
 
 # ------------------------------------------------------------------ per-forward state
+CHAIN_MAX_DEPTH = 12        # blocks per launch of the one-launch encoder kernels (vit_chain.hip MAX_DEPTH: the argument segment)
+
+
 class _Arena:
     """Activation / scratch buffers for one (B, dtype, grad) configuration with pre-built ctypes structs."""
 
@@ -520,7 +523,7 @@ class _BlockFn(torch.autograd.Function):
                     # THIS node returns, so its weight-gradient GEMMs must have been launched by then (deferring them to
                     # block 0's node handed DDP stale buffers)
                     group = 1
-                if len(st.dw_pending) >= group or idx == 0:
+                if len(st.dw_pending) >= min(group, CHAIN_MAX_DEPTH) or idx == 0:
                     pend, st.dw_pending = st.dw_pending, []
                     n = len(pend)
                     scs = [L.BlockScratch(a.du_blk[i].data_ptr(), a.dxn.data_ptr(), a.dxmid_blk[i].data_ptr(), a.dattn_chain.data_ptr(),
@@ -589,6 +592,7 @@ class _EncoderFn(torch.autograd.Function):
                 # weight gradients: all blocks in one grouped launch, or groups of dw_group_overlapped blocks while gradient slices
                 # are exchanged during the backward (a group's gradients are handed to the exchange as soon as it has run)
                 group = D if (m._grad_sync is None or st.holding) else m.dw_group_overlapped
+                group = min(group, CHAIN_MAX_DEPTH)            # (rgbnm_vit_blocks_bwd_dw takes at most twelve blocks per call)
                 idx = D - 1
                 while idx >= 0:
                     pend = list(range(idx, max(idx - group, -1), -1))
@@ -940,13 +944,13 @@ class ViT(FlatParamModule):
 
     def _warn_chain_refused(self, which):
         """The library refused the one-launch encoder kernel for a model that looks eligible from here (E = 192, 3 heads, bf16,
-        option on): depth > 12 or no usable GELU table.  The per-operation kernels run instead -- same results, about half the
+        option on): no usable GELU table.  The per-operation kernels run instead -- same results, about half the
         speed -- so say it once instead of silently."""
         key = "_warned_chain_" + which
         if not getattr(self, key, False):
             setattr(self, key, True)
-            warnings.warn(f"rgb-no-more_amd: the one-launch encoder {which} kernel refused this model (depth {self.depth} > 12 or no "
-                          f"GELU table); running the per-operation kernels (about 2x slower)", RuntimeWarning, stacklevel=3)
+            warnings.warn(f"rgb-no-more_amd: the one-launch encoder {which} kernel refused this model (no GELU "
+                          f"table); running the per-operation kernels (about 2x slower)", RuntimeWarning, stacklevel=3)
 
     def _chain_forward(self, a):
         """Run all encoder blocks as one launch into arena `a` (rgbnm_vit_chain_fwd); False = not eligible (per-block path)."""
@@ -962,11 +966,16 @@ class ViT(FlatParamModule):
                                          ac.xn1, ac.mean1, ac.rstd1, ac.qkv, ac.lse, ac.attn, ac.x_mid, ac.xn2, ac.mean2, ac.rstd2,
                                          ac.u, ac.gl, ac.x_out)
             a.chain_table = blocks        # host array: the library copies it into the kernel's argument segment
-        rc = L.lib().rgbnm_vit_chain_fwd(C.byref(a.cfg), a.chain_table, self.depth, a.xbuf(0).data_ptr(), L.stream())
-        if rc == 1:
-            self._warn_chain_refused("forward")
-            return False
-        L.check(rc, "vit_chain_fwd")
+        # the kernel carries at most twelve blocks in its argument segment: a deeper encoder runs as several launches, each handing the
+        # next one its residual stream through the x buffer of its last block
+        for s0 in range(0, self.depth, CHAIN_MAX_DEPTH):
+            n = min(CHAIN_MAX_DEPTH, self.depth - s0)
+            sub = C.cast(C.byref(a.chain_table, s0 * C.sizeof(L.ChainBlock)), C.POINTER(L.ChainBlock))
+            rc = L.lib().rgbnm_vit_chain_fwd(C.byref(a.cfg), sub, n, a.xbuf(s0).data_ptr(), L.stream())
+            if rc == 1 and s0 == 0:
+                self._warn_chain_refused("forward")
+                return False
+            L.check(rc, "vit_chain_fwd")
         return True
 
     def _chain_backward(self, a, dy):
@@ -999,11 +1008,15 @@ class ViT(FlatParamModule):
                     a.lnpart[i, 0].data_ptr(), a.lnpart[i, 1].data_ptr())
             a.chain_bwd_table = blocks
             a.chain_bwd_dy = dy.data_ptr()
-        rc = L.lib().rgbnm_vit_chain_bwd(C.byref(a.cfg), a.chain_bwd_table, D, a.dattn_chain.data_ptr(), L.stream())
-        if rc == 1:
-            self._warn_chain_refused("backward")
-            return False
-        L.check(rc, "vit_chain_bwd")
+        starts = list(range(0, D, CHAIN_MAX_DEPTH))
+        for s0 in reversed(starts):             # the last blocks first; a launch's first block (lowest index) leaves the next launch its dy
+            n = min(CHAIN_MAX_DEPTH, D - s0)
+            sub = C.cast(C.byref(a.chain_bwd_table, s0 * C.sizeof(L.ChainBwdBlock)), C.POINTER(L.ChainBwdBlock))
+            rc = L.lib().rgbnm_vit_chain_bwd(C.byref(a.cfg), sub, n, a.dattn_chain.data_ptr(), L.stream())
+            if rc == 1 and s0 == starts[-1]:
+                self._warn_chain_refused("backward")
+                return False
+            L.check(rc, "vit_chain_bwd")
         return True
 
     # ---------------------------------------------------------------- arenas
