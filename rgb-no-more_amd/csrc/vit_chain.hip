@@ -212,6 +212,15 @@ __device__ __forceinline__ void wg_barrier() {
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Between a wave's accesses to ITS OWN LDS tile (write the fragment layout, read row pieces back, overwrite with the next tile) no
+// wait is needed: the LDS executes one wave's DS instructions in order, and the compiler counts lgkmcnt for the registers that are
+// used.  What must not happen is the compiler reordering the accesses (differently typed pointers): a compiler-only fence.  The
+// drains that stood here cost two LDS round trips per stored tile (~50 tiles per block and wave).  -DX_LDSWAIT restores them.
+#ifdef X_LDSWAIT
+__device__ __forceinline__ void own_tile_fence() { wait_lds(); }
+#else
+__device__ __forceinline__ void own_tile_fence() { asm volatile("" ::: "memory"); }
+#endif
 
 // ---- DMA wave helpers: linear 1 KB pieces
 template <int NKB>
@@ -300,7 +309,7 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
     *reinterpret_cast<u32x4*>(smem + (wo ^ 64u)) = p2;
     *reinterpret_cast<u32x4*>(smem + (wo ^ 96u)) = p3;
   }
-  wait_lds();
+  own_tile_fence();
   const int rl = ln >> 3, seg = ln & 7;
   const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));      // row i * 8 + rl: (row & 7) == rl
   bf16* gp = dst + (size_t)rl * ld + seg * 8;
@@ -311,7 +320,7 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
     if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v;
 #endif
   }
-  wait_lds();
+  own_tile_fence();
 }
 __device__ __forceinline__ void rows_out(unsigned char* smem, unsigned stg, const Rows& x, bf16* dst, int live) {
 #pragma unroll
@@ -810,7 +819,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
               const u32x2 q2 = {src[2 * (rq & 1)], src[2 * (rq & 1) + 1]};
               *reinterpret_cast<u32x2*>(smem + (wo ^ (unsigned)((dt * 4 + rq) << 4))) = q2;
             }
-          wait_lds();
+          own_tile_fence();
           const int rl = ln >> 3, seg = ln & 7;
           const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));
           bf16* dst = b.attn + (grow0 + rl) * INNER + h * HD + seg * 8;
@@ -821,7 +830,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v;
 #endif
           }
-          wait_lds();
+          own_tile_fence();
         }
       }
     }
@@ -1064,8 +1073,10 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
       }
-      // the chunk's gelu / gelu' tiles out as whole 128-byte row pieces
-      wait_lds();
+      // the chunk's gelu / gelu' tiles out as whole 128-byte row pieces (handed tiles: written out before the barrier behind which
+      // the DMA wave takes them)
+      if (handed) wait_lds();
+      else own_tile_fence();
       if (!handed) {
         const int ln = lane_id_here();
 #pragma unroll
@@ -1082,7 +1093,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #endif
           }
         }
-        wait_lds();
+        own_tile_fence();
       }
     }
     BAR(28);                                      // step 27: the MLP stages are dead; the last tiles of waves 4-6 are being taken

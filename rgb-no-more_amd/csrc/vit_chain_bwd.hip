@@ -175,6 +175,15 @@ __device__ __forceinline__ void wg_barrier() {
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Between a wave's accesses to ITS OWN LDS tile (write the fragment layout, read row pieces back, overwrite with the next tile) no
+// wait is needed: the LDS executes one wave's DS instructions in order, and the compiler counts lgkmcnt for the registers that are
+// used.  What must not happen is the compiler reordering the accesses (differently typed pointers): a compiler-only fence.  The
+// drains that stood here cost two LDS round trips per stored tile (~50 tiles per block and wave).  -DX_LDSWAIT restores them.
+#ifdef X_LDSWAIT
+__device__ __forceinline__ void own_tile_fence() { wait_lds(); }
+#else
+__device__ __forceinline__ void own_tile_fence() { asm volatile("" ::: "memory"); }
+#endif
 __device__ __forceinline__ unsigned pack2(float a, float b) {
   const bf16x2v v = {(bf16)a, (bf16)b};
   unsigned r = __builtin_bit_cast(unsigned, v);
@@ -220,7 +229,7 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
   *reinterpret_cast<u32x4*>(smem + (wo ^ 32u)) = p1;
   *reinterpret_cast<u32x4*>(smem + (wo ^ 64u)) = p2;
   *reinterpret_cast<u32x4*>(smem + (wo ^ 96u)) = p3;
-  wait_lds();
+  own_tile_fence();
   const int rl = ln >> 3, seg = ln & 7;
   const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));
   bf16* gp = dst + (size_t)rl * ld + seg * 8;
@@ -229,7 +238,7 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
     const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
     if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v;
   }
-  wait_lds();
+  own_tile_fence();
 }
 
 // acc (32 output rows x 32 tokens, swapped) += chunk rows [32 ht .. +31] (384 B rows, pchunk swizzle) . x
@@ -670,7 +679,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
 #endif
         }
         // the chunk's du tile out as whole row pieces
-        wait_lds();
+        own_tile_fence();
         const int ln = lane_id_here();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -802,17 +811,17 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
           qraw[0] = *reinterpret_cast<const u32x4*>(qside + lane_id_here() * 16);        // (landed: vmcnt(0) above)
 #pragma unroll
           for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = qraw[i];
-          wait_lds();
+          own_tile_fence();
 #pragma unroll
           for (int c = 0; c < 4; ++c) qf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
-          wait_lds();
+          own_tile_fence();
 #pragma unroll
           for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = graw[i];
-          wait_lds();
+          own_tile_fence();
 #pragma unroll
           for (int c = 0; c < 4; ++c) gf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
           const float Dq = D_s[row];
-          wait_lds();
+          own_tile_fence();
           const float lq2 = lq * LOG2E;
           if (L.g == 0) L2_s[row] = lq2;
 #pragma unroll
