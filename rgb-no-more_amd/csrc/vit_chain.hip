@@ -313,13 +313,21 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
   const int rl = ln >> 3, seg = ln & 7;
   const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));      // row i * 8 + rl: (row & 7) == rl
   bf16* gp = dst + (size_t)rl * ld + seg * 8;
+  // all four row pieces are requested before the first store (one LDS round trip, not four), and a full tile -- six of the seven
+  // waves -- stores behind ONE uniform branch instead of four divergent ones
+  u32x4 v[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+  for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
 #ifndef X_NOSAVE      // (experiments only: the kernel without its global stores -- what the saved tensors cost)
-    if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v;
-#endif
+  if (live == 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
   }
+#endif
   own_tile_fence();
 }
 __device__ __forceinline__ void rows_out(unsigned char* smem, unsigned stg, const Rows& x, bf16* dst, int live) {
@@ -823,13 +831,19 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
           const int rl = ln >> 3, seg = ln & 7;
           const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));
           bf16* dst = b.attn + (grow0 + rl) * INNER + h * HD + seg * 8;
+          u32x4 v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+          for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
 #ifndef X_NOSAVE
-            if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v;
-#endif
+          if (live == 32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v[i];
           }
+#endif
           own_tile_fence();
         }
       }
@@ -1079,18 +1093,38 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
       else own_tile_fence();
       if (!handed) {
         const int ln = lane_id_here();
+        if (live == 32) {                 // (waves 0 - 3: always) all eight row pieces requested before the first store
+          bf16x8 v0[4], v1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
-          if (row < live) {
+          for (int i = 0; i < 4; ++i) {
+            const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
             const unsigned so = tg + (unsigned)(row * ROWB + ((vec ^ (row & 7)) << 4));
-            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(smem + so);
-            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(smem + so + tpoff);
-            const size_t go = (grow0 + row) * HID + chunk * 64 + vec * 8;
+            v0[i] = *reinterpret_cast<const bf16x8*>(smem + so);
+            v1[i] = *reinterpret_cast<const bf16x8*>(smem + so + tpoff);
+          }
 #ifndef X_NOSAVE
-            *reinterpret_cast<bf16x8*>(b.gl + go) = v0;
-            *reinterpret_cast<bf16x8*>(b.gp + go) = v1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+            const size_t go = (grow0 + row) * HID + chunk * 64 + vec * 8;
+            *reinterpret_cast<bf16x8*>(b.gl + go) = v0[i];
+            *reinterpret_cast<bf16x8*>(b.gp + go) = v1[i];
+          }
 #endif
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+            if (row < live) {
+              const unsigned so = tg + (unsigned)(row * ROWB + ((vec ^ (row & 7)) << 4));
+              const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(smem + so);
+              const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(smem + so + tpoff);
+              const size_t go = (grow0 + row) * HID + chunk * 64 + vec * 8;
+#ifndef X_NOSAVE
+              *reinterpret_cast<bf16x8*>(b.gl + go) = v0;
+              *reinterpret_cast<bf16x8*>(b.gp + go) = v1;
+#endif
+            }
           }
         }
         own_tile_fence();

@@ -233,10 +233,16 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
   const int rl = ln >> 3, seg = ln & 7;
   const unsigned ro = stg + (unsigned)(rl * ROWB + ((seg ^ rl) << 4));
   bf16* gp = dst + (size_t)rl * ld + seg * 8;
+  u32x4 v[4];                     // (all four row pieces requested before the first store; full tiles store behind one uniform branch)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
-    if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v;
+  for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
+  if (live == 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
   }
   own_tile_fence();
 }
@@ -681,11 +687,24 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
         // the chunk's du tile out as whole row pieces
         own_tile_fence();
         const int ln = lane_id_here();
+        bf16x8 dv0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
-          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(smem + stg + TILE + row * ROWB + ((vec ^ (row & 7)) << 4));
-          if (row < live) *reinterpret_cast<bf16x8*>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8) = v0;
+          dv0[i] = *reinterpret_cast<const bf16x8*>(smem + stg + TILE + row * ROWB + ((vec ^ (row & 7)) << 4));
+        }
+        if (live == 32) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+            *reinterpret_cast<bf16x8*>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8) = dv0[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
+            if (row < live) *reinterpret_cast<bf16x8*>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8) = dv0[i];
+          }
         }
       }
     }
