@@ -85,7 +85,7 @@ def test_gradient_norms_vs_reference_golden(golden):
     gn = np.array([np.linalg.norm(gc[n].astype(np.float64).ravel()) for n, _ in m.named_parameters()])
     rel = np.abs(gn - g["ti_d12_b256_gradnorms"]) / (g["ti_d12_b256_gradnorms"] + 1e-12)
     print(f"grad-norm rel err vs the reference: median {np.median(rel):.3e} max {rel.max():.3e}")
-    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+    assert np.median(rel) < 3e-3 and rel.max() < 6e-3         # (measured 1.1e-3 / 2.8e-3; the bars were 2e-2 / 0.15 until round 5)
 
 
 def test_bit_reproducible():

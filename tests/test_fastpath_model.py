@@ -10,7 +10,7 @@ itself on detfill weights, tests/golden/make_golden_r2.py) and, for full tensors
 
 Tolerances: fp32 mode <= 1e-3 on logits (north_star), gradient norms rtol 1e-3; bf16 mode <= 1e-2 on logits (measured
 4.4e-3 at B = 256 depth 12; torch's own bf16 autocast of the reference: 5.7e-3) and <= 2x the error of torch's own bf16
-autocast of the oracle, gradient norms median 2e-2 (see tests/test_vit_model.py).  Golden g20 (make_golden_r3.py) holds
+autocast of the oracle, gradient norms median 3e-3 / max 6e-3 (2x the worst measured; see GRADNORM_*_BAR).  Golden g20 (make_golden_r3.py) holds
 EVERY logit of the bench configuration (B = 256, depth 12) and of JPEG-S at depth 12.
 """
 import ctypes as C
@@ -41,7 +41,7 @@ DEV = "cuda"
 CASES = {"ti_d2_b64": (192, 3, 2, 64, False), "ti_d12_b64": (192, 3, 12, 64, False), "s_d2_b64": (384, 6, 2, 64, False),
          "ti_d12_b256": (192, 3, 12, 256, True), "s_d12_b64": (384, 6, 12, 64, False)}
 BF16_LOGIT_TOL = 1e-2        # bf16 operands, fp32 accumulate, vs the fp32 reference (bench.py's parity_check uses the same bar)
-GRADNORM_MEDIAN_BAR, GRADNORM_MAX_BAR = 2e-2, 0.15      # bf16 gradient norms vs the reference (tightened below where measured)
+GRADNORM_MEDIAN_BAR, GRADNORM_MAX_BAR = 3e-3, 6e-3      # bf16 gradient norms vs the reference: about 2x the worst measured (1.1e-3 / 2.8e-3; 2e-2 / 0.15 until round 5)
 FAST_OPTS = ("nt_wres", "nt_kpipe", "ln_fuse", "attn_persist", "tn_pipe", "mlp_fuse", "mlp_bwd")
 
 
@@ -116,7 +116,7 @@ def test_bf16_fast_path_vs_reference_golden(golden, tag):
           f"grad-norm rel err median {np.median(rel):.3e} max {rel.max():.3e}")
     assert err <= BF16_LOGIT_TOL
     assert abs(loss - float(g[tag + "_loss"])) < 5e-3
-    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+    assert np.median(rel) < GRADNORM_MEDIAN_BAR and rel.max() < GRADNORM_MAX_BAR
     named = dict(m.named_parameters())
     for nm in ("encoder.0.0.fn.eb_mha.qkv.weight", "encoder.1.1.fn.eb_ffb.0.weight", "patchembed.projection.0.weight"):
         got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
@@ -152,7 +152,7 @@ def test_every_logit_at_full_size_vs_reference_golden(golden, tag, compute):
     else:
         assert err <= BF16_LOGIT_TOL
         assert abs(loss - float(g[tag + "_loss"])) < 5e-3
-        assert np.median(rel) < 2e-2 and rel.max() < 0.15
+        assert np.median(rel) < GRADNORM_MEDIAN_BAR and rel.max() < GRADNORM_MAX_BAR
         for nm in slices:
             got = named[nm].grad.reshape(-1)[::37].double().cpu().numpy()
             want = g[tag + "_grad_" + nm].astype(np.float64)
@@ -390,7 +390,7 @@ def test_jpeg_s_at_the_timed_batch_256_vs_reference_golden(golden, compute):
         assert worst < 2e-3
     else:
         assert err <= BF16_LOGIT_TOL and abs(loss - float(g[tag + "_loss"])) < 5e-3
-        assert np.median(rel) < 2e-2 and rel.max() < 0.15
+        assert np.median(rel) < GRADNORM_MEDIAN_BAR and rel.max() < GRADNORM_MAX_BAR
         assert worst < 3e-2                      # per-tensor bf16 gradient bar
 
 
