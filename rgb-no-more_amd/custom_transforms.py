@@ -313,19 +313,29 @@ def _whole(Y):
 
 
 class Resize_DCT(torch.nn.Module):
-    """custom_transforms.py:468-525: resize the whole block grid to `size` (x2, identity or /2 on the HIP path)."""
+    """custom_transforms.py:468-525: resize the whole block grid to `size` (chroma: ceil(size / chroma_scale)).  Square grids of
+    size / 2, size or 2 x size blocks on the 28 / 32 pipelines -- everything datasets.get_transform composes -- run on the HIP
+    augment kernels; any other grid or size takes dct_ops.resize_dct (the reference's up-by-size/gcd, down-by-H/gcd, as device
+    tensor ops; golden g23)."""
 
     def __init__(self, size, chroma_scale=2, dtype_resize=torch.float32, strict_even_size=False):
         super().__init__()
         if strict_even_size:
             assert size % 2 == 0, f"ERROR: Resize_dct should have even numbered 'size' parameter. Current size: {size}"
+        if dtype_resize != torch.float32:
+            raise NotImplementedError("resize runs in fp32 (the reference's default dtype_resize)")
         self.size, self.chroma_scale = size, chroma_scale
 
     def forward(self, coeff):
         Y, C, single, batched = _unpack(coeff)
-        if Y.shape[2] != Y.shape[3]:
-            raise NotImplementedError("Resize_DCT on the HIP path resizes square block grids")
-        return _pack(*_run_chain(Y, C, self.size, [_whole(Y)] * Y.shape[0], None, None, 0, torch.int16), single, batched)
+        H, W = Y.shape[2], Y.shape[3]
+        on_kernels = (self.size in (28, 32) and H == W and H in (self.size // 2, self.size, 2 * self.size) and Y.dtype == torch.int16
+                      and (C is None or (C.dtype == torch.int16 and C.shape[2] * 2 == H and C.shape[3] * 2 == W and self.chroma_scale == 2)))
+        if on_kernels:
+            return _pack(*_run_chain(Y, C, self.size, [_whole(Y)] * Y.shape[0], None, None, 0, torch.int16), single, batched)
+        oy = dops.resize_dct(Y, self.size)
+        oc = None if C is None else dops.resize_dct(C, math.ceil(self.size / self.chroma_scale))
+        return _pack(oy, oc, single, batched)
 
 
 class RandomCrop_DCT(torch.nn.Module):

@@ -70,6 +70,25 @@ def test_g5_resize_within_one_lsb_exact_off_ties(golden):
             np.testing.assert_allclose(raw, raw64, atol=2e-3)
 
 
+def test_g23_general_resize_factors(golden):
+    """g23 (make_golden_r5_resize.py): utils/dct_ops.py:529-580 for grids that are not size / 2, size or 2 x size (20 -> 28 = x7 / 5,
+    36 -> 28 = x7 / 9, a non-square 24 x 20, chroma 10 x 12 -> 14, 6 -> 4) and Resize_DCT(28) on a (Y, CbCr) pair (chroma size
+    ceil(28 / 2), custom_transforms.py:505-507): the oracle's resize is the same up / down composition -- <= 1 LSB, exact off ties."""
+    g = golden("g23_resize_general.npz")
+    for nm in [str(s) for s in g["case_names"]]:
+        x, size = g[nm + "_in"], int(g[nm + "_size"])
+        out, ref, raw = O.resize(x, size), g[nm + "_f32"], g[nm + "_f64raw"].astype(np.float64)
+        assert out.dtype == np.int16 and out.shape == ref.shape
+        diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+        assert diff.max() <= 1
+        frac = np.abs(raw - np.floor(raw) - 0.5)
+        assert (diff[frac > 1e-3] == 0).all()
+        np.testing.assert_allclose(O.resize_raw(x, size), raw, atol=4e-3)
+    for inp, want, size in ((g["pair_Y"], g["pair_oY"], 28), (g["pair_C"], g["pair_oC"], 14)):
+        d = np.abs(O.resize(inp, size).astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
 def test_g6_photometric_and_dispatch(golden):
     g = golden("g6_photo.npz")
     Y, C = g["Y"], g["C"]

@@ -223,3 +223,35 @@ def test_get_transform_chain_equals_fused_transform_bitwise():
     # luma-only input (grayscale JPEG: CbCr is None in the reference) keeps its structure
     gy = rg.datasets.get_transform("imagenet_dct", "val")(dev(Y[0]))
     assert torch.is_tensor(gy) and gy.shape == (1, 28, 28, 8, 8) and torch.equal(gy, ey[0])
+
+
+@pytest.mark.gpu
+def test_resize_dct_general_factors_vs_reference_golden(golden):
+    """Resize_DCT for grids the HIP augment kernels do not cover (any factor: dct_ops.resize_dct, device tensor ops restating
+    utils/dct_ops.py:436-580) against the reference itself (golden g23: 20 -> 28, 36 -> 28, 24 x 20 -> 28, chroma 10 x 12 -> 14,
+    6 -> 4, and the class on a (Y, CbCr) pair): <= 1 LSB, exact off .5 ties; batched = per sample; the factors 1/2, 1, 2 of the
+    28-block pipeline still take the kernels (same results as the oracle, as test_resized_crop_classes_vs_oracle checks)."""
+    from rgb_no_more_amd import dct_ops as D
+    g = golden("g23_resize_general.npz")
+    for nm in [str(s) for s in g["case_names"]]:
+        x, size = torch.from_numpy(g[nm + "_in"]).to(DEV), int(g[nm + "_size"])
+        out = D.resize_dct(x, size)
+        assert out.dtype == torch.int16 and out.is_cuda
+        ref, raw = g[nm + "_f32"], g[nm + "_f64raw"].astype(np.float64)
+        diff = np.abs(out.cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+        assert diff.max() <= 1, nm
+        frac = np.abs(raw - np.floor(raw) - 0.5)
+        assert (diff[frac > 1e-3] == 0).all(), nm
+        both = D.resize_dct(torch.stack([x, x.flip(1)]), size)
+        assert torch.equal(both[0], out)
+    Y, C = torch.from_numpy(g["pair_Y"]).to(DEV), torch.from_numpy(g["pair_C"]).to(DEV)
+    oy, oc = CT.Resize_DCT(28)((Y, C))                           # 20 x 20 / 10 x 10: not a kernel case
+    for got, want in ((oy, g["pair_oY"]), (oc, g["pair_oC"])):
+        d = np.abs(got.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+        assert got.shape == want.shape and d.max() <= 1 and (d > 0).mean() < 1e-3
+    # a kernel case goes on taking the kernels and agrees with the general path to the rounding of ties
+    Y56 = torch.from_numpy(detfill.integers((2, 1, 56, 56, 8, 8), 91, -1024, 1016)).to(DEV)
+    C28 = torch.from_numpy(detfill.integers((2, 2, 28, 28, 8, 8), 92, -1024, 1016)).to(DEV)
+    ky, kc = CT.Resize_DCT(28)((Y56, C28))
+    gy = D.resize_dct(Y56, 28)
+    assert ky.shape == gy.shape and (ky.int() - gy.int()).abs().max().item() <= 1
