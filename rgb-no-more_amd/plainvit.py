@@ -710,8 +710,11 @@ class ViT(FlatParamModule):
                                       "_Separate_subblock) or 3 (PatchEmbedding_DCT_Concat)")
         if ver in (1, 3) and not use_subblock:
             raise NotImplementedError("embed_type 1 / 3 without sub-block conversion are not in any reference config")
-        if drop_p not in (0, 0.0):
-            raise NotImplementedError("dropout p must be 0 (cfg.TRAIN.DROP default, configs.py:27)")
+        # nn.Dropout(drop_p) of plainvit.py:489, 515, 525 is the identity in eval mode: a model built with the constructor's default
+        # (0.1) evaluates fine; TRAINING with p > 0 (no reference config: cfg.TRAIN.DROP = 0, configs.py:27) is refused at forward()
+        if not 0.0 <= float(drop_p) < 1.0:
+            raise ValueError("dropout probability has to be in [0, 1)")
+        self.drop_p = float(drop_p)
         if head_size != 64 or emb_size not in (192, 384, 512, 768, 1024) or input_embed >= 0:
             raise NotImplementedError("HIP kernels cover head_size 64 and emb_size 192 / 384 (JPEG-Ti / JPEG-S; tuned) and "
                                       "512 / 768 / 1024 (vitb / vitl of utils/configs.py:104-122; generic kernels)")
@@ -1053,6 +1056,9 @@ class ViT(FlatParamModule):
             cdtype = torch.bfloat16
         if cdtype not in (torch.float32, torch.bfloat16):
             raise NotImplementedError(f"compute dtype {cdtype}: the MI355X path implements fp32 and bf16")
+        if self.drop_p and self.training:
+            raise NotImplementedError("training with dropout p > 0 is not implemented on the HIP path (cfg.TRAIN.DROP is 0 in every "
+                                      "reference config, configs.py:27); model.eval() runs, where nn.Dropout is the identity")
         self._ensure_flat()
         B = x.shape[0]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._named.values())

@@ -102,6 +102,27 @@ def test_eval_no_grad_matches_train_forward():
     assert torch.equal(a, b)
 
 
+def test_dropout_probability_is_an_eval_time_identity_and_a_loud_refusal_in_training():
+    """plainvit.py:489, 515, 525: nn.Dropout(drop_p).  A model built with the constructor's default drop_p = 0.1 evaluates like
+    drop_p = 0 (dropout is the identity in eval mode); a TRAINING forward with p > 0 raises instead of silently not dropping."""
+    kw = dict(depth=2, n_classes=10, device=DEV, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
+    torch.manual_seed(3)
+    m0 = rg.ViT(3, 16, 192, drop_p=0.0, **kw)
+    m1 = rg.ViT(3, 16, 192, **kw)                          # drop_p = 0.1, the reference's default
+    m1.load_state_dict(m0.state_dict())
+    y = torch.from_numpy(detfill.normalish((2, 1, 28, 28, 8, 8), 5)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((2, 2, 14, 14, 8, 8), 6)).to(DEV)
+    m0.eval()
+    m1.eval()
+    with torch.no_grad():
+        assert torch.equal(m0(y, c), m1(y, c))
+    m1.train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        m1(y, c)
+    with pytest.raises(ValueError):
+        rg.ViT(3, 16, 192, drop_p=1.0, **kw)
+
+
 def test_training_steps_track_oracle_fp32():
     """3 optimizer steps (clip + AdamW + WeightDecay, train.py:153-176) in fp32: loss curve and weights follow
     the oracle (torch autograd + oracle optimizer restatement)."""
