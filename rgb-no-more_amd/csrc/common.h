@@ -159,6 +159,19 @@ __device__ __forceinline__ float dgelu_fast(float x) {
   return c + p;
 }
 
+// gelu'(u), the second output of the fc1 + GELU epilogues: nobody reads it before the backward pass -- a non-temporal store keeps
+// it from pushing the rows the NEXT launch reads (gelu(u)) out of L2.  -DNT_C2=0: plain store (experiments).
+#ifndef NT_C2
+#define NT_C2 1
+#endif
+__device__ __forceinline__ void store_c2(bf16* ptr, const bf16x8& v) {
+#if NT_C2
+  __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(ptr));
+#else
+  *reinterpret_cast<bf16x8*>(ptr) = v;
+#endif
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

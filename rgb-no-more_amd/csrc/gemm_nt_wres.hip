@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_wres_kernel(WresArgs p) {
             cv[e] = (bf16)gv[0];
             cv[e + 1] = (bf16)gv[1];
           }
-          *reinterpret_cast<bf16x8*>(c2base + c2_lane[i % 3] + (i / 3) * 16 * p.ldc2) = dv;
+          store_c2(c2base + c2_lane[i % 3] + (i / 3) * 16 * p.ldc2, dv);
         }
         if (HASR) {
 #pragma unroll

@@ -15,6 +15,12 @@
 #include "internal.h"
 #include "../../include/rgbnm.h"
 
+// Operand streams: TN_NT bit 0 = the dY slices (read by ONE workgroup, once) non-temporal (aux = 2 of global_load_lds), bit 1 = the
+// X tiles (shared by the tiles of a GEMM through their XCD's L2)
+#ifndef TN_NT
+#define TN_NT 0
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -152,10 +158,10 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
     unsigned char* st = smem + stage * STAGE + w * 1024;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(gA + offA[j]), (lds_ptr)(st + j * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gA + offA[j]), (lds_ptr)(st + j * 8192), 16, 0, (TN_NT & 1) ? 2 : 0);
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(gB + offB[j]), (lds_ptr)(st + A_STAGE + j * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gB + offB[j]), (lds_ptr)(st + A_STAGE + j * 8192), 16, 0, (TN_NT & 2) ? 2 : 0);
     gA += stepA;
     gB += stepB;
   };

@@ -212,6 +212,26 @@ __device__ __forceinline__ void wg_barrier() {
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Global stores of the saved tensors: NON-TEMPORAL (`global_store_dwordx4 ... nt`).  Nobody reads them for a millisecond (the
+// backward), so they should not push the weight images and the next phases' lines out of L2: -3 % on this launch and -1.3 % on
+// the backward launch behind it (interleaved A/B; the same hint did nothing for the per-operation kernels of
+// round 2, whose outputs the next launch reads at once).  -DX_STORE=0 plain, =2 write-through (sc1), =3 sc0 sc1 (experiments).
+#ifndef X_STORE
+#define X_STORE 1
+#endif
+template <typename V, typename P>
+__device__ __forceinline__ void gstore(P* ptr, const V& v) {
+#if X_STORE == 1
+  __builtin_nontemporal_store(v, reinterpret_cast<V*>(ptr));
+#elif X_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(reinterpret_cast<V*>(ptr)), "v"(v) : "memory");   // (store-data hazard: the compiler cannot see this store)
+#elif X_STORE == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(reinterpret_cast<V*>(ptr)), "v"(v) : "memory");
+#else
+  *reinterpret_cast<V*>(ptr) = v;
+#endif
+}
+
 // Between a wave's accesses to ITS OWN LDS tile (write the fragment layout, read row pieces back, overwrite with the next tile) no
 // wait is needed: the LDS executes one wave's DS instructions in order, and the compiler counts lgkmcnt for the registers that are
 // used.  What must not happen is the compiler reordering the accesses (differently typed pointers): a compiler-only fence.  The
@@ -278,6 +298,11 @@ __device__ __forceinline__ void ln_stats(const Rows& x, float& mu, float& rs, fl
 }
 // y = (x - mu) * rs * gamma + beta, gamma | beta = 2 x 192 floats in LDS
 __device__ __forceinline__ void ln_apply(const Rows& x, float mu, float rs, const float* gb, int g, Rows& y) {
+#ifdef X_NOLN        // (experiments only, wrong numbers: what the five LayerNorm applications per block cost -- y = x)
+#pragma unroll
+  for (int c = 0; c < 12; ++c) y.v[c] = x.v[c];
+  return;
+#endif
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
     const float* gp = gb + 16 * c + 8 * g;
@@ -321,11 +346,11 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
 #ifndef X_NOSAVE      // (experiments only: the kernel without its global stores -- what the saved tensors cost)
   if (live == 32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
+    for (int i = 0; i < 4; ++i) gstore(gp + (size_t)i * 8 * ld, v[i]);
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
+      if (i * 8 + rl < live) gstore(gp + (size_t)i * 8 * ld, v[i]);
   }
 #endif
   own_tile_fence();
@@ -519,8 +544,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             if (row < lr) {
               const size_t go = ((size_t)img * NTOK + 32 * (4 + q) + row) * HID + chunk * 64 + tvec * 8;
 #ifndef X_NOSAVE
-              *reinterpret_cast<u32x4*>(b.gl + go) = tv[q][0][i];
-              *reinterpret_cast<u32x4*>(b.gp + go) = tv[q][1][i];
+              gstore(b.gl + go, tv[q][0][i]);
+              gstore(b.gp + go, tv[q][1][i]);
 #endif
             }
           }
@@ -780,7 +805,11 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             float pr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#ifdef X_NOEXP      // (experiments only, wrong numbers: what the exponentials cost)
+              pr[r] = fmaf(acc[r], c2, -mc2);
+#else
               pr[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mc2));
+#endif
               if (t * 32 + 32 > NTOK && t * 32 + acc_row(r, L.lane) >= NTOK) pr[r] = 0.f;
               sum += pr[r];
             }
@@ -837,11 +866,11 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
 #ifndef X_NOSAVE
           if (live == 32) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v[i];
+            for (int i = 0; i < 4; ++i) gstore(dst + (size_t)i * 8 * INNER, v[i]);
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8 * INNER) = v[i];
+              if (i * 8 + rl < live) gstore(dst + (size_t)i * 8 * INNER, v[i]);
           }
 #endif
           own_tile_fence();
@@ -1016,6 +1045,10 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             const f32x2 uu = f32x2{a1[8 * hs + j], a1[8 * hs + j + 1]} + (j < 4 ? f32x2{bl[j], bl[j + 1]} : f32x2{bh[j - 4], bh[j - 3]});
             const bf16x2v pbv = {(bf16)uu[0], (bf16)uu[1]};
             pb[jj] = __builtin_bit_cast(unsigned, pbv);
+#ifdef X_NOGELU      // (experiments only, wrong numbers: what the table GELU's index arithmetic and lookups cost -- gelu = gelu' = u)
+            agv[jj] = alo[jj] = ahi[jj] = 0;
+            continue;
+#endif
             unsigned p1, p2, ak, i4, sg;
             asm("v_pk_min_u16 %0, %1, %2" : "=v"(p1) : "v"(pb[jj]), "s"(kneg));
             asm("v_pk_min_i16 %0, %1, %2" : "=v"(p2) : "v"(p1), "s"(kpos));
@@ -1029,6 +1062,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
             alo[jj] = i4 & 0xffffu;
             ahi[jj] = i4 >> 16;
           }
+#ifndef X_NOGELU
           asm volatile(
               "ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
               "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\t"
@@ -1036,14 +1070,19 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
               : "=&v"(e0[0]), "=&v"(e1[0]), "=&v"(e0[1]), "=&v"(e1[1]), "=&v"(e0[2]), "=&v"(e1[2]), "=&v"(e0[3]), "=&v"(e1[3])
               : "v"(alo[0]), "v"(ahi[0]), "v"(alo[1]), "v"(ahi[1]), "v"(alo[2]), "v"(ahi[2]), "v"(alo[3]), "v"(ahi[3])
               : "memory");
+#endif
           u32x4 gq, dq;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
+#ifdef X_NOGELU
+            gq[jj] = dq[jj] = pb[jj];
+#else
             const unsigned dpair = __builtin_amdgcn_perm(e1[jj], e0[jj], 0x05040100u);
             unsigned gm;
             asm("v_pk_sub_u16 %0, %1, %2" : "=v"(gm) : "v"(agv[jj]), "v"(dpair));
             gq[jj] = (pb[jj] & 0x80008000u) | gm;
             dq[jj] = __builtin_amdgcn_perm(e1[jj], e0[jj], 0x07060302u);
+#endif
           }
           gv = __builtin_bit_cast(bf16x8, gq);
           dv = __builtin_bit_cast(bf16x8, dq);
@@ -1107,8 +1146,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
           for (int i = 0; i < 4; ++i) {
             const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
             const size_t go = (grow0 + row) * HID + chunk * 64 + vec * 8;
-            *reinterpret_cast<bf16x8*>(b.gl + go) = v0[i];
-            *reinterpret_cast<bf16x8*>(b.gp + go) = v1[i];
+            gstore(b.gl + go, v0[i]);
+            gstore(b.gp + go, v1[i]);
           }
 #endif
         } else {
@@ -1121,8 +1160,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_fwd_kernel(ChainArgs p) {
               const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(smem + so + tpoff);
               const size_t go = (grow0 + row) * HID + chunk * 64 + vec * 8;
 #ifndef X_NOSAVE
-              *reinterpret_cast<bf16x8*>(b.gl + go) = v0;
-              *reinterpret_cast<bf16x8*>(b.gp + go) = v1;
+              gstore(b.gl + go, v0);
+              gstore(b.gp + go, v1);
 #endif
             }
           }

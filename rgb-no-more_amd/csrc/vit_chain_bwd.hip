@@ -175,6 +175,21 @@ __device__ __forceinline__ void wg_barrier() {
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Global stores: XB_NT bit 0 = du (read again only by the weight-gradient launch) non-temporal, bit 1 = the gradient tiles the DMA
+// wave writes (d(q, k, v): read back by phase X of the same workgroup), bit 2 = d(attention output) tiles (read back by phase A)
+#ifndef XB_NT
+#define XB_NT 1
+#endif
+// Loads: XB_NTLD bit 0 = the gelu' rows of phase M (read once) non-temporal, bit 1 = the K / V / Q / dO arrays of phase A (LDS-DMA aux = 2)
+#ifndef XB_NTLD
+#define XB_NTLD 0
+#endif
+template <bool NT, typename V, typename P>
+__device__ __forceinline__ void gstore(P* ptr, const V& v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(ptr));
+  else *reinterpret_cast<V*>(ptr) = v;
+}
+
 // Between a wave's accesses to ITS OWN LDS tile (write the fragment layout, read row pieces back, overwrite with the next tile) no
 // wait is needed: the LDS executes one wave's DS instructions in order, and the compiler counts lgkmcnt for the registers that are
 // used.  What must not happen is the compiler reordering the accesses (differently typed pointers): a compiler-only fence.  The
@@ -206,7 +221,7 @@ __device__ __forceinline__ void dma_matrix_all(const bf16* __restrict__ src, int
     const int row = 8 * i + (lane >> 3), pc = lane & 7;
     const int lc = pc ^ fswz(row);
     const int srow = row < NTOK ? row : NTOK - 1;
-    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)srow * ld + lc * 8), (lds_ptr)(dst + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)srow * ld + lc * 8), (lds_ptr)(dst + i * 1024), 16, 0, (XB_NTLD & 2) ? 2 : 0);
   }
 }
 // the seven waves' own 32 x 64 pieces of a [N][ld] matrix (columns c0 .. c0 + 63) -> row tiles, chunk q of row r at q ^ (r & 7)
@@ -238,11 +253,11 @@ __device__ __forceinline__ void tile_out(unsigned char* smem, unsigned stg, cons
   for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + ro + i * 8 * ROWB);
   if (live == 32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
+    for (int i = 0; i < 4; ++i) gstore<(XB_NT & 4) != 0>(gp + (size_t)i * 8 * ld, v[i]);
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i * 8 + rl < live) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ld) = v[i];
+      if (i * 8 + rl < live) gstore<(XB_NT & 4) != 0>(gp + (size_t)i * 8 * ld, v[i]);
   }
   own_tile_fence();
 }
@@ -345,7 +360,7 @@ __device__ __forceinline__ void tiles_write(const u32x4 (&v)[NTILE][4], bf16* __
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = wv * 32 + i * 8 + rl;
-      if (row < NTOK) *reinterpret_cast<u32x4*>(g0 + (size_t)row * ld + seg * 8) = v[wv][i];
+      if (row < NTOK) gstore<(XB_NT & 2) != 0>(g0 + (size_t)row * ld + seg * 8, v[wv][i]);
     }
 }
 
@@ -580,7 +595,8 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
           const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
           int rr = row0 + row;
           rr = rr < NTOK ? rr : NTOK - 1;
-          gpraw[i] = *reinterpret_cast<const bf16x8*>(b.gp + ((size_t)img * NTOK + rr) * HID + chunk * CH + vec * 8);
+          const bf16x8* gsrc = reinterpret_cast<const bf16x8*>(b.gp + ((size_t)img * NTOK + rr) * HID + chunk * CH + vec * 8);
+          gpraw[i] = (XB_NTLD & 1) ? __builtin_nontemporal_load(gsrc) : *gsrc;
         }
       };
       load_gp(0);
@@ -697,13 +713,13 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
-            *reinterpret_cast<bf16x8*>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8) = dv0[i];
+            gstore<(XB_NT & 1) != 0>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8, dv0[i]);
           }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int idx = ln + 64 * i, row = idx >> 3, vec = idx & 7;
-            if (row < live) *reinterpret_cast<bf16x8*>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8) = dv0[i];
+            if (row < live) gstore<(XB_NT & 1) != 0>(b.du + (grow0 + row) * HID + chunk * CH + vec * 8, dv0[i]);
           }
         }
       }

@@ -8,11 +8,11 @@ OUT=gpurun_out/chain_variants; mkdir -p $OUT; rm -f $OUT/times.txt
 LIB=rgb-no-more_amd/librgbnm.so
 build() {   # build <index> <flags>
   local V="$2" only=both
-  case "$V" in fwd:*) only=fwd; V="${V#fwd:}";; bwd:*) only=bwd; V="${V#bwd:}";; esac
-  touch rgb-no-more_amd/csrc/vit_chain.hip rgb-no-more_amd/csrc/vit_chain_bwd.hip
+  case "$V" in fwd:*) only=fwd; V="${V#fwd:}";; bwd:*) only=bwd; V="${V#bwd:}";; tn:*) only=tn; V="${V#tn:}";; esac      # tn: = gemm_tn_pipe.hip
+  touch rgb-no-more_amd/csrc/vit_chain.hip rgb-no-more_amd/csrc/vit_chain_bwd.hip rgb-no-more_amd/csrc/gemm_tn_pipe.hip
   if [ $only != both ]; then
     python rgb-no-more_amd/build.py > $OUT/build.log 2>&1
-    [ $only = fwd ] && touch rgb-no-more_amd/csrc/vit_chain.hip || touch rgb-no-more_amd/csrc/vit_chain_bwd.hip
+    case $only in fwd) touch rgb-no-more_amd/csrc/vit_chain.hip;; bwd) touch rgb-no-more_amd/csrc/vit_chain_bwd.hip;; tn) touch rgb-no-more_amd/csrc/gemm_tn_pipe.hip;; esac
   fi
   if [ "$V" = base ]; then python rgb-no-more_amd/build.py > $OUT/build.log 2>&1; else RGBNM_HIPCC_FLAGS="$V" python rgb-no-more_amd/build.py > $OUT/build.log 2>&1; fi
   if [ $? -ne 0 ]; then echo "$2: BUILD FAILED"; grep -m3 error $OUT/build.log; return 1; fi
@@ -29,8 +29,9 @@ for r in $(seq 1 ${ROUNDS:-3}); do
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 g = {re.search(r"vit_chain_\w+_kernel", r["Name"]).group(0): float(r["AverageNs"]) / 1e3 for r in rows if "vit_chain" in r["Name"]}
+tn = sum(float(r["TotalDurationNs"]) for r in rows if "gemm_tn_pipe" in r["Name"])
 tot = sum(float(r["TotalDurationNs"]) for r in rows); steps = [int(r["Calls"]) for r in rows if "vit_chain_fwd" in r["Name"]][0]
-print(sys.argv[2], g.get("vit_chain_fwd_kernel", 0), g.get("vit_chain_bwd_kernel", 0), tot / steps / 1e3)
+print(sys.argv[2], g.get("vit_chain_fwd_kernel", 0), g.get("vit_chain_bwd_kernel", 0), tot / steps / 1e3, tn / steps / 1e3)
 PY
     rm -rf $OUT/kt
   done
@@ -41,13 +42,13 @@ import sys
 names = sys.argv[2:]
 acc = {}
 for ln in open(sys.argv[1]):
-    i, f, b, t = ln.split()
-    acc.setdefault(int(i), []).append((float(f), float(b), float(t)))
+    i, f, b, t, n = ln.split()
+    acc.setdefault(int(i), []).append((float(f), float(b), float(t), float(n)))
 for i, n in enumerate(names):
     v = acc.get(i, [])
     if not v:
         continue
-    m = [sum(x[k] for x in v) / len(v) for k in range(3)]
-    sp = [max(x[k] for x in v) - min(x[k] for x in v) for k in range(3)]
-    print(f"{n:46s} fwd {m[0]:8.1f} (+-{sp[0] / 2:4.1f}) us  bwd {m[1]:8.1f} (+-{sp[1] / 2:4.1f}) us  kernel sum / step {m[2]:8.1f} us   [{len(v)} runs]")
+    m = [sum(x[k] for x in v) / len(v) for k in range(4)]
+    sp = [max(x[k] for x in v) - min(x[k] for x in v) for k in range(4)]
+    print(f"{n:40s} fwd {m[0]:7.1f} (+-{sp[0] / 2:4.1f})  bwd {m[1]:7.1f} (+-{sp[1] / 2:4.1f})  dW {m[3]:6.1f} (+-{sp[3] / 2:4.1f})  kernel sum / step {m[2]:7.1f} us  [{len(v)} runs]")
 PY
