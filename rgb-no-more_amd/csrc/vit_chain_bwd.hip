@@ -186,6 +186,10 @@ __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)"
 #endif
 template <bool NT, typename V, typename P>
 __device__ __forceinline__ void gstore(P* ptr, const V& v) {
+#ifdef XB_NOSTORE     // (experiments only, wrong gradients downstream: the kernel without the stores this helper issues)
+  if ((XB_NOSTORE & 1) && NT) return;          // bit 0: du (the only non-temporal stream)
+  if ((XB_NOSTORE & 2) && !NT) return;         // bit 1: the d(q, k, v) / d(attention output) tiles
+#endif
   if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(ptr));
   else *reinterpret_cast<V*>(ptr) = v;
 }
