@@ -83,6 +83,10 @@ int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, 
 // returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st) {
+  if (rgbnm_get_option("nt_kstream")) {
+    const int rc = rgbnm_launch_nt_kstream(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
+    if (rc != 1) return rc;
+  }
   if (use_kp8(M, N, epi)) return kp8::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
   return use_split(N) ? kp4::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st)
                       : kp7::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);

@@ -96,6 +96,45 @@ __device__ __forceinline__ void tr_chunk(unsigned aA, unsigned aB0, unsigned aB1
   fb[2].v = pack8(b2l, b2h);
 }
 
+// the same eight reads through the builtin (no wait inside: the compiler counts lgkmcnt), for the software-pipelined loop
+typedef bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4v* lds_b64_ptr;
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* smem, unsigned off) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_ptr)(smem + off)));
+}
+template <int C>
+__device__ __forceinline__ void tr_chunk_b(const unsigned char* sp, unsigned oA, unsigned oB0, unsigned oB1, unsigned oB2,
+                                           Frag<bf16>& fa, Frag<bf16> (&fb)[3]) {
+  fa.v = pack8(tr_read(sp, oA + C * 16 * A_ROW), tr_read(sp, oA + C * 16 * A_ROW + 4 * A_ROW));
+  fb[0].v = pack8(tr_read(sp, oB0 + C * 16 * B_ROW), tr_read(sp, oB0 + C * 16 * B_ROW + 4 * B_ROW));
+  fb[1].v = pack8(tr_read(sp, oB1 + C * 16 * B_ROW), tr_read(sp, oB1 + C * 16 * B_ROW + 4 * B_ROW));
+  fb[2].v = pack8(tr_read(sp, oB2 + C * 16 * B_ROW), tr_read(sp, oB2 + C * 16 * B_ROW + 4 * B_ROW));
+}
+
+#ifndef TN_FPIPE
+#define TN_FPIPE 1
+#endif
+// ... and as one asm block WITHOUT the wait (TN_FPIPE == 2): the compiler drains vmcnt before a builtin LDS read that follows
+// LDS-DMA (it cannot tell the ring stages apart), which empties the DMA pipeline; asm reads are invisible to that rule, so the waits
+// (lgkmcnt counted by hand: LDS returns in order) are written out next to them
+template <int C>
+__device__ __forceinline__ void tr_chunk_nw(unsigned aA, unsigned aB0, unsigned aB1, unsigned aB2, u32x2 (&r)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %9 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:%15\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:%15\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:%14\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%15"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(aA), "v"(aB0), "v"(aB1), "v"(aB2), "i"(C * 16 * A_ROW), "i"(C * 16 * A_ROW + 4 * A_ROW),
+        "i"(C * 16 * B_ROW), "i"(C * 16 * B_ROW + 4 * B_ROW)
+      : "memory");
+}
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
 __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // 256 workgroups, block b runs on XCD b % 8: unit u = (b % 8) * 32 + b / 8 keeps consecutive units -- the tiles of one
@@ -193,29 +232,91 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
       issue(i);
       st_issue = i + 1 == NSTAGE ? 0 : i + 1;
     }
-  for (int t = 0; t < T; ++t) {
-    // tile t landed; NSTAGE - 2 younger tiles (5 DMA instructions each) may stay in flight
-    if (NSTAGE >= 4 && t + 2 < T) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();     // tile t landed for every wave; every wave is done with tile t-1
-    if (t + NSTAGE - 1 < T) {
-      issue(st_issue);
-      st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
-    }
-    const unsigned sb = lds0 + st_comp * STAGE;
-    st_comp = st_comp == NSTAGE - 1 ? 0 : st_comp + 1;
-    const unsigned aA = sb + oA, aB0 = sb + oB0, aB1 = sb + oB1, aB2 = sb + oB2;
-    Frag<bf16> fa, fb[3];
-#define CHUNK(C)                                   \
-    tr_chunk<C>(aA, aB0, aB1, aB2, fa, fb);        \
-    mma(acc[0], fa, fb[0]);                        \
-    mma(acc[1], fa, fb[1]);                        \
-    mma(acc[2], fa, fb[2]);                        \
-    if (do_bias) mma(accb, fa, ones);
-    CHUNK(0) CHUNK(1) CHUNK(2) CHUNK(3)
+  // two copies of the tile loop, with and without the bias MFMA: a branch inside the chunk sequence would end the scheduling region
+  // the fragment pipeline lives in
+  auto tiles = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
+    for (int t = 0; t < T; ++t) {
+      // tile t landed; NSTAGE - 2 younger tiles (5 DMA instructions each) may stay in flight
+      if (NSTAGE >= 4 && t + 2 < T) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();     // tile t landed for every wave; every wave is done with tile t-1
+      if (t + NSTAGE - 1 < T) {
+        issue(st_issue);
+        st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
+      }
+  #if TN_FPIPE == 2
+      const unsigned sb = lds0 + st_comp * STAGE;
+      st_comp = st_comp == NSTAGE - 1 ? 0 : st_comp + 1;
+      const unsigned aA = sb + oA, aB0 = sb + oB0, aB1 = sb + oB1, aB2 = sb + oB2;
+      u32x2 r[2][8];
+      tr_chunk_nw<0>(aA, aB0, aB1, aB2, r[0]);
+#define CHUNK(C)                                                                     \
+      if (C < 3) {                                                                   \
+        tr_chunk_nw<C + 1>(aA, aB0, aB1, aB2, r[(C + 1) & 1]);                       \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                           \
+      } else {                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+      }                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                             \
+      {                                                                              \
+        Frag<bf16> fa, fb0, fb1, fb2;                                                \
+        fa.v = pack8(r[C & 1][0], r[C & 1][1]);                                      \
+        fb0.v = pack8(r[C & 1][2], r[C & 1][3]);                                     \
+        fb1.v = pack8(r[C & 1][4], r[C & 1][5]);                                     \
+        fb2.v = pack8(r[C & 1][6], r[C & 1][7]);                                     \
+        mma(acc[0], fa, fb0);                                                        \
+        mma(acc[1], fa, fb1);                                                        \
+        mma(acc[2], fa, fb2);                                                        \
+        if constexpr (BIAS) mma(accb, fa, ones);                                     \
+      }                                                                              \
+      __builtin_amdgcn_sched_barrier(0);
+      CHUNK(0) CHUNK(1) CHUNK(2) CHUNK(3)
 #undef CHUNK
-  }
+#elif TN_FPIPE
+      // fragments of chunk C + 1 are read while the MFMAs of chunk C run (two register sets; LDS returns in order, so the compiler's
+      // counted lgkmcnt waits let the next chunk's eight reads stay in flight)
+      const unsigned char* sp = smem + st_comp * STAGE;
+      st_comp = st_comp == NSTAGE - 1 ? 0 : st_comp + 1;
+      Frag<bf16> fa[2], fb[2][3];
+      tr_chunk_b<0>(sp, oA, oB0, oB1, oB2, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#define CHUNK(C)                                                                     \
+      if (C < 3) tr_chunk_b<C + 1>(sp, oA, oB0, oB1, oB2, fa[(C + 1) & 1], fb[(C + 1) & 1]);  \
+      mma(acc[0], fa[C & 1], fb[C & 1][0]);                                            \
+      mma(acc[1], fa[C & 1], fb[C & 1][1]);                                            \
+      mma(acc[2], fa[C & 1], fb[C & 1][2]);                                            \
+      if constexpr (BIAS) mma(accb, fa[C & 1], ones);                                  \
+      if (C < 3) {            /* the next chunk's reads trickle out between this chunk's MFMAs */ \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                             \
+        if constexpr (BIAS) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+      }
+      CHUNK(0) CHUNK(1) CHUNK(2) CHUNK(3)
+#undef CHUNK
+#else
+      const unsigned sb = lds0 + st_comp * STAGE;
+      st_comp = st_comp == NSTAGE - 1 ? 0 : st_comp + 1;
+      const unsigned aA = sb + oA, aB0 = sb + oB0, aB1 = sb + oB1, aB2 = sb + oB2;
+      Frag<bf16> fa, fb[3];
+  #define CHUNK(C)                                   \
+      tr_chunk<C>(aA, aB0, aB1, aB2, fa, fb);        \
+      mma(acc[0], fa, fb[0]);                        \
+      mma(acc[1], fa, fb[1]);                        \
+      mma(acc[2], fa, fb[2]);                        \
+      if constexpr (BIAS) mma(accb, fa, ones);
+      CHUNK(0) CHUNK(1) CHUNK(2) CHUNK(3)
+  #undef CHUNK
+  #endif
+    }
+  };
+  if (do_bias) tiles(BoolTag<true>());
+  else tiles(BoolTag<false>());
 
   // (perm > 0 only in a launch without a token split, where part / bpart ARE the gradient tensors: the rows leave in the order
   // the reduction would have given them)

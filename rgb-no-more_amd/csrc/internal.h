@@ -45,6 +45,10 @@ int rgbnm_launch_nt_wres(int epi, const void* A, int lda, const void* W, int ldw
 // Row-panel N = 192 bf16 NT GEMM with a pipelined reduction (gemm_nt_kpipe.hip).  Same return convention.
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st);
+// Streaming row-panel GEMM for N >= 384 (gemm_nt_kstream.hip): a unit's epilogue and stores run under the next unit's reduction.
+// Same arguments and return convention as rgbnm_launch_nt_kpipe.
+int rgbnm_launch_nt_kstream(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
+                            const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st);
 // Linear + bias + residual + LayerNorm of the result in one launch (gemm_nt_kpipe.hip); 1 = not eligible.
 int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* R,
                                  int ldr, void* x, int ldc, const float* gamma, const float* beta, void* y, int ldy,

@@ -10,6 +10,7 @@
 #   abopt <opt> <v0> <v1> [n]       interleaved A/B of one library option on the bench step (same box)
 #   abso <base.so> [n] [bench args] interleaved A/B of two BUILDS: the in-tree librgbnm.so against <base.so> (built before an edit;
 #                                   scratch copies live under tools/*.so, git-ignored)
+#   abmany <n> "<bench args>" a.so b.so ...   the same over several prebuilt libraries
 #   kstats <tag> [bench args]       rocprofv3 kernel stats of the bench step -> gpurun_out/<tag>/kernel_stats.csv
 #   variants <file.hip> <kernel-pattern> <-DFLAG ...>   rebuild ONE csrc file per flag on the box and print that kernel's time
 #   stalls <tag> [bench args]       SQ activity / wait / LDS-conflict counters per kernel (three --pmc passes)
@@ -76,6 +77,14 @@ abso)
     timeout 400 python bench.py --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline --no-parity-check "$@" 2>/dev/null | tail -1 | line $v
   done; done
   cp /tmp/new.so rgb-no-more_amd/librgbnm.so ;;
+abmany)     # abmany <n> "<bench args>" a.so b.so ...: interleaved rounds over several prebuilt libraries (built in the container, scratch_so/)
+  N=$1; ARGS=$2; shift; shift
+  cp rgb-no-more_amd/librgbnm.so /tmp/keep.so
+  for r in $(seq 1 $N); do for so in "$@"; do
+    cp $so rgb-no-more_amd/librgbnm.so
+    timeout 400 python bench.py --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline --no-parity-check $ARGS 2>/dev/null | tail -1 | line $(basename $so .so) | cut -d" " -f1-4
+  done; done
+  cp /tmp/keep.so rgb-no-more_amd/librgbnm.so ;;
 kstats)
   TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; kstats $OUT "$@" ;;
 variants)
