@@ -83,7 +83,10 @@ int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, 
 // returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st) {
-  if (rgbnm_get_option("nt_kstream")) {
+  // nt_kstream: 1 = the fc1 + GELU epilogue only (where it wins: 157 -> 125 us at E = 384, M = 50176), 2 = every eligible shape
+  // (the plain epilogues measure 10 - 15 % slower than the kernels below: its 32-wide k-tiles pay two barriers where they pay one)
+  const int ksopt = rgbnm_get_option("nt_kstream");
+  if (ksopt >= 2 || (ksopt == 1 && epi == 2)) {
     const int rc = rgbnm_launch_nt_kstream(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
     if (rc != 1) return rc;
   }

@@ -125,9 +125,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kstream_kernel(KsArgs p) {
       else offI[j] = (unsigned)(n0 + r16) * (unsigned)p.ldw + lc;
     }
   };
-  int issued = 0, consumed = 0;
-  auto issue_next = [&]() {
-    if (iu >= J) return;
+  // The request stream never stops: behind the last k-tile of the last unit it repeats that tile into the stage just freed (never
+  // read again) -- four straight-line DMA instructions per k-tile that the scheduling pipeline below can place between MFMAs, and
+  // a vmcnt arithmetic without a tail case
+  auto issue4 = [&]() {
     unsigned char* st = smem + stI * STAGE;
     const int k0 = ikt * TK;
 #pragma unroll
@@ -137,12 +138,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kstream_kernel(KsArgs p) {
       const bf16* base = i < ASLOT ? p.A : p.W;
       __builtin_amdgcn_global_load_lds((glb_ptr)(base + (size_t)offI[j] + k0), (lds_ptr)(st + i * 1024), 16, 0, 0);
     }
+  };
+  auto advance = [&]() {
     stI = (stI + 1) & (NSTAGE - 1);
-    ++issued;
-    if (++ikt == T2) {
-      ikt = 0;
+    if (iu < J && ++ikt == T2) {
       iu = next_unit(iu);
-      if (iu < J) set_off(iu);
+      if (iu < J) { ikt = 0; set_off(iu); }
+      else ikt = T2 - 1;
     }
   };
   // fragment offsets inside a stage: lane (l31, g) reads k-elements 16 c + 8 g .. + 7 of row l31 (chunk 2 c + g, swizzled)
@@ -159,9 +161,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kstream_kernel(KsArgs p) {
         __builtin_amdgcn_global_load_lds((glb_ptr)(p.tab_img + (i * 64 + lane) * 4), (lds_ptr)(smem0 + i * 1024), 16, 0, 0);
   }
   set_off(u0);
-  issue_next();
-  issue_next();
-  issue_next();
+  issue4(); advance();
+  issue4(); advance();
+  issue4(); advance();
 
   f32x16 acc[6];
 #pragma unroll
@@ -272,13 +274,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kstream_kernel(KsArgs p) {
   // the stores of the last three k-tiles (s1, s2, s3; counted exactly: an immediate is all s_waitcnt takes, hence the switch)
   int s1 = 0, s2 = 0, s3 = 0;
 #ifdef KS_PROF
-  unsigned long long pw[5] = {0, 0, 0, 0, 0};
+  unsigned long long pw[6] = {0, 0, 0, 0, 0, 0};
   const unsigned long long tstart = __builtin_readcyclecounter();
 #endif
-#ifndef KS_PHASE
-#define KS_PHASE 1
+#ifndef KS_LATE
+#define KS_LATE 1
 #endif
-  const bool dma_first = KS_PHASE ? w < 4 : true;
+  const bool late = KS_LATE && w >= 4;
   auto wait_vm = [&](int allow) {
     switch (allow >> 1) {
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -297,44 +299,84 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kstream_kernel(KsArgs p) {
   // one k-tile: wait for it, barrier, request the tile three ahead, [slice into scratch], 12 MFMAs, [slice out of scratch -> stores]
   auto ktile = [&](auto put_tag, auto get_tag, int extra_vm) {
     constexpr int PS = decltype(put_tag)::value, GS = decltype(get_tag)::value;      // slice to write / to store, -1: none
-    const int younger = issued - consumed - 1;                // k-tiles requested after the one needed now (0 .. 2)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KSTAMP(t0);
-    wait_vm(NDMA * younger + s1 + s2 + s3);
+    wait_vm(2 * NDMA + s1 + s2 + (late ? 0 : s3));
     KSTAMP(t1);
     __builtin_amdgcn_s_barrier();
     KSTAMP(t2);
-    // The two waves of a SIMD leave the barrier together: were both to request their DMA slots first (a few hundred cycles of vmem
-    // issue each, nothing else moving) and run their MFMAs afterwards, the phases of a k-tile would add up.  Waves 0 - 3 request
-    // first, waves 4 - 6 (their SIMD partners) run their MFMAs first: one wave's vmem issue sits under the other's MFMAs.
-    if (dma_first) issue_next();
-    KSTAMP(t3);
-    ++consumed;
-    if constexpr (PS >= 0) {
-      if (have) put_slice(put_tag);
+    // The two waves of a SIMD leave the barrier together.  A slice's epilogue is VALU + LDS work (table GELU: ~130 instructions and
+    // two LDS round trips per wave), its way out 2 - 4 store instructions, the MFMA block in between leaves the VALU idle: waves
+    // 0 - 3 run slice-in, MFMAs, slice-out; their SIMD partners 4 - 6 ("late") slice-out (of the slice before), MFMAs, slice-in --
+    // one wave's slice work sits under the other's MFMAs.  (Stores first: the late waves' vmcnt allowance has no s3 term.)
+    int sn = extra_vm;
+    if constexpr (GS >= 0) {
+      if (have && late) sn += get_slice(get_tag);
     }
+    if constexpr (PS >= 0) {
+      if (have && !late) put_slice(put_tag);
+    }
+#ifdef KS_PROF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    KSTAMP(t3);
     const unsigned char* sA = smem + stC * STAGE + a_row;
     const unsigned char* sW = smem + stC * STAGE + A_STAGE;
     stC = (stC + 1) & (NSTAGE - 1);
+    // One scheduling region: the seven fragments of the first 16 k, then one MFMA at a time with a fragment of the second 16 k (into
+    // the registers the MFMA just read) and, four times, a DMA request of the k-tile three ahead behind it.  Left to itself the
+    // compiler reads two fragments, waits, issues their MFMAs, reads the next two ... (seven exposed LDS latencies per k-tile), and
+    // all waves of the CU pushed their DMA requests into the texture addresser in one burst right behind the barrier.
+    __builtin_amdgcn_sched_barrier(0);
+    {
+#define SB __builtin_amdgcn_sched_barrier(0)
+      Frag<bf16> fa0, fa1, fb0[6], fb1[6];
+      unsigned char* stD = smem + stI * STAGE;
+      const int k0 = ikt * TK;
+      auto dma = [&](int j) {
+        int i = w + NCW * j;
+        i = i < NSLOT ? i : i - NSLOT;
+        const bf16* base = i < ASLOT ? p.A : p.W;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(base + (size_t)offI[j] + k0), (lds_ptr)(stD + i * 1024), 16, 0, 0);
+      };
+      fa0.v = *reinterpret_cast<const bf16x8*>(sA + foff[0]);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      Frag<bf16> fa, fb[6];
-      fa.v = *reinterpret_cast<const bf16x8*>(sA + foff[c]);
+      for (int b = 0; b < 6; ++b) fb0[b].v = *reinterpret_cast<const bf16x8*>(sW + 32 * b * TKB + foff[0]);
+      SB;
+      mma(acc[0], fb0[0], fa0); SB;
+      fa1.v = *reinterpret_cast<const bf16x8*>(sA + foff[1]);
+      fb1[0].v = *reinterpret_cast<const bf16x8*>(sW + 32 * 0 * TKB + foff[1]); SB;
+      mma(acc[1], fb0[1], fa0); SB;
+      fb1[1].v = *reinterpret_cast<const bf16x8*>(sW + 32 * 1 * TKB + foff[1]); dma(0); SB;
+      mma(acc[2], fb0[2], fa0); SB;
+      fb1[2].v = *reinterpret_cast<const bf16x8*>(sW + 32 * 2 * TKB + foff[1]); dma(1); SB;
+      mma(acc[3], fb0[3], fa0); SB;
+      fb1[3].v = *reinterpret_cast<const bf16x8*>(sW + 32 * 3 * TKB + foff[1]); dma(2); SB;
+      mma(acc[4], fb0[4], fa0); SB;
+      fb1[4].v = *reinterpret_cast<const bf16x8*>(sW + 32 * 4 * TKB + foff[1]); dma(3); SB;
+      mma(acc[5], fb0[5], fa0); SB;
+      fb1[5].v = *reinterpret_cast<const bf16x8*>(sW + 32 * 5 * TKB + foff[1]); SB;
 #pragma unroll
-      for (int b = 0; b < 6; ++b) fb[b].v = *reinterpret_cast<const bf16x8*>(sW + 32 * b * TKB + foff[c]);
-#pragma unroll
-      for (int b = 0; b < 6; ++b) mma(acc[b], fb[b], fa);
+      for (int b = 0; b < 6; ++b) mma(acc[b], fb1[b], fa1);
+#undef SB
     }
-    if (!dma_first) issue_next();
-    int sn = extra_vm;
+    __builtin_amdgcn_sched_barrier(0);
+    advance();
+#ifdef KS_PROF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    KSTAMP(t3b);
+#endif
+    if constexpr (PS >= 0) {
+      if (have && late) put_slice(put_tag);
+    }
     if constexpr (GS >= 0) {
-      if (have) sn += get_slice(get_tag);
+      if (have && !late) sn += get_slice(get_tag);
     }
     s3 = s2; s2 = s1; s1 = sn;
 #ifdef KS_PROF
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KSTAMP(t4);
-    pw[0] += t1 - t0; pw[1] += t2 - t1; pw[2] += t3 - t2; pw[3] += t4 - t3; pw[4] += 1;
+    pw[0] += t1 - t0; pw[1] += t2 - t1; pw[2] += t3 - t2; pw[3] += t3b - t3; pw[5] += t4 - t3b; pw[4] += 1;
 #endif
   };
 
@@ -394,10 +436,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kstream_kernel(KsArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   drain(IntTag<0>()); drain(IntTag<1>()); drain(IntTag<2>()); drain(IntTag<3>()); drain(IntTag<4>()); drain(IntTag<5>());
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the repeated requests behind the stream's end still target this LDS
 #ifdef KS_PROF
   if (lane == 0 && blockIdx.x < 256) {
     unsigned long long* o = g_ks_prof + (blockIdx.x * 8 + w) * 6;
-    o[0] = pw[0]; o[1] = pw[1]; o[2] = pw[2]; o[3] = pw[3]; o[4] = pw[4]; o[5] = __builtin_readcyclecounter() - tstart;
+    o[0] = pw[0]; o[1] = pw[1]; o[2] = pw[2]; o[3] = pw[3]; o[4] = pw[4]; o[5] = pw[5];
   }
 #endif
 }

@@ -36,7 +36,7 @@ for name, N, K, epi in (("fc1+gelu", 1536, 384, 2), ("qkv", 1152, 384, 0), ("dX 
     outs = {}
     t = {}
     for opt in (0, 1):
-        L.check(lib.rgbnm_set_option(b"nt_kstream", opt))
+        L.check(lib.rgbnm_set_option(b"nt_kstream", 2 * opt))
         Cc = torch.full((M, N), 7.0, device="cuda", dtype=dt)
         C2 = torch.full((M, N), 7.0, device="cuda", dtype=dt)
         f = lambda: L.check(lib.rgbnm_gemm_nt(1, epi, A.data_ptr(), K, W.data_ptr(), K, Cc.data_ptr(), N, b.data_ptr(), R.data_ptr(), N,  # noqa: E731

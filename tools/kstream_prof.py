@@ -43,8 +43,8 @@ for wg in (0, 9, 255):
     for w in range(7):
         q = p[wg, w]
         n = max(q[4], 1)
-        print(f"wg {wg:3d} wave {w}: k-tiles {int(q[4]):3d}  per k-tile: vmcnt wait {q[0] / n:6.0f}  barrier {q[1] / n:6.0f}  dma issue {q[2] / n:6.0f}  work {q[3] / n:6.0f}   total {q[5]:8.0f} cycles")
+        print(f"wg {wg:3d} wave {w}: k-tiles {int(q[4]):3d}  per k-tile: vmcnt wait {q[0] / n:6.0f}  barrier {q[1] / n:6.0f}  slice in {q[2] / n:6.0f}  fragments + MFMAs + DMA {q[3] / n:6.0f}  slice out {q[5] / n:6.0f}")
 q = p[:, :7].reshape(-1, 6)
 q = q[q[:, 4] > 0]
 n = q[:, 4:5]
-print("mean over all waves, per k-tile: vmcnt wait %.0f  barrier %.0f  dma issue %.0f  work %.0f ; kernel life %.0f cycles" % (*(q[:, :4] / n).mean(0), q[:, 5].mean()))
+print("mean over all waves, per k-tile: vmcnt wait %.0f  barrier %.0f  slice in %.0f  MFMA block %.0f  slice out %.0f" % (*(q[:, :4] / n).mean(0), (q[:, 5:6] / n).mean()))
