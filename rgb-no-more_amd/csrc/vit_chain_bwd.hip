@@ -164,6 +164,47 @@ __device__ __forceinline__ Frag<bf16> rowfrag_x(const unsigned char* arr, unsign
   f.v = *reinterpret_cast<const bf16x8*>(arr + (rb ^ (unsigned)(c << 5)) + t * 32 * ROWB);
   return f;
 }
+// The eight MFMAs of one 32-row tile in the attention phases (scores and their gradient: two accumulators, K = 64 in four steps)
+// with their eight row fragments in a PINNED order: four fragments ahead, every MFMA followed by the read of the fragment two steps
+// on (into registers an earlier MFMA has read -- the sixteen the transposed fragments of the tile's second half take afterwards).
+// Left alone the compiler emits read - wait - MFMA eight times with ONE fragment buffer: an exposed LDS latency per MFMA, 336 of
+// them per block and wave.  XB_ROWPIPE=0: the plain loop (experiments).  Same order per accumulator: same bits.
+#ifndef XB_ROWPIPE
+#define XB_ROWPIPE 1
+#endif
+__device__ __forceinline__ void row_pair_mma(f32x16& sa, f32x16& da, const unsigned char* arrS, const unsigned char* arrD, unsigned rb,
+                                             int t, const Frag<bf16> (&xs)[4], const Frag<bf16> (&xd)[4]) {
+#if XB_ROWPIPE
+#define XB_SB __builtin_amdgcn_sched_barrier(0)
+  Frag<bf16> fs[4], fd[4];
+  XB_SB;
+  fs[0] = rowfrag_x(arrS, rb, t, 0);
+  fd[0] = rowfrag_x(arrD, rb, t, 0);
+  fs[1] = rowfrag_x(arrS, rb, t, 1);
+  fd[1] = rowfrag_x(arrD, rb, t, 1);
+  XB_SB;
+  mma(sa, fs[0], xs[0]); XB_SB;
+  fs[2] = rowfrag_x(arrS, rb, t, 2); XB_SB;
+  mma(da, fd[0], xd[0]); XB_SB;
+  fd[2] = rowfrag_x(arrD, rb, t, 2); XB_SB;
+  mma(sa, fs[1], xs[1]); XB_SB;
+  fs[3] = rowfrag_x(arrS, rb, t, 3); XB_SB;
+  mma(da, fd[1], xd[1]); XB_SB;
+  fd[3] = rowfrag_x(arrD, rb, t, 3); XB_SB;
+  mma(sa, fs[2], xs[2]);
+  mma(da, fd[2], xd[2]);
+  mma(sa, fs[3], xs[3]);
+  mma(da, fd[3], xd[3]);
+  XB_SB;
+#undef XB_SB
+#else
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mma(sa, rowfrag_x(arrS, rb, t, c), xs[c]);
+    mma(da, rowfrag_x(arrD, rb, t, c), xd[c]);
+  }
+#endif
+}
 __device__ __forceinline__ unsigned opaque(unsigned v) {
   asm volatile("" : "+v"(v));
   return v;
@@ -875,11 +916,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
             f32x16 sa, da;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              mma(sa, rowfrag_x(Ks, rb, t, c), qf[c]);
-              mma(da, rowfrag_x(Vs, rb, t, c), gf[c]);
-            }
+            row_pair_mma(sa, da, Ks, Vs, rb, t, qf, gf);
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -925,11 +962,7 @@ __global__ __launch_bounds__(NTHREADS) void vit_chain_bwd_kernel(BwdArgs p) {
             f32x16 sa, da;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              mma(sa, rowfrag_x(Qs, rb, t, c), kf[c]);
-              mma(da, rowfrag_x(Gs, rb, t, c), vf[c]);
-            }
+            row_pair_mma(sa, da, Qs, Gs, rb, t, kf, vf);
             float pp[16], ds[16];
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
