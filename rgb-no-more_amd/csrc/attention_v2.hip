@@ -56,6 +56,63 @@ __device__ __forceinline__ Frag<bf16> rowfrag_x(const unsigned char* arr, unsign
   return f;
 }
 
+// MFMA groups of one 32-row tile with their row fragments in a PINNED order (sched_barrier after every step).  Left alone the
+// compiler emits read - wait - MFMA with ONE fragment buffer: an exposed LDS latency per MFMA (36 of attn3_fwd's 80 MFMAs, 50 of
+// attn3_bwd's 196).  row_mma4: one accumulator, the four fragments requested together; row_pair_mma: two accumulators (scores and
+// their gradient), four fragments ahead, every MFMA followed by the read of the fragment two steps on.  Same MFMA order per
+// accumulator: same bits.  -DAV2_ROWPIPE=0: the plain loops (experiments).
+#ifndef AV2_ROWPIPE
+#define AV2_ROWPIPE 1
+#endif
+__device__ __forceinline__ void row_mma4(f32x16& acc, const unsigned char* arr, unsigned rb, int t, const Frag<bf16> (&x)[4]) {
+#if AV2_ROWPIPE
+  Frag<bf16> f[4];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) f[c] = rowfrag_x(arr, rb, t, c);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mma(acc, f[c], x[c]);
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mma(acc, rowfrag_x(arr, rb, t, c), x[c]);
+#endif
+}
+__device__ __forceinline__ void row_pair_mma(f32x16& sa, f32x16& da, const unsigned char* arrS, const unsigned char* arrD, unsigned rb,
+                                             int t, const Frag<bf16> (&xs)[4], const Frag<bf16> (&xd)[4]) {
+#if AV2_ROWPIPE
+#define AV2_SB __builtin_amdgcn_sched_barrier(0)
+  Frag<bf16> fs[4], fd[4];
+  AV2_SB;
+  fs[0] = rowfrag_x(arrS, rb, t, 0);
+  fd[0] = rowfrag_x(arrD, rb, t, 0);
+  fs[1] = rowfrag_x(arrS, rb, t, 1);
+  fd[1] = rowfrag_x(arrD, rb, t, 1);
+  AV2_SB;
+  mma(sa, fs[0], xs[0]); AV2_SB;
+  fs[2] = rowfrag_x(arrS, rb, t, 2); AV2_SB;
+  mma(da, fd[0], xd[0]); AV2_SB;
+  fd[2] = rowfrag_x(arrD, rb, t, 2); AV2_SB;
+  mma(sa, fs[1], xs[1]); AV2_SB;
+  fs[3] = rowfrag_x(arrS, rb, t, 3); AV2_SB;
+  mma(da, fd[1], xd[1]); AV2_SB;
+  fd[3] = rowfrag_x(arrD, rb, t, 3); AV2_SB;
+  mma(sa, fs[2], xs[2]);
+  mma(da, fd[2], xd[2]);
+  mma(sa, fs[3], xs[3]);
+  mma(da, fd[3], xd[3]);
+  AV2_SB;
+#undef AV2_SB
+#else
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mma(sa, rowfrag_x(arrS, rb, t, c), xs[c]);
+    mma(da, rowfrag_x(arrD, rb, t, c), xd[c]);
+  }
+#endif
+}
+
 // The same 28 instructions issued by ONE wave (the DMA wave of attn3_bwd_kernel).
 __device__ __forceinline__ void dma_matrix_all(const bf16* __restrict__ src, int ld, int N, unsigned char* dst, int lane) {
 #pragma unroll 4
@@ -742,11 +799,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
           f32x16 sa, da;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            mma(sa, rowfrag_x(Ks, rb, t, c), qf[c]);
-            mma(da, rowfrag_x(Vs, rb, t, c), gf[c]);
-          }
+          row_pair_mma(sa, da, Ks, Vs, rb, t, qf, gf);
           float ds[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -797,11 +850,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_bwd_kernel(const bf16* __rest
           f32x16 sa, da;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            mma(sa, rowfrag_x(Qs, rb, t, c), kf[c]);   // rows = queries, cols = keys
-            mma(da, rowfrag_x(Gs, rb, t, c), vf[c]);
-          }
+          row_pair_mma(sa, da, Qs, Gs, rb, t, kf, vf);
           float pp[16], ds[16];
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {   // accumulator rows 4 q4 .. 4 q4 + 3 = queries t*32 + 8 q4 + 4 g + 0..3
@@ -946,8 +995,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_fwd_kernel(const bf16* __rest
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mma(acc, rowfrag_x(Ks, rb, t, c), qf[c]);
+        row_mma4(acc, Ks, rb, t, qf);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[r];
@@ -971,8 +1019,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_fwd_kernel(const bf16* __rest
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mma(acc, rowfrag_x(Ks, rb, t, c), qf[c]);
+        row_mma4(acc, Ks, rb, t, qf);
         float pr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1122,8 +1169,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_proj_fwd_kernel(AttnProjArgs 
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) mma(acc, rowfrag_x(Ks, rb, t, c), qf[c]);
+          row_mma4(acc, Ks, rb, t, qf);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[r];
@@ -1147,8 +1193,7 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_proj_fwd_kernel(AttnProjArgs 
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) mma(acc, rowfrag_x(Ks, rb, t, c), qf[c]);
+          row_mma4(acc, Ks, rb, t, qf);
           float pr[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
