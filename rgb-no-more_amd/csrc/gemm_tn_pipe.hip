@@ -96,7 +96,10 @@ __device__ __forceinline__ void tr_chunk(unsigned aA, unsigned aB0, unsigned aB1
   fb[2].v = pack8(b2l, b2h);
 }
 
-// the same eight reads through the builtin (no wait inside: the compiler counts lgkmcnt), for the software-pipelined loop
+// Experiments (round 5, TN_FPIPE; default 0 = the loop above's read - wait - MFMA per 16 tokens, two waves per SIMD covering each
+// other): 1 = the same eight reads through the builtin with the next chunk's reads under the current MFMAs -- MEASURED +50 % on the
+// launch: the compiler drains vmcnt in front of every builtin LDS read that follows an LDS-DMA, which empties the ring;
+// 2 = asm reads without the wait, lgkmcnt counted by hand: +-0.5 % (the kernel waits for its operand stream, not for LDS).
 typedef bf16 bf16x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4v* lds_b64_ptr;
 __device__ __forceinline__ u32x2 tr_read(const unsigned char* smem, unsigned off) {
@@ -112,7 +115,7 @@ __device__ __forceinline__ void tr_chunk_b(const unsigned char* sp, unsigned oA,
 }
 
 #ifndef TN_FPIPE
-#define TN_FPIPE 1
+#define TN_FPIPE 0
 #endif
 // ... and as one asm block WITHOUT the wait (TN_FPIPE == 2): the compiler drains vmcnt before a builtin LDS read that follows
 // LDS-DMA (it cannot tell the ring stages apart), which empties the DMA pipeline; asm reads are invisible to that rule, so the waits

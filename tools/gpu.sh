@@ -11,6 +11,7 @@
 #   abso <base.so> [n] [bench args] interleaved A/B of two BUILDS: the in-tree librgbnm.so against <base.so> (built before an edit;
 #                                   scratch copies live under tools/*.so, git-ignored)
 #   abmany <n> "<bench args>" a.so b.so ...   the same over several prebuilt libraries
+#   abkern <n> "<bench args>" "<regex>" a.so b.so ...   the same under rocprofv3: mean launch time of the matching kernels in the step
 #   kstats <tag> [bench args]       rocprofv3 kernel stats of the bench step -> gpurun_out/<tag>/kernel_stats.csv
 #   variants <file.hip> <kernel-pattern> <-DFLAG ...>   rebuild ONE csrc file per flag on the box and print that kernel's time
 #   stalls <tag> [bench args]       SQ activity / wait / LDS-conflict counters per kernel (three --pmc passes)
@@ -83,6 +84,20 @@ abmany)     # abmany <n> "<bench args>" a.so b.so ...: interleaved rounds over s
   for r in $(seq 1 $N); do for so in "$@"; do
     cp $so rgb-no-more_amd/librgbnm.so
     timeout 400 python bench.py --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline --no-parity-check $ARGS 2>/dev/null | tail -1 | line $(basename $so .so) | cut -d" " -f1-4
+  done; done
+  cp /tmp/keep.so rgb-no-more_amd/librgbnm.so ;;
+abkern)     # abkern <n> "<bench args>" "<kernel regex>" a.so b.so ...: interleaved rounds under rocprofv3; mean launch time of the matching kernels IN THE STEP
+  N=$1; ARGS=$2; PAT=$3; shift; shift; shift
+  cp rgb-no-more_amd/librgbnm.so /tmp/keep.so; OUT=gpurun_out/abkern; mkdir -p $OUT
+  for r in $(seq 1 $N); do for so in "$@"; do
+    cp $so rgb-no-more_amd/librgbnm.so
+    timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python bench.py --steps ${STEPS:-10} --warmup 4 --prewarm-sec 1 --no-cpu-baseline --no-trace --no-parity-check $ARGS > $OUT/kt.log 2>&1
+    python - "$(find $OUT/kt -name "*kernel_stats.csv" | head -1)" "$PAT" "$(basename $so .so)" <<'PY'
+import csv, re, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if re.search(sys.argv[2], r["Name"])]
+print(sys.argv[3], "  ".join(f"{re.sub(r'.*::', '', r['Name'].split('(')[0])[:34]} {float(r['AverageNs']) / 1e3:.1f}" for r in rows))
+PY
+    rm -rf $OUT/kt
   done; done
   cp /tmp/keep.so rgb-no-more_amd/librgbnm.so ;;
 kstats)
