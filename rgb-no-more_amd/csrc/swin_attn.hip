@@ -171,6 +171,35 @@ __device__ __forceinline__ float inv_norm(float n2) { return fminf(__builtin_amd
 template <typename T> __device__ __forceinline__ Frag<T> rowfrag(const T* tile, int row, int c, int g) {
   return load_frag<T>(tile + row * RP + c * WA<T>::CH + g * WA<T>::EPL);
 }
+// The score / score-gradient MFMAs of one 32-row tile with ALL their row fragments requested first (pinned by sched_barrier): left
+// alone the compiler emits read - wait - MFMA per fragment with one buffer -- an exposed LDS latency per MFMA in a kernel that runs
+// one wave per SIMD (nothing else to hide it).  Same MFMA order per accumulator: same bits.
+template <typename T, int NCH>
+__device__ __forceinline__ void row_pair_mma(f32x16& sa, f32x16& da, const T* tileS, const T* tileD, int row, int g,
+                                             const Frag<T> (&xs)[NCH], const Frag<T> (&xd)[NCH]) {
+  if constexpr (sizeof(T) == 2) {
+    Frag<T> fs[NCH], fd[NCH];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      fs[c] = rowfrag<T>(tileS, row, c, g);
+      fd[c] = rowfrag<T>(tileD, row, c, g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      mma(sa, fs[c], xs[c]);
+      mma(da, fd[c], xd[c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      mma(sa, rowfrag<T>(tileS, row, c, g), xs[c]);
+      mma(da, rowfrag<T>(tileD, row, c, g), xd[c]);
+    }
+  }
+}
 // A-operand fragment from a transposed tile [d][TP]: row d, tokens of fragment `fi` of 32-token tile `t`, lane group g
 template <typename T> __device__ __forceinline__ Frag<T> tfrag(const T* img, int d, int t, int fi, int g) {
   Frag<T> f;
@@ -562,11 +591,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         f32x16 sa, da;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < A::NCH; ++c) {
-          mma(sa, rowfrag<T>(Kn, 32 * t + l31, c, g), qf[c]);          // rows = keys, cols = queries
-          mma(da, rowfrag<T>(Vr, 32 * t + l31, c, g), gf[c]);
-        }
+        row_pair_mma<T, A::NCH>(sa, da, Kn, Vr, 32 * t + l31, g, qf, gf);          // rows = keys, cols = queries
         float dss[16];
         auto softmax_bwd = [&](auto MK) {          // element pairs: packed fp32 VALU (v_pk_fma / v_pk_mul / v_pk_add)
 #pragma unroll
@@ -659,11 +684,7 @@ __global__ __launch_bounds__(64 * WA<T>::BWD_WAVES) void win_attn_bwd_kernel(
         f32x16 sa, da;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < A::NCH; ++c) {
-          mma(sa, rowfrag<T>(Qn, 32 * i + l31, c, g), kf[c]);          // rows = queries, cols = keys
-          mma(da, rowfrag<T>(Gr, 32 * i + l31, c, g), vf[c]);
-        }
+        row_pair_mma<T, A::NCH>(sa, da, Qn, Gr, 32 * i + l31, g, kf, vf);          // rows = queries, cols = keys
         float pp[16], dss[16];
         auto softmax_bwd = [&](auto MK) {
 #pragma unroll
