@@ -51,7 +51,10 @@ int rgbnm_abi_version(void);
  *   "mlp_fuse"  1   FeedForwardBlock forward (fc1 + GELU + fc2 + residual [+ next LayerNorm]) as one launch (bf16, E = 192)
  *   "mlp_bwd"   1   its backward data path (dGELU product + fc1 dX + LayerNorm backward) as one launch (bf16, E = 192)
  *   "nt_small"  1   NT GEMMs with at most 512 rows (the classification head) on 32 x 32 tiles with an in-workgroup split of K
- *   "mlp_dmast" 1   fused MLP kernels: the DMA wave stores the saved-tensor tiles of waves 4-6 (the critical wave of each SIMD pair) */
+ *   "mlp_dmast" 1   fused MLP kernels: the DMA wave stores the saved-tensor tiles of waves 4-6 (the critical wave of each SIMD pair)
+ *   "nt_kstream" 0  streaming row-panel GEMM (csrc/gemm_nt_kstream.hip: a finished tile leaves under the next tile's reduction) for
+ *                   N >= 384, K >= 384: 1 = the fc1 + GELU epilogue only, 2 = every eligible shape.  The bits of the default kernels
+ *                   (tests/test_kstream.py); faster stand-alone, slower inside the training step: kept opt-in */
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
 /* With option "trace" = (1 << tag) the launchers bracket kernels of that class with HIP events recorded on the launch
