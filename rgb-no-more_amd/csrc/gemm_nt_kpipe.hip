@@ -11,6 +11,7 @@
 #include "common.h"
 #include "internal.h"
 #include "ln_bwd_rows.h"
+#include "gelu_table.h"
 #include "../../include/rgbnm.h"
 
 #define KP_NS kp7

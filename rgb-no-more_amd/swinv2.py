@@ -568,6 +568,10 @@ class SwinTransformerV2(FlatParamModule):
         # weight gradients then exist only when backward() has returned, which torch DDP's reducer hooks do not wait for
         self.group_dw_backward = False
         self._conv = None
+        # set-up call (synchronises once per device, so not inside a graph capture): the GELU table of the fc1 + GELU epilogues
+        # (rgbnm.h rgbnm_gelu_table_init; without it those epilogues use the arithmetic form -- the same bits, more instructions)
+        if torch.cuda.is_available():
+            L.check(L.lib().rgbnm_gelu_table_init(L.stream()), "gelu_table_init")
 
     @staticmethod
     def _init_weights(m):

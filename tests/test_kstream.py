@@ -44,3 +44,19 @@ def test_streaming_kernel_gives_the_bits_of_the_row_panel_kernels(M, N, K, epi):
     else:
         assert (got[1] == 7.0).all()                             # C2 untouched by the plain epilogue
     assert torch.isfinite(got[0].float()).all()
+
+
+@pytest.mark.parametrize("M", [50176, 8300, 65536])      # persistent 7-wave kernel (full / ragged panels), 8-wave kernel (resident image)
+def test_row_panel_gelu_epilogue_table_form_gives_the_bits_of_the_arithmetic_form(M):
+    """fc1 + GELU through the persistent row-panel kernel (gemm_nt_kpipe_body.inc): the table lookup of its staging pass (image
+    reloaded behind every k-loop) against the erf arithmetic -- gelu and gelu' bit for bit."""
+    L.check(L.lib().rgbnm_gelu_table_init(L.stream()))
+    N, K = 1536, 384
+    torch.manual_seed(M)
+    A = (torch.randn(M, K, device="cuda") * 2.0).to(torch.bfloat16)      # pre-activations well outside +-4 too
+    W = (torch.randn(N, K, device="cuda") * 0.08).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda")
+    arith = _run(0, 2, A, W, b, M, N, K, table=0)
+    tab = _run(0, 2, A, W, b, M, N, K, table=1)
+    assert torch.equal(arith[0], tab[0]) and torch.equal(arith[1], tab[1])
+    assert float(arith[0].float().abs().max()) > 4.0
