@@ -48,12 +48,12 @@
 
 // kp8 when its rounds of workgroups cost less than kp7's: rounds x rows per panel, kp8 charged 5 % for its shallower ring
 // (measured: equal at M = 2^18 where both geometries fill their rounds, 17 % / 28 % faster at M = 2^16 / 2^14).
-static bool use_kp8(int M, int N, int epi) {
+static bool use_kp8(int M, int N, int) {
   if (M % 256 || N % 192 || !rgbnm_get_option("kp8")) return false;
-  // row counts that suit both geometries (M = 50176 = 224 x 224 = 196 x 256, the ViT batch): measured per epilogue at E = 384 -- the
-  // plain GEMMs gain from the 2-D wave tiles (qkv 79 -> 71 us, the dX GEMMs 2 - 5 %), the residual / GELU / dGELU ones are level
-  // or lose the persistent form's prefetch (dGELU 128 -> 135 us)
-  if (M % 224 == 0) return epi == 0;
+  // row counts that suit both geometries (M = 50176 = 224 x 224 = 196 x 256, the ViT batch): the persistent 7-wave kernel.  (Round 4
+  // measured the plain GEMMs 2 - 10 % faster on the 2-D wave tiles of kp8; with the pinned k-tile order of ktile_mma the
+  // persistent kernel is ahead again: 55.5 vs 57.7 us per launch over the 48 plain GEMMs of a JPEG-S step.)
+  if (M % 224 == 0) return false;
   const long long nt = N / 192, cus = 256;
   const long long r7 = ((long long)((M + 223) / 224) * nt + cus - 1) / cus * 224, r8 = ((long long)(M / 256) * nt + cus - 1) / cus * 256;
   return r8 * 105 < r7 * 100;
