@@ -255,7 +255,11 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   // ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ------------------------------------
   // tn_group: the four dW GEMMs run one per launch (0), as pairs fc2 + fc1 / proj + qkv (1) or all in one launch at the
   // end of the block (2): T tiles in a launch -> 256 / T splits of the token axis -> that many fp32 partial tiles
-  const int group = rgbnm_get_option("tn_group");
+  // E = 192: all four in one launch measured best (21 tiles, 12 token splits).  E = 384: 72 tiles leave 3 splits on 216 of the 256
+  // CUs; as pairs (48 tiles x 5 splits, 24 x 10: 240 CUs each, the first pair launched right behind the MLP data path whose
+  // outputs it reads) the JPEG-S step is 1 % faster (13.26 -> 13.13 ms, interleaved)
+  int group = rgbnm_get_option("tn_group");
+  if (group == 2 && E > 192) group = 1;
   if (group) rgbnm_tn_defer_begin();
   TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
   // du = (dy . W2) * gelu'(u) and dx_mid = dy + LN2'(du . W1) in ONE launch when eligible (mlp_fused.hip, option mlp_bwd)
