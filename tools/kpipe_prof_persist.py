@@ -40,7 +40,7 @@ assert fn(buf.ctypes.data) == 0
 p = buf[:256 * 8 * 4].reshape(256, 8, 4).astype(np.int64)
 t0 = p[:, 0, 0].min()
 for wg in (0, 1, 100, 255):
-    print(f"workgroup {wg} (ticks of 10 ns from the first stamp of the launch): unit start | k-loop | pass 1 | pass 2 (stores issued, barrier) | gap to next unit")
+    print(f"workgroup {wg} (s_memtime ticks = shader cycles): unit start | k-loop | pass 1 | pass 2 (stores issued, barrier) | gap to next unit")
     for ui in range(8):
         q = p[wg, ui]
         if q[3] <= q[0]:
