@@ -46,6 +46,26 @@ __global__ __launch_bounds__(1024) void k_store(unsigned char* buf, size_t per_w
   }
 }
 
+// store width: one wave per CU, a continuous stream of dword / dwordx2 / dwordx4 stores (256 / 512 / 1024 bytes per instruction)
+template <int W>
+__global__ __launch_bounds__(64) void k_width(unsigned char* buf, size_t per_wave, int nstore, unsigned long long* out) {
+  const int lane = threadIdx.x & 63;
+  unsigned char* base = buf + (size_t)blockIdx.x * 16 * per_wave + lane * 4 * W;
+  u32x4 v = {(unsigned)threadIdx.x, 1u, 2u, 3u};
+  asm volatile("" : "+v"(v));
+  const size_t wrap = per_wave / (256 * W);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < nstore; ++i) {
+    unsigned char* p = base + (size_t)(i % wrap) * 256 * W;
+    if (W == 1) *reinterpret_cast<unsigned*>(p) = v[0];
+    else if (W == 2) { typedef unsigned int u32x2v __attribute__((ext_vector_type(2))); u32x2v t = {v[0], v[1]}; *reinterpret_cast<u32x2v*>(p) = t; }
+    else *reinterpret_cast<u32x4*>(p) = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) { out[blockIdx.x * 32] = t2 - t0; out[blockIdx.x * 32 + 1] = t2 - t0; }
+}
+
 __global__ __launch_bounds__(1024) void k_work(int n, unsigned long long* out, int work) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float f0 = threadIdx.x, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3, fa = 1.0001f, fb = 0.5f;
@@ -121,5 +141,23 @@ int main() {
       }
       printf("%8d %10d | %8.1f   [%8.1f] | %7.1f\n", waves, work * 4, res[0], res[1], (double)ncu * waves * 1024 * 1024.0 / (mss[0] * 1e-3) / ncu / 1e9);
     }
+  printf("\nstore width, one wave per CU: bytes/instruction | ticks per store | GB/s per CU\n");
+  for (int wd : {1, 2, 4}) {
+    const int nstore = 2048;
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      if (wd == 1) hipLaunchKernelGGL(k_width<1>, dim3(ncu), dim3(64), 0, 0, buf, per_wave, nstore, out);
+      else if (wd == 2) hipLaunchKernelGGL(k_width<2>, dim3(ncu), dim3(64), 0, 0, buf, per_wave, nstore, out);
+      else hipLaunchKernelGGL(k_width<4>, dim3(ncu), dim3(64), 0, 0, buf, per_wave, nstore, out);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+    }
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
+    double t = 0;
+    for (int b = 0; b < ncu; ++b) t += (double)h[b * 32];
+    printf("%6d | %8.1f | %7.1f\n", 256 * wd, t / ncu / nstore, (double)nstore * 256 * wd / (ms * 1e-3) / 1e9);
+  }
   return 0;
 }
