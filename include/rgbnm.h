@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RGBNM_ABI_VERSION 2
+#define RGBNM_ABI_VERSION 3
 #define RGBNM_DT_F32 0
 #define RGBNM_DT_BF16 1
 #define RGBNM_DT_I16 2   /* only as out_dtype of rgbnm_dct_augment[_ex] */
@@ -115,11 +115,21 @@ typedef struct rgbnm_linear_desc {
   int pair;            /* != 0: block-diagonal shadows diag(W, W) [2N,2K] and diag(W^T, W^T) [2K,2N] (off-diagonal blocks left as
                           the caller zeroed them).  x [M,K] read as [M/2,2K] times diag(W,W)^T is y [M,N] read as [M/2,2N]: a
                           96-wide Linear (SwinV2-T stage 1) then runs on the kernels tuned for 192-wide rows            */
+  int chain_kind;      /* rgbnm_prep_weights_chain: 0, or which Linear of an encoder block this is: 1 qkv, 2 projection, 3 fc1, 4 fc2 */
+  long long chain_off; /* ... and the element offset of that block's image inside the forward / backward chain images */
 } rgbnm_linear_desc;
 
 /* master fp32 -> per-step operand shadows for every Linear (descs_dev: device array of ndesc descriptors). */
 int rgbnm_prep_weights(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
                        float* bias_perm, void* stream);
+/* The same launch also writes the chain images of the one-launch encoder kernels (rgbnm_vit_chain_fwd / _bwd below; bf16,
+ * E = 192, 3 heads) straight from the fp32 masters: for every descriptor with chain_kind != 0 the weight goes to its place in
+ * chain_fwd ([N, K] orientation) and chain_bwd ([K, N]) -- either may be NULL -- exactly where rgbnm_chain_gather over the
+ * shadows would put it (rgb-no-more_amd/chain.py documents the layout; the kernel carries its arithmetic inverse).
+ * skip_chain_shadows != 0: the [N, K] / [K, N] shadows of those descriptors are NOT written (nothing reads them while the
+ * one-launch kernels run the encoder).  Before round 6 this was four launches per step (prep, bias gather, two image gathers). */
+int rgbnm_prep_weights_chain(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
+                             float* bias_perm, void* chain_fwd, void* chain_bwd, int skip_chain_shadows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (nn.LayerNorm(emb), plainvit.py:513,522,551) and head pooling (:551-552)
@@ -234,6 +244,16 @@ int rgbnm_dct_augment_packed(const int16_t* Ypacked, const int16_t* Cpacked, con
  * dlogits = (softmax*sum(t) - t) * grad_scale, pass grad_scale = 1/B for the mean reduction. */
 int rgbnm_softxent(int dl_dtype, const float* logits, const float* soft_target, const long long* hard_target,
                    float* loss_rows, float* loss, void* dlogits, int B, int C, float grad_scale, void* stream);
+/* The same loss as one launch per direction (round 6).  _loss: loss_rows [B], row_stats [2B] (log-sum-exp, target mass per row)
+ * and loss[0] = the mean in ONE launch: the workgroup that finishes last sums the rows in a fixed order; `ticket` is one zeroed
+ * 32-bit word of caller-owned device memory that the launch leaves zero again (one ticket per stream that may run the call).
+ * _grad: dlogits (dl_dtype) = (softmax * sum(t) - t) * grad_scale * gout_dev[0] from the saved row statistics; gout_dev (device,
+ * may be NULL = 1) is autograd's output gradient of the loss (GradScaler's scale under fp16 AMP, train.py:159): no host sync and
+ * no element-wise launches to scale or convert it. */
+int rgbnm_softxent_loss(const float* logits, const float* soft_target, const long long* hard_target, float* loss_rows,
+                        float* row_stats, float* loss, unsigned* ticket, int B, int C, void* stream);
+int rgbnm_softxent_grad(int dl_dtype, const float* logits, const float* soft_target, const long long* hard_target,
+                        const float* row_stats, const float* gout_dev, void* dlogits, int B, int C, float grad_scale, void* stream);
 /* RandomMixup_DCT (cls_transforms.py:163-176): out[b] = lam[0]*in[b] + lam[1]*in[b-1]; lam on device. */
 int rgbnm_mixup(int in_dtype, int out_dtype, const void* in, void* out, const float* lam_dev, int B,
                 long long per_sample, void* stream);

@@ -80,32 +80,65 @@ class RandomMixup_DCT(torch.nn.Module):
         return (outs[0] if single else tuple(outs)), tgt
 
 
+_TICKETS = {}       # (device index, raw stream) -> one zeroed 32-bit word for rgbnm_softxent_loss (left zero by every launch)
+
+
+def _ticket(device):
+    key = (device.index, L.stream())
+    t = _TICKETS.get(key)
+    if t is None:
+        t = torch.zeros(1, device=device, dtype=torch.int32)
+        if not torch.cuda.is_current_stream_capturing():      # (memory of a graph's private pool is not kept beyond the capture)
+            _TICKETS[key] = t
+    return t
+
+
 class _SoftXent(torch.autograd.Function):
+    """loss = CrossEntropyLoss()(logits, target) as one launch; its backward as one launch that reads autograd's output gradient on
+    the device.  `edge` is the tensor the gradient flows back through: the logits themselves (gradient in their dtype), or the
+    compute-dtype twin a rgb-no-more_amd head hands out next to its fp32 logits (plainvit._HeadFn) -- the bf16 head backward then
+    gets its bf16 dlogits without the fp32 round trip autograd's dtype check would force on a gradient of fp32 logits."""
+
     @staticmethod
-    def forward(ctx, logits, target, dl_dtype):
+    def forward(ctx, edge, logits, target):
         B, Cn = logits.shape
         hard = target.dtype == torch.int64
         rows = torch.empty(B, device=logits.device, dtype=torch.float32)
+        stat = torch.empty(2 * B, device=logits.device, dtype=torch.float32)
         loss = torch.empty(1, device=logits.device, dtype=torch.float32)
-        dl = torch.empty(B, Cn, device=logits.device, dtype=dl_dtype)
-        L.check(L.lib().rgbnm_softxent(L.dt_of(dl_dtype), logits.data_ptr(), None if hard else target.data_ptr(),
-                                       target.data_ptr() if hard else None, rows.data_ptr(), loss.data_ptr(),
-                                       dl.data_ptr(), B, Cn, 1.0 / B, L.stream()), "softxent")
-        ctx.save_for_backward(dl)
+        L.check(L.lib().rgbnm_softxent_loss(logits.data_ptr(), None if hard else target.data_ptr(),
+                                            target.data_ptr() if hard else None, rows.data_ptr(), stat.data_ptr(),
+                                            loss.data_ptr(), _ticket(logits.device).data_ptr(), B, Cn, L.stream()), "softxent_loss")
+        ctx.save_for_backward(logits, target, stat)
+        ctx.dl_dtype = edge.dtype
         return loss[0]
 
     @staticmethod
     def backward(ctx, gout):
-        (dl,) = ctx.saved_tensors
-        return dl * gout.to(dl.dtype), None, None
+        logits, target, stat = ctx.saved_tensors
+        B, Cn = logits.shape
+        hard = target.dtype == torch.int64
+        dl = torch.empty(B, Cn, device=logits.device, dtype=ctx.dl_dtype)
+        if gout.dtype != torch.float32 or not gout.is_cuda:
+            gout = gout.to(device=logits.device, dtype=torch.float32)
+        L.check(L.lib().rgbnm_softxent_grad(L.dt_of(ctx.dl_dtype), logits.data_ptr(), None if hard else target.data_ptr(),
+                                            target.data_ptr() if hard else None, stat.data_ptr(), gout.data_ptr(), dl.data_ptr(),
+                                            B, Cn, 1.0 / B, L.stream()), "softxent_grad")
+        return dl, None, None
 
 
 def cross_entropy(logits: Tensor, target: Tensor, grad_dtype=torch.float32) -> Tensor:
     """torch.nn.CrossEntropyLoss()(logits, target) for class-index (int64 [B]) or probability ([B,C] fp32)
-    targets, mean reduction; loss and dlogits come from one HIP kernel."""
+    targets, mean reduction: one HIP launch forward, one backward.  grad_dtype: the dtype the model's head wants its dlogits
+    in; honoured when `logits` come from a rgb-no-more_amd head that handed out a gradient edge of that dtype (fp32 logits keep an
+    fp32 gradient otherwise, as autograd demands)."""
     L.require_cuda(logits, target)
+    edge = getattr(logits, "_rgbnm_grad_edge", None)
     if logits.dtype != torch.float32:
-        logits = logits.float()
+        logits, edge = logits.float(), None
     if target.dtype != torch.int64:
         target = target.float().contiguous()
-    return _SoftXent.apply(logits.contiguous(), target, grad_dtype)
+    logits = logits.contiguous()
+    if edge is None or edge.dtype != grad_dtype or edge.shape != logits.shape or not edge.requires_grad:
+        edge = logits
+    return _SoftXent.apply(edge, logits.detach(), target)

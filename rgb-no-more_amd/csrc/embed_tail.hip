@@ -123,6 +123,80 @@ __global__ __launch_bounds__(256) void softxent_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The loss as ONE launch forward and ONE backward (round 6; rgbnm_softxent above stays for callers that want dlogits at once):
+// forward: per-row loss, log-sum-exp and target mass; the workgroup that finishes LAST (a ticket in caller-owned memory) sums the
+// rows in the fixed order of mean_kernel -- same bits, no second launch.  backward: dlogits = (softmax * sum(t) - t) * gscale *
+// gout[0] straight from the saved row statistics, gout read on the device (the autograd output gradient: no host sync, no
+// element-wise launches to scale / convert it).
+__global__ __launch_bounds__(256) void softxent_loss_kernel(const float* __restrict__ logits, const float* __restrict__ soft,
+                                                            const long long* __restrict__ hard, float* __restrict__ rows,
+                                                            float* __restrict__ stat, float* __restrict__ loss,
+                                                            unsigned* __restrict__ ticket, int C) {
+  __shared__ float red[4];
+  __shared__ int last_s;
+  const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* z = logits + (size_t)b * C;
+  const long long lab = hard ? hard[b] : -1;
+  float m = -INFINITY;
+  for (int c = tid; c < C; c += 256) m = fmaxf(m, z[c]);
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f, st = 0.f, stz = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+    se += __expf(z[c] - m);
+    st += t;
+    stz += t * z[c];
+  }
+  float vals[3] = {se, st, stz};
+  for (int k = 0; k < 3; ++k) {
+    const float v = wave_sum(vals[k]);
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    vals[k] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+  const float lse = m + __logf(vals[0]);
+  if (tid == 0) {
+    __hip_atomic_store(rows + b, lse * vals[1] - vals[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stat[2 * b] = lse;
+    stat[2 * b + 1] = vals[1];
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = (t == (unsigned)B - 1u);
+  }
+  __syncthreads();
+  if (!last_s) return;
+  float a = 0.f;                                   // mean_kernel's order: stride-256 partial sums, wave sums, four partials
+  for (int i = tid; i < B; i += 256) a += __hip_atomic_load(rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = wave_sum(a);
+  if (lane == 0) red[w] = a;
+  __syncthreads();
+  if (tid == 0) {
+    loss[0] = (red[0] + red[1] + red[2] + red[3]) / B;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softxent_grad_kernel(const float* __restrict__ logits, const float* __restrict__ soft,
+                                                            const long long* __restrict__ hard, const float* __restrict__ stat,
+                                                            const float* __restrict__ gout, T* __restrict__ dlogits, int C,
+                                                            float gscale) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* z = logits + (size_t)b * C;
+  const long long lab = hard ? hard[b] : -1;
+  const float lse = stat[2 * b], sumt = stat[2 * b + 1];
+  const float g = gout ? gscale * gout[0] : gscale;
+  for (int c = tid; c < C; c += 256) {
+    const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+    dlogits[(size_t)b * C + c] = from_f32<T>((__expf(z[c] - lse) * sumt - t) * g);
+  }
+}
+
 __global__ void mean_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
   __shared__ float red[4];
   float a = 0.f;
@@ -249,6 +323,28 @@ int rgbnm_softxent(int dl_dtype, const float* logits, const float* soft_target, 
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, loss_rows, loss, B);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_softxent_loss(const float* logits, const float* soft_target, const long long* hard_target, float* loss_rows,
+                        float* row_stats, float* loss, unsigned* ticket, int B, int C, void* stream) {
+  if (!logits || (!soft_target && !hard_target) || !loss_rows || !row_stats || !loss || !ticket || B <= 0 || C <= 0) return RGBNM_EINVAL;
+  hipLaunchKernelGGL(softxent_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, soft_target, hard_target, loss_rows,
+                     row_stats, loss, ticket, C);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_softxent_grad(int dl_dtype, const float* logits, const float* soft_target, const long long* hard_target,
+                        const float* row_stats, const float* gout_dev, void* dlogits, int B, int C, float grad_scale, void* stream) {
+  if (!logits || (!soft_target && !hard_target) || !row_stats || !dlogits || B <= 0 || C <= 0) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dl_dtype == DT_BF16)
+    hipLaunchKernelGGL((softxent_grad_kernel<bf16>), dim3(B), dim3(256), 0, st, logits, soft_target, hard_target, row_stats, gout_dev, (bf16*)dlogits, C, grad_scale);
+  else if (dl_dtype == DT_F32)
+    hipLaunchKernelGGL((softxent_grad_kernel<float>), dim3(B), dim3(256), 0, st, logits, soft_target, hard_target, row_stats, gout_dev, (float*)dlogits, C, grad_scale);
+  else return RGBNM_EINVAL;
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

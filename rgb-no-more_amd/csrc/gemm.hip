@@ -633,13 +633,55 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
 // ------------------------------------------------------------------------------------------------
 // 32 x 32 tiles through LDS so that BOTH shadows are written with coalesced rows (the transposed one was a stride-N
 // scatter before: 57 us per step for JPEG-Ti, 460 us for SwinV2-T's 28 M parameters).
+// One-launch encoder (vit_chain.hip / vit_chain_bwd.hip): where element (R, c) of a block Linear's [N, K] operand lies in the
+// forward chain image, and element (kr, n) of its [K, N] transpose in the backward one -- the arithmetic inverse of the layout
+// rgb-no-more_amd/chain.py builds as an index table (block_index / block_index_bwd; tests/test_chain_fwd.py compares the two).
+// kind: 1 qkv (rows de-interleaved q | k | v), 2 projection, 3 fc1, 4 fc2;  E = 192, 3 heads.
+__device__ __forceinline__ int ch_fswz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 1) | (((r >> 3) & 1) << 1); }
+__device__ __forceinline__ int ch_swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+constexpr int CH_SLOT = 12288;
+__device__ __forceinline__ int ch_pos384(int rl, int col) {        // [64 LDS rows][192]: 16-byte chunks swizzled inside groups of 8
+  const int lc = col >> 3;
+  return rl * 192 + (((lc & ~7) | ((lc & 7) ^ ch_fswz(rl))) << 3) + (col & 7);
+}
+__device__ __forceinline__ int ch_pos128(int rl, int kk) {         // [192 LDS rows][64]: chunk q at q ^ fswz(row)
+  return rl * 64 + (((kk >> 3) ^ ch_fswz(rl)) << 3) + (kk & 7);
+}
+__device__ __forceinline__ int chain_fwd_pos(int kind, int R, int c) {
+  switch (kind) {
+    case 1: return (((R % 192) >> 6) * 3 + R / 192) * CH_SLOT + ch_pos384(ch_swap23(R & 63), c);
+    case 2: return (9 + (c >> 6)) * CH_SLOT + ch_pos128(ch_swap23(R), ch_swap23(c & 63));
+    case 3: return (12 + 2 * (R >> 6)) * CH_SLOT + ch_pos384(ch_swap23(R & 63), c);
+    default: return (13 + 2 * (c >> 6)) * CH_SLOT + ch_pos128(ch_swap23(R), c & 63);
+  }
+}
+__device__ __forceinline__ int chain_bwd_pos(int kind, int kr, int n) {
+  switch (kind) {
+    case 4: return (2 * (kr >> 6)) * CH_SLOT + ch_pos384(ch_swap23(kr & 63), n);
+    case 3: return (2 * (n >> 6) + 1) * CH_SLOT + ch_pos128(kr, n & 63);
+    case 2: return (24 + (kr >> 6)) * CH_SLOT + ch_pos384(ch_swap23(kr & 63), n);
+    default: return (27 + (n >> 6)) * CH_SLOT + ch_pos128(kr, n & 63);
+  }
+}
+
+// chain_fwd / chain_bwd (bf16 only, may be null): the chain images, written straight from the fp32 masters for every descriptor
+// with chain_kind != 0 -- the per-block [N, K] / [K, N] shadows of those Linears are skipped when skip_chain_shadows is set (nothing
+// reads them while the one-launch kernels run).  The de-interleaved qkv bias (gather_bias, a launch of its own before round 6) is
+// written by the first three workgroups of a descriptor's row of the grid.
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_desc* __restrict__ descs,
-                                                           const float* __restrict__ master, T* __restrict__ shadow) {
+                                                           const float* __restrict__ master, T* __restrict__ shadow,
+                                                           float* __restrict__ bias_out, T* __restrict__ chain_fwd,
+                                                           T* __restrict__ chain_bwd, int skip_chain_shadows) {
   __shared__ float tile[32][33];
   const rgbnm_linear_desc d = descs[blockIdx.y];
+  if (bias_out && d.perm_heads > 0 && blockIdx.x < 3)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.N; i += 3 * 256)
+      bias_out[d.bperm_off + i] = master[d.b_off + qkv_row(i, d.perm_heads)];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
   const int tr = (d.N + 31) / 32, tc = (d.K + 31) / 32;
+  const int kind = (chain_fwd || chain_bwd) ? d.chain_kind : 0;
+  const bool shadows = !(kind && skip_chain_shadows);
   for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
     const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
 #pragma unroll
@@ -649,7 +691,9 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
       if (r < d.N && c < d.K) {
         const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
         v = master[d.w_off + (size_t)src * d.K + c] + ((d.add_identity && r == c) ? 1.0f : 0.0f);
-        if (d.pair) {                                            // diag(W, W): row pitch 2K, second copy at (N, K)
+        if (kind && chain_fwd) chain_fwd[d.chain_off + chain_fwd_pos(kind, r, c)] = from_f32<T>(v);
+        if (!shadows) {
+        } else if (d.pair) {                                     // diag(W, W): row pitch 2K, second copy at (N, K)
           shadow[d.ws_off + (size_t)r * (2 * d.K) + c] = from_f32<T>(v);
           shadow[d.ws_off + (size_t)(d.N + r) * (2 * d.K) + d.K + c] = from_f32<T>(v);
         } else {
@@ -663,7 +707,9 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + ty + 8 * k, r = r0 + tx;
       if (r < d.N && c < d.K) {
-        if (d.pair) {
+        if (kind && chain_bwd) chain_bwd[d.chain_off + chain_bwd_pos(kind, c, r)] = from_f32<T>(tile[tx][ty + 8 * k]);
+        if (!shadows) {
+        } else if (d.pair) {
           shadow[d.wst_off + (size_t)c * (2 * d.N) + r] = from_f32<T>(tile[tx][ty + 8 * k]);
           shadow[d.wst_off + (size_t)(d.K + c) * (2 * d.N) + d.N + r] = from_f32<T>(tile[tx][ty + 8 * k]);
         } else {
@@ -673,14 +719,6 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
     }
     __syncthreads();
   }
-}
-
-__global__ void gather_bias_kernel(const rgbnm_linear_desc* __restrict__ descs, const float* __restrict__ master,
-                                   float* __restrict__ bias_out) {
-  const rgbnm_linear_desc d = descs[blockIdx.y];
-  if (d.perm_heads <= 0) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x)
-    bias_out[d.bperm_off + i] = master[d.b_off + qkv_row(i, d.perm_heads)];
 }
 
 }  // namespace
@@ -750,21 +788,26 @@ int rgbnm_gemm_tn_group_end(void* stream) {
   return rc;
 }
 
-int rgbnm_prep_weights(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
-                       float* bias_perm, void* stream) {
+int rgbnm_prep_weights_chain(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
+                             float* bias_perm, void* chain_fwd, void* chain_bwd, int skip_chain_shadows, void* stream) {
   if (!descs_dev || !master || !shadow || ndesc <= 0) return RGBNM_EINVAL;
+  if ((chain_fwd || chain_bwd) && dtype != DT_BF16) return RGBNM_EINVAL;
+  if (skip_chain_shadows && !chain_fwd && !chain_bwd) return RGBNM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((prep_weights_kernel<bf16>), dim3(64, ndesc), dim3(256), 0, st, descs_dev, master, (bf16*)shadow);
+    hipLaunchKernelGGL((prep_weights_kernel<bf16>), dim3(64, ndesc), dim3(256), 0, st, descs_dev, master, (bf16*)shadow, bias_perm,
+                       (bf16*)chain_fwd, (bf16*)chain_bwd, skip_chain_shadows);
   else if (dtype == DT_F32)
-    hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(64, ndesc), dim3(256), 0, st, descs_dev, master, (float*)shadow);
+    hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(64, ndesc), dim3(256), 0, st, descs_dev, master, (float*)shadow, bias_perm,
+                       (float*)nullptr, (float*)nullptr, 0);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
-  if (bias_perm) {
-    hipLaunchKernelGGL(gather_bias_kernel, dim3(3, ndesc), dim3(256), 0, st, descs_dev, master, bias_perm);
-    LAUNCH_CHECK();
-  }
   return RGBNM_OK;
+}
+
+int rgbnm_prep_weights(int dtype, const rgbnm_linear_desc* descs_dev, int ndesc, const float* master, void* shadow,
+                       float* bias_perm, void* stream) {
+  return rgbnm_prep_weights_chain(dtype, descs_dev, ndesc, master, shadow, bias_perm, nullptr, nullptr, 0, stream);
 }
 
 }  // extern "C"

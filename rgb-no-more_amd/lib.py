@@ -19,7 +19,8 @@ HOST_WAIT = {"sec": 0.0}
 
 class LinearDesc(C.Structure):
     _fields_ = [("w_off", _ll), ("b_off", _ll), ("ws_off", _ll), ("wst_off", _ll), ("bperm_off", _ll),
-                ("N", _i), ("K", _i), ("perm_heads", _i), ("add_identity", _i), ("ldn", _i), ("pair", _i)]
+                ("N", _i), ("K", _i), ("perm_heads", _i), ("add_identity", _i), ("ldn", _i), ("pair", _i),
+                ("chain_kind", _i), ("chain_off", _ll)]
 
 
 class VitCfg(C.Structure):
@@ -69,7 +70,7 @@ class ChainBwdBlock(C.Structure):
                                    "rstd2", "u", "dy", "du", "dx_mid", "dqkv", "dx", "part2", "part1")]
 
 
-ABI_VERSION = 2      # include/rgbnm.h RGBNM_ABI_VERSION this binding was written against
+ABI_VERSION = 3      # include/rgbnm.h RGBNM_ABI_VERSION this binding was written against
 
 _P = C.POINTER
 # name -> (restype, argtypes); every symbol include/rgbnm.h declares
@@ -87,6 +88,7 @@ PROTOTYPES = {
     "rgbnm_gemm_tn_workspace": (_sz, [_i, _i, _i]),
     "rgbnm_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "rgbnm_prep_weights": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "rgbnm_prep_weights_chain": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "rgbnm_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "rgbnm_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "rgbnm_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
@@ -104,6 +106,8 @@ PROTOTYPES = {
     "rgbnm_dct_augment_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _i, _vp, _sz, _vp]),
     "rgbnm_softxent": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "rgbnm_softxent_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "rgbnm_softxent_grad": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "rgbnm_mixup": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _vp]),
     "rgbnm_mixup_target": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "rgbnm_clip_adamw_wd_workspace": (_sz, []),

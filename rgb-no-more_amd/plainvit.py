@@ -643,12 +643,25 @@ class _HeadFn(torch.autograd.Function):
                           a.h1.data_ptr(), logits.data_ptr())
         L.check(L.lib().rgbnm_head_fwd(C.byref(a.cfg), C.byref(m._hparams), C.byref(acts), L.stream()), "head_fwd")
         ctx.st, ctx.acts, ctx.x = st, acts, x
-        return logits if m._ncls_pad == m.n_classes else logits[:, :m.n_classes].contiguous()
+        ctx.set_materialize_grads(False)
+        if m._ncls_pad != m.n_classes:
+            return logits[:, :m.n_classes].contiguous()
+        if a.cdtype == torch.float32:
+            return logits
+        # bf16 compute: a second, uninitialised [B, C] output in the compute dtype whose only purpose is to carry a gradient in
+        # THAT dtype: cls_transforms.cross_entropy sends its dlogits back through it, so the bf16 head backward is not fed through
+        # the fp32 round trip autograd's dtype check forces on a gradient of fp32 logits (two cast launches).  Any other loss uses
+        # `logits` as always; gradients arriving on both edges are added.
+        return logits, torch.empty(a.B, m._ncls_pad, device=x.device, dtype=a.cdtype)
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, dedge=None):
         st = ctx.st
         m, a = st.model, st.arena
+        if dlogits is None and dedge is None:
+            return (None,) * (2 + len(m._head_param_order))
+        if dedge is not None:
+            dlogits = dedge if dlogits is None else dedge + dlogits.to(dedge.dtype)
         names = m._head_names
         grads = [m._gview(st.gbuf, n) for n in names]
         padded = m._ncls_pad != m.n_classes
@@ -787,7 +800,13 @@ class ViT(FlatParamModule):
         lin += [("h1", "classhead.ch_linear1", 0), ("h2", "classhead.ch_linear2", 0)]
         descs = (L.LinearDesc * len(lin))()
         self._sh_off, so, bo = {}, 0, 0
+        # one-launch encoder kernels (chain.py): rgbnm_prep_weights_chain writes a block Linear straight into the chain images
+        chain_ok = self.emb_size == 192 and self.num_heads == 3 and self.n_tokens == 196
+        from . import chain as _chain
+        kinds = {"eb_mha.qkv": 1, "eb_mha.projection": 2, "eb_ffb.0": 3, "eb_ffb.3": 4}
         for k, (key, name, ph) in enumerate(lin):
+            ck = kinds[name.split(".fn.")[1]] if chain_ok and name.startswith("encoder.") else 0
+            coff = int(name.split(".")[1]) * _chain.BLOCK_ELEMS if ck else 0
             Nn, Kk = self._shapes[name + ".weight"]
             Np = self._ncls_pad if key == "h2" else Nn          # shadow rows / transposed-shadow stride (padded class count)
             ws, wst = so, so + _align(Np * Kk)
@@ -796,7 +815,7 @@ class ViT(FlatParamModule):
             if ph:
                 bo += _align(Nn)
             descs[k] = L.LinearDesc(offs[name + ".weight"], offs[name + ".bias"], ws, wst, bp, Nn, Kk, ph,
-                                    1 if key == "peM" else 0, Np if Np != Nn else 0, 0)
+                                    1 if key == "peM" else 0, Np if Np != Nn else 0, 0, ck, coff)
             self._sh_off[key] = (ws, wst, bp)
         self._ndesc, self._sh_total = len(lin), so
         self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
@@ -812,22 +831,16 @@ class ViT(FlatParamModule):
             self._sep_cache = {}
         else:
             self._conv16 = self.patchembed.conv_Y.to(dev).contiguous()
-        # one-launch encoder forward (chain.py): constant gather table for the per-step chain image
+        # one-launch encoder kernels: the two chain images (forward: [N, K] orientation, backward: transposed), rewritten every step
+        # by rgbnm_prep_weights_chain.  _chain_idx stays the eligibility flag older code tests; the index TABLES that document the
+        # layout (chain.py) are only built on demand (_chain_index_tables: tests compare the kernel's arithmetic with them)
         self._chain_idx = None
-        if self.emb_size == 192 and self.num_heads == 3 and self.n_tokens == 196:
-            from . import chain as _chain
-            idx = np.concatenate([_chain.block_index(self._sh_off[f"qkv{i}"][0], self._sh_off[f"proj{i}"][0],
-                                                     self._sh_off[f"fc1{i}"][0], self._sh_off[f"fc2{i}"][0])
-                                  for i in range(self.depth)])
-            assert idx.max() < 2 ** 31 and _chain.BLOCK_ELEMS == L.lib().rgbnm_chain_image_elems()
-            self._chain_idx = torch.from_numpy(idx.astype(np.int32)).to(dev)
-            self._chain_img = torch.zeros(idx.size, device=dev, dtype=torch.bfloat16)
-            idb = np.concatenate([_chain.block_index_bwd(self._sh_off[f"qkv{i}"][1], self._sh_off[f"proj{i}"][1],
-                                                         self._sh_off[f"fc1{i}"][1], self._sh_off[f"fc2{i}"][1])
-                                  for i in range(self.depth)])
-            assert idb.max() < 2 ** 31
-            self._chain_idx_bwd = torch.from_numpy(idb.astype(np.int32)).to(dev)
-            self._chain_img_bwd = torch.zeros(idb.size, device=dev, dtype=torch.bfloat16)
+        self._chain_refused = False
+        if chain_ok:
+            assert _chain.BLOCK_ELEMS == L.lib().rgbnm_chain_image_elems()
+            self._chain_idx = True
+            self._chain_img = torch.zeros(self.depth * _chain.BLOCK_ELEMS, device=dev, dtype=torch.bfloat16)
+            self._chain_img_bwd = torch.zeros(self.depth * _chain.BLOCK_ELEMS, device=dev, dtype=torch.bfloat16)
         self._pos = sincos_table(14, 14, self.emb_size, dev)
         self._pos7 = sincos_table(7, 7, self.emb_size, dev) if self.embed_kind == "concat" else None
         self._zc = {}
@@ -892,23 +905,35 @@ class ViT(FlatParamModule):
         ws, wst, _ = self._sh_off[key]
         return sh.data_ptr() + (ws if which == "ws" else wst) * sh.element_size()
 
+    def _chain_index_tables(self):
+        """(forward, backward) int32 gather tables over the operand shadows (chain.py): dst[i] = shadow[idx[i]] -- the definition of
+        the chain images that rgbnm_prep_weights_chain's address arithmetic is tested against."""
+        from . import chain as _chain
+        dev = self._flat.device
+        idx = np.concatenate([_chain.block_index(self._sh_off[f"qkv{i}"][0], self._sh_off[f"proj{i}"][0],
+                                                 self._sh_off[f"fc1{i}"][0], self._sh_off[f"fc2{i}"][0]) for i in range(self.depth)])
+        idb = np.concatenate([_chain.block_index_bwd(self._sh_off[f"qkv{i}"][1], self._sh_off[f"proj{i}"][1],
+                                                     self._sh_off[f"fc1{i}"][1], self._sh_off[f"fc2{i}"][1])
+                              for i in range(self.depth)])
+        assert max(idx.max(), idb.max()) < 2 ** 31
+        return torch.from_numpy(idx.astype(np.int32)).to(dev), torch.from_numpy(idb.astype(np.int32)).to(dev)
+
     def _prep(self, cdtype):
-        """fp32 masters -> operand shadows (cast, qkv de-interleave, transposes) for this step."""
+        """fp32 masters -> operand shadows (cast, qkv de-interleave, transposes) and, for the one-launch encoder kernels, their
+        chain images -- ONE launch per step."""
         if cdtype not in self._shadow:
             self._shadow[cdtype] = torch.zeros(self._sh_total, device=self._flat.device, dtype=cdtype)
         self._cur_dtype = cdtype
         self._prep_gen = getattr(self, "_prep_gen", 0) + 1        # (the shadows and the chain images are model-global: see _check_prep_gen)
-        L.check(L.lib().rgbnm_prep_weights(L.dt_of(cdtype), self._descs_dev.data_ptr(), self._ndesc,
-                                           self._flat.data_ptr(), self._shadow[cdtype].data_ptr(),
-                                           self._bias_perm.data_ptr(), L.stream()), "prep_weights")
-        if cdtype == torch.bfloat16 and self._chain_idx is not None and L.lib().rgbnm_get_option(b"fwd_chain"):
-            L.check(L.lib().rgbnm_chain_gather(self._shadow[cdtype].data_ptr(), self._chain_idx.data_ptr(),
-                                               self._chain_img.data_ptr(), self._chain_idx.numel(), L.stream()), "chain_gather")
-        if (cdtype == torch.bfloat16 and self._chain_idx is not None and L.lib().rgbnm_get_option(b"bwd_chain")
-                and torch.is_grad_enabled()):
-            L.check(L.lib().rgbnm_chain_gather(self._shadow[cdtype].data_ptr(), self._chain_idx_bwd.data_ptr(),
-                                               self._chain_img_bwd.data_ptr(), self._chain_idx_bwd.numel(), L.stream()),
-                    "chain_gather (backward image)")
+        chain = cdtype == torch.bfloat16 and self._chain_idx is not None
+        img_f = self._chain_img.data_ptr() if chain and L.lib().rgbnm_get_option(b"fwd_chain") else None
+        img_b = (self._chain_img_bwd.data_ptr() if chain and L.lib().rgbnm_get_option(b"bwd_chain") and torch.is_grad_enabled()
+                 else None)
+        # the block Linears' own shadows are only read by the per-operation kernels: skipped while both directions run as chains
+        skip = bool(img_f and (img_b or not torch.is_grad_enabled()) and not self._chain_refused)
+        L.check(L.lib().rgbnm_prep_weights_chain(L.dt_of(cdtype), self._descs_dev.data_ptr(), self._ndesc, self._flat.data_ptr(),
+                                                 self._shadow[cdtype].data_ptr(), self._bias_perm.data_ptr(), img_f, img_b,
+                                                 1 if skip else 0, L.stream()), "prep_weights")
         if cdtype not in self._bparams_by_dtype:
             bps = []
             for i in range(self.depth):
@@ -977,6 +1002,9 @@ class ViT(FlatParamModule):
             rc = L.lib().rgbnm_vit_chain_fwd(C.byref(a.cfg), sub, n, a.xbuf(s0).data_ptr(), L.stream())
             if rc == 1 and s0 == 0:
                 self._warn_chain_refused("forward")
+                if not self._chain_refused:           # the per-operation kernels need the block shadows this step's prep skipped
+                    self._chain_refused = True
+                    self._prep(a.cdtype)
                 return False
             L.check(rc, "vit_chain_fwd")
         return True
@@ -1018,6 +1046,9 @@ class ViT(FlatParamModule):
             rc = L.lib().rgbnm_vit_chain_bwd(C.byref(a.cfg), sub, n, a.dattn_chain.data_ptr(), L.stream())
             if rc == 1 and s0 == starts[-1]:
                 self._warn_chain_refused("backward")
+                if not self._chain_refused:
+                    self._chain_refused = True
+                    self._prep(a.cdtype)
                 return False
             L.check(rc, "vit_chain_bwd")
         return True
@@ -1085,7 +1116,11 @@ class ViT(FlatParamModule):
         else:
             for i in range(self.depth):
                 h = _BlockFn.apply(h, st, i, *[named[n] for n in self._block_param_order[i]])
-        return _HeadFn.apply(h, st, *[named[n] for n in self._head_param_order])
+        out = _HeadFn.apply(h, st, *[named[n] for n in self._head_param_order])
+        if isinstance(out, tuple):
+            out, edge = out
+            out._rgbnm_grad_edge = edge      # cls_transforms.cross_entropy: the compute-dtype gradient edge of these logits
+        return out
 
     def _all_block_params(self):
         named = self._named

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(dll, s), f"librgbnm.so does not export {s}"
     # and the python prototypes cover exactly the header
     assert sorted(L.PROTOTYPES) == syms
-    assert L.lib().rgbnm_abi_version() == L.ABI_VERSION == 2
+    assert L.lib().rgbnm_abi_version() == L.ABI_VERSION == 3
     assert b"workspace" in L.lib().rgbnm_strerror(-3)
 
 

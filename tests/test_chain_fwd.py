@@ -193,3 +193,40 @@ def test_depth_13_runs_as_two_chain_launches():
     assert worst < 1e-5, worst                            # chain backward (two launches) vs the per-operation backward
     lo_f, _, _ = step(m, y, c, tgt, False)                # the whole model on the per-operation kernels
     assert np.abs(lo_c - lo_f).max() < 2e-2
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_chain_images_written_by_prep_equal_the_gather_tables(depth):
+    """Round 6: rgbnm_prep_weights_chain writes both chain images straight from the fp32 masters (address arithmetic in the kernel);
+    chain.py's index tables over the operand shadows are the layout's definition: image[i] == shadow[idx[i]] for every element,
+    forward and backward image, with and without the block shadows skipped; the de-interleaved qkv bias comes out of the same launch."""
+    m, y, c, tgt = build(depth, 2)
+    m._ensure_flat()
+    with torch.no_grad():
+        m._flat.copy_(torch.from_numpy(detfill.normalish((m._flat.numel(),), 91)).to(DEV))
+    m._chain_refused = True          # (as after a refusal: the launch writes the shadows AND the images)
+    m._chain_img.zero_()
+    m._chain_img_bwd.zero_()
+    m._prep(torch.bfloat16)
+    sh = m._shadow[torch.bfloat16]
+    idx, idb = m._chain_index_tables()
+    want_f, want_b = sh[idx.long()], sh[idb.long()]
+    assert torch.equal(m._chain_img, want_f) and torch.equal(m._chain_img_bwd, want_b)
+    bias = m._bias_perm.clone()
+    for i in range(depth):           # bias_perm[q | k | v blocks] = the interleaved '(h d qkv)' bias de-interleaved (plainvit.py:447)
+        b = m._named[f"encoder.{i}.0.fn.eb_mha.qkv.bias"].detach().view(3, 64, 3)
+        o = m._sh_off[f"qkv{i}"][2]
+        assert torch.equal(bias[o:o + 576].view(3, 3, 64), b.permute(2, 0, 1).contiguous())
+    # the default: block shadows skipped, images the same bits; head / patch-embedding shadows still written
+    m._chain_refused = False
+    sh_before = sh.clone()
+    sh.zero_()
+    m._chain_img.zero_()
+    m._chain_img_bwd.zero_()
+    m._prep(torch.bfloat16)
+    assert torch.equal(m._chain_img, want_f) and torch.equal(m._chain_img_bwd, want_b)
+    for key in ("pe", "h1", "h2"):
+        ws, wst, _ = m._sh_off[key]
+        assert torch.equal(sh[ws:ws + 64], sh_before[ws:ws + 64]) and torch.equal(sh[wst:wst + 64], sh_before[wst:wst + 64])
+    ws = m._sh_off["qkv0"][0]
+    assert not sh[ws:ws + 576 * 192].any()

@@ -257,6 +257,57 @@ def test_softxent(hard):
     assert relerr(zz.grad, zr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("hard", [False, True])
+def test_softxent_one_launch_per_direction(hard):
+    """rgbnm_softxent_loss / _grad (round 6) against the two-launch rgbnm_softxent: the loss the SAME BITS (the last workgroup sums
+    the rows in mean_kernel's order), dlogits the same bits at gout = 1 and scaled by a device-side gout otherwise; run twice so
+    that the self-resetting ticket is exercised."""
+    B, Cn = 256, 1000
+    z = dev(detfill.normalish((B, Cn), 51) * 3)
+    if hard:
+        t = torch.from_numpy(detfill.integers((B,), 52, 0, Cn - 1, np.int64)).to(DEV)
+    else:
+        tt = detfill.uniform((B, Cn), 53, 0, 1)
+        t = dev(tt / tt.sum(1, keepdims=True))
+    soft, hardp = (None, t.data_ptr()) if hard else (t.data_ptr(), None)
+    rows0, loss0 = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    for dt in DTS:
+        dl0 = torch.empty(B, Cn, device=DEV, dtype=dt)
+        L.check(L.lib().rgbnm_softxent(L.dt_of(dt), z.data_ptr(), soft, hardp, rows0.data_ptr(), loss0.data_ptr(), dl0.data_ptr(),
+                                       B, Cn, 1.0 / B, L.stream()))
+        ticket = torch.zeros(1, device=DEV, dtype=torch.int32)
+        for rep in range(2):
+            rows, stat, loss = torch.empty(B, device=DEV), torch.empty(2 * B, device=DEV), torch.empty(1, device=DEV)
+            L.check(L.lib().rgbnm_softxent_loss(z.data_ptr(), soft, hardp, rows.data_ptr(), stat.data_ptr(), loss.data_ptr(),
+                                                ticket.data_ptr(), B, Cn, L.stream()))
+            assert torch.equal(loss, loss0) and torch.equal(rows, rows0) and int(ticket.item()) == 0
+        for gv in (1.0, 0.37, 1024.0):
+            gout = torch.full((), gv, device=DEV)
+            dl = torch.empty(B, Cn, device=DEV, dtype=dt)
+            L.check(L.lib().rgbnm_softxent_grad(L.dt_of(dt), z.data_ptr(), soft, hardp, stat.data_ptr(), gout.data_ptr(),
+                                                dl.data_ptr(), B, Cn, 1.0 / B, L.stream()))
+            if gv == 1.0:
+                assert torch.equal(dl, dl0)
+                dl1 = torch.empty_like(dl)
+                L.check(L.lib().rgbnm_softxent_grad(L.dt_of(dt), z.data_ptr(), soft, hardp, stat.data_ptr(), None, dl1.data_ptr(),
+                                                    B, Cn, 1.0 / B, L.stream()))
+                assert torch.equal(dl1, dl0)
+            else:
+                assert relerr(dl, dl0.float() * gv) < tol(dt, 1e-6, 4e-3)
+
+
+def test_cross_entropy_scaled_backward():
+    """autograd's output gradient (GradScaler's scale, train.py:159; a weighted sum of losses) reaches dlogits on the device."""
+    B, Cn = 19, 1000
+    z = dev(detfill.normalish((B, Cn), 54) * 2)
+    t = torch.from_numpy(detfill.integers((B,), 55, 0, Cn - 1, np.int64)).to(DEV)
+    zr = z.clone().requires_grad_(True)
+    (torch.nn.CrossEntropyLoss()(zr, t) * 3.5).backward()
+    zz = z.clone().requires_grad_(True)
+    (rg.cls_transforms.cross_entropy(zz, t) * 3.5).backward()
+    assert relerr(zz.grad, zr.grad) < 1e-5
+
+
 def test_mixup_golden(golden):
     g = golden("g13_mixup.npz")
     mix = rg.cls_transforms.RandomMixup_DCT(10, alpha=0.2)

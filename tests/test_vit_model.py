@@ -538,3 +538,41 @@ def test_vit_step_is_bit_reproducible(emb, heads, B):
         assert torch.equal(runs[0][0], runs[k][0])
         bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[k][1][n])]
         assert not bad, bad[:5]
+
+
+def test_bf16_gradient_edge_of_the_head():
+    """Round 6: in bf16 mode the head hands out, next to its fp32 logits, a compute-dtype gradient edge; cls_transforms.cross_entropy
+    (grad_dtype = bf16) sends dlogits back through it -- no fp32 round trip, no cast launches.  Same bits as the gradient that
+    arrives through the fp32 logits (grad_dtype = fp32: the head casts it), any other loss still differentiates through `logits`,
+    and gradients arriving on BOTH edges are added."""
+    m, sd, y, c, tgt = build("ti_d2", compute=torch.bfloat16)
+
+    def grads(loss_fn):
+        m.zero_grad()
+        logits = m(y, c)
+        assert logits.dtype == torch.float32 and logits._rgbnm_grad_edge.dtype == torch.bfloat16
+        loss_fn(logits).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    g_edge = grads(lambda lg: rg.cls_transforms.cross_entropy(lg, tgt, grad_dtype=torch.bfloat16))
+    g_f32 = grads(lambda lg: rg.cls_transforms.cross_entropy(lg, tgt, grad_dtype=torch.float32))
+    bad = [n for n in g_edge if not torch.equal(g_edge[n], g_f32[n])]
+    assert not bad, bad[:5]
+    # torch's own criterion on the same logits (what an unchanged train.py does): fp32 gradient through `logits`
+    g_torch = grads(lambda lg: torch.nn.CrossEntropyLoss()(lg, tgt))
+    for n in g_edge:
+        d = (g_torch[n] - g_edge[n]).norm() / (g_edge[n].norm() + 1e-12)
+        assert d < 2e-2, (n, d.item())
+    # both edges at once: the loss through the edge plus a second term through the logits; d/dlogits of the sum is the sum
+    w = torch.from_numpy(detfill.normalish((y.shape[0], 1000), 75)).to(DEV) * 1e-3
+    g_both = grads(lambda lg: rg.cls_transforms.cross_entropy(lg, tgt, grad_dtype=torch.bfloat16) + (lg * w).sum())
+    g_second = grads(lambda lg: (lg * w).sum())
+    for n in ("classhead.ch_linear2.bias", "classhead.ch_linear2.weight", "encoder.0.0.fn.eb_mha.qkv.weight"):
+        want = g_edge[n] + g_second[n]
+        d = (g_both[n] - want).norm() / (want.norm() + 1e-12)
+        assert d < 2e-2, (n, d.item())
+    # a forward whose logits get no gradient at all leaves the parameters without one (no stale launch)
+    m.zero_grad()
+    m(y, c)
+    torch.cuda.synchronize()
