@@ -459,6 +459,9 @@ def main():
     opt = rg.custom_optims.FusedClipAdamWWD(model, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
     mix = rg.cls_transforms.RandomMixup_DCT(1000, alpha=0.2)
     mix.out_dtype = cdt
+    # the ViT mixes the batch while its sub-block kernel loads it (cls_transforms.LazyMixed: same bits, the mixed batch never
+    # exists in memory); needs the augment stage's output in the compute dtype (it is) -- SwinV2 mixes the ordinary way
+    mix.lazy = (not swin) and not a.no_augment and os.environ.get("RGBNM_BENCH_LAZY_MIX", "1") == "1"
     B = a.batch
     lab = torch.randint(0, 999, (B,), device=dev)
     S = 32 if swin else 28
@@ -471,12 +474,17 @@ def main():
         sampler = CT.FastParamSampler(aug, seed=1234 + rank)
 
     def data_part(out=None):
+        """out: (y, c, target, lambda) static buffers of the captured graph.  Lazy mixing: the augment stage writes y, c itself and
+        the batch stays un-mixed; the mixed target and the lambda the model's first kernel reads go to their static places."""
         if a.no_augment:
             y, c = y_in, c_in
         else:
             packed, nops = sampler.sample(B, 64, 64)
-            y, c = CT.apply_packed(aug, Yq, Cq, quant, packed, nops)
-        return mix((y, c), lab, out=out)
+            y, c = CT.apply_packed(aug, Yq, Cq, quant, packed, nops, out=out[:2] if (out is not None and mix.lazy) else None)
+        if mix.lazy:
+            lam = mix.sample_lambda(lab.device, out=None if out is None else out[3])
+            return mix((y, c), lab, lam=lam, out=None if out is None else (None, None, out[2]))
+        return mix((y, c), lab, out=None if out is None else out[:3])
 
     def model_part(my, mc, mt):
         logits = net(my, mc)
@@ -500,8 +508,11 @@ def main():
             sy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=cdt)
             sc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=cdt)
             smt = torch.empty(B, 1000, device=dev, dtype=torch.float32)
-            static = (sy, sc, smt)
+            slam = torch.empty(2, device=dev, dtype=torch.float32)
+            static = (sy, sc, smt, slam)
             data_part(out=static)
+            if mix.lazy:
+                sy, sc = rg.cls_transforms.LazyMixed(sy, slam), rg.cls_transforms.LazyMixed(sc, slam)
             if swin:
                 # DropPath draws new masks in every pass (captured Philox offsets advance with the replays), so a train-mode replay
                 # cannot be compared bit for bit.  The capture is therefore validated FIRST with DropPath off (eval mode: same ~600
@@ -550,6 +561,7 @@ def main():
             elif model.flat_grad_base() is None or not torch.equal(gloss.detach(), ref_loss) or not torch.equal(got_grad, ref_grad):
                 raise RuntimeError("graph replay does not reproduce the eager pass")
             graph = (g, gloss, static)
+            graph_inputs = (sy, sc, smt)
         except Exception as e:          # noqa: BLE001
             print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
@@ -651,7 +663,7 @@ def main():
             # the replayed backward + one explicit all-reduce must give the gradients of the eager step with the same inputs
             fs.bucket_elems = 1 << 60
             opt.zero_grad(set_to_none=True)
-            model_part(*graph[2])
+            model_part(*graph_inputs)
             torch.cuda.synchronize()
             g_eager = model._gflat.clone()
             graph[0].replay()

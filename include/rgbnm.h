@@ -164,6 +164,12 @@ int rgbnm_attention_bwd(int dtype, const void* qkv, const void* out, const void*
  * ------------------------------------------------------------------------------------------- */
 int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* conv16,
                          void* feat, int B, int Hb, int Wb, int transpose_a, void* stream);
+/* The same on a batch that RandomMixup_DCT (utils/cls_transforms.py:163-176) has NOT been applied to yet: lam_dev (device, two
+ * floats, may be NULL = no mixing) mixes image b with image b - 1 (mod B) as the values are loaded, rounded to in_dtype exactly
+ * as rgbnm_mixup(in_dtype -> in_dtype) stores them -- the same bits as rgbnm_mixup followed by rgbnm_subblock_embed without the
+ * mixed batch ever existing in memory (two launches and a round trip of the batch less per step). */
+int rgbnm_subblock_embed_mix(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* lam_dev, const float* conv16,
+                             void* feat, int B, int Hb, int Wb, int transpose_a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DCT-domain data path: replaces, per batch and on device, what the reference does per sample
@@ -420,6 +426,10 @@ size_t rgbnm_reduce_hold_table_bytes(void);
 int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* cfg, int in_dtype, const void* y, const void* cbcr,
                           const float* conv16, const void* wpe, const float* bpe, const float* pos, void* feat,
                           void* x0, int Hb, int Wb, void* stream);
+/* ... with the batch mixup applied on the way in (rgbnm_subblock_embed_mix; lam_dev NULL = rgbnm_patch_embed_fwd) */
+int rgbnm_patch_embed_fwd_mix(const rgbnm_vit_cfg* cfg, int in_dtype, const void* y, const void* cbcr, const float* lam_dev,
+                              const float* conv16, const void* wpe, const float* bpe, const float* pos, void* feat, void* x0,
+                              int Hb, int Wb, void* stream);
 int rgbnm_patch_embed_bwd(const rgbnm_vit_cfg* cfg, const void* dx0, const void* feat, float* dwpe, float* dbpe,
                           void* ws, size_t ws_bytes, void* stream);
 

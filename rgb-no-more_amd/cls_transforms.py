@@ -9,6 +9,36 @@ from torch import Tensor
 from . import lib as L
 
 
+class LazyMixed:
+    """A batch item RandomMixup_DCT(lazy=True) has NOT mixed yet: the un-mixed tensor plus the device lambda.  rgb-no-more_amd's
+    ViT applies the roll-by-one mix while its sub-block kernel loads the values (rgbnm_subblock_embed_mix: the same bits as the
+    mixed tensor, which then never exists in memory); any other consumer calls .materialize().  An explicit opt-in for loops that
+    hand the batch straight to the model, as train.py / pipeline_utils.unpack_data do."""
+    __slots__ = ("tensor", "lam")
+
+    def __init__(self, tensor, lam):
+        self.tensor, self.lam = tensor, lam
+
+    shape = property(lambda self: self.tensor.shape)
+    dtype = property(lambda self: self.tensor.dtype)
+    device = property(lambda self: self.tensor.device)
+    is_cuda = property(lambda self: self.tensor.is_cuda)
+
+    def dim(self):
+        return self.tensor.dim()
+
+    def is_contiguous(self):
+        return self.tensor.is_contiguous()
+
+    def materialize(self, out=None):
+        t = self.tensor
+        o = torch.empty_like(t) if out is None else out
+        B = t.shape[0]
+        L.check(L.lib().rgbnm_mixup(L.dt_of(t.dtype), L.dt_of(o.dtype), t.data_ptr(), o.data_ptr(), self.lam.data_ptr(), B,
+                                    t.numel() // B, L.stream()), "mixup")
+        return o
+
+
 class RandomMixup_DCT(torch.nn.Module):
     """Roll-by-one batch mixup of (Y, CbCr) and labels; lambda ~ Dirichlet(alpha, alpha) sorted descending
     (cls_transforms.py:135-182).  As in the reference (:168) lambda is drawn on the HOST from torch's CPU generator -- the same
@@ -24,10 +54,18 @@ class RandomMixup_DCT(torch.nn.Module):
             raise ValueError("Alpha param can't be zero.")
         self.num_classes, self.alpha, self.inplace = num_classes, alpha, inplace
         self.out_dtype = None   # None: keep the input dtype
+        # lazy = True: the batch items come back as LazyMixed (un-mixed tensor + lambda) for a rgb-no-more_amd model to mix while
+        # it loads them -- same bits, two launches and one round trip of the batch less per step; the target is mixed at once
+        self.lazy = False
 
-    def sample_lambda(self, device):
+    def draw_lambda(self):
+        """The reference's own draw on the CPU generator (cls_transforms.py:168): (lambda, 1 - lambda) sorted descending, fp32."""
         lam, _ = torch._sample_dirichlet(torch.tensor([self.alpha, self.alpha])).sort(descending=True)
-        lam = lam.to(torch.float32)
+        return lam.to(torch.float32).contiguous()
+
+    def sample_lambda(self, device, out=None):
+        """out: a device tensor (2 floats) to receive the draw (a static buffer of a captured HIP graph) instead of a ring slot."""
+        lam = self.draw_lambda()
         device = torch.device(device)
         if device.type != "cuda":
             return lam.contiguous()
@@ -44,15 +82,16 @@ class RandomMixup_DCT(torch.nn.Module):
             st["ev"][i].synchronize()          # the copy that last used this pinned slot (16 steps ago) has long completed
             L.HOST_WAIT["sec"] += time.perf_counter() - t0
         st["host"][i].copy_(lam)
-        st["dev"][i].copy_(st["host"][i], non_blocking=True)
+        dst = st["dev"][i] if out is None else out
+        dst.copy_(st["host"][i], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         st["ev"][i] = ev
-        return st["dev"][i]
+        return dst
 
     def forward(self, batch, target: Tensor, lam: Tensor = None, out=None) -> Tuple[Tensor, Tensor]:
         """out: optional (tensors for the mixed batch items ..., tensor for the mixed target) to write into (static buffers of a
-        captured HIP graph); default: fresh tensors."""
+        captured HIP graph; None entries for items that come back as LazyMixed); default: fresh tensors."""
         if target.ndim != 1:
             raise ValueError(f"Target ndim should be 1. Got {target.ndim}")
         if target.dtype != torch.int64:
@@ -65,6 +104,9 @@ class RandomMixup_DCT(torch.nn.Module):
         outs = []
         for k, t in enumerate(items):
             od = self.out_dtype or t.dtype
+            if self.lazy and od == t.dtype and (out is None or out[k] is None):
+                outs.append(LazyMixed(t, lam))
+                continue
             o = torch.empty(t.shape, device=t.device, dtype=od) if out is None else out[k]
             if o.shape != t.shape or o.dtype != od or not o.is_contiguous():
                 raise ValueError("out tensors must match the batch items in shape and output dtype")

@@ -21,10 +21,16 @@ namespace {
 //                      -> the lane holds T[c][4 g + r], r = 0..3
 //   Z^T = A . T^T   :  reduction index taken in the order o = 4 g + kk, so that the B-operand of step kk IS register r = kk;
 //                      A-operand A[c][4 g + kk]  -> the lane holds Z[c][4 g + r]: four consecutive outputs of row c
+// lam != null (round 6): the batch is mixed on the way in -- RandomMixup_DCT's roll-by-one (cls_transforms.py:163-176) applied to
+// the values as they are loaded: x[b] <- round_TI(lam[0] x[b] + lam[1] x[b - 1]), exactly what rgbnm_mixup writes (mix2 below is
+// its arithmetic, the rounding its output type), so that the mixed batch never exists in memory.
+__device__ __forceinline__ float mix2(float a, float c, float l0, float l1) { return fmaf(c, l1, a * l0); }
+
 template <typename TI, typename T>
-__global__ __launch_bounds__(256) void subblock_embed_kernel(const TI* __restrict__ y, const TI* __restrict__ cbcr,
+__global__ __launch_bounds__(256, 8) void subblock_embed_kernel(const TI* __restrict__ y, const TI* __restrict__ cbcr,
                                                              const float* __restrict__ A, T* __restrict__ feat,
-                                                             int B, int Hb, int Wb, int transpose_a) {
+                                                             int B, int Hb, int Wb, int transpose_a,
+                                                             const float* __restrict__ lam) {
   __shared__ float Xs[4][16][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -34,31 +40,59 @@ __global__ __launch_bounds__(256) void subblock_embed_kernel(const TI* __restric
     a1[kk] = transpose_a ? A[(4 * kk + g) * 16 + c] : A[c * 16 + 4 * kk + g];
     a2[kk] = transpose_a ? A[(4 * g + kk) * 16 + c] : A[c * 16 + 4 * g + kk];
   }
-  const int ph_n = Hb / 2, pw_n = Wb / 2;
-  const long long npatch = (long long)B * ph_n * pw_n;
-  // a wave walks patches with the grid's stride (the launcher caps the grid): the eight A operands are loaded once per wave, not
-  // once per patch (50 k waves x 8 table loads were 4 x the payload in L2 traffic)
+  const int ph_n = Hb / 2, pw_n = Wb / 2, npos = ph_n * pw_n;
+  const long long npatch = (long long)B * npos;
+  // A wave owns a CONTIGUOUS run of the patch list taken position-major, image-minor (q = pos * B + b): the eight A operands are
+  // loaded once per wave, the inputs of the next THREE patches are in flight while one is converted (the kernel is bound by bytes in
+  // flight: 768 B per patch and wave; one patch ahead ran at 2 TB/s), and with mixing on a patch's rolled partner (image b - 1, same
+  // position) is the patch the wave converted just before -- every input is loaded once.
   const int pdh = lane >> 5, pdw = (lane >> 4) & 1, l16 = lane & 15;
   const int p1 = l16 >> 1, p2 = (l16 & 1) * 4;
   const int e0 = lane * 2, cc = e0 >> 6, k = e0 & 63;
+  const bool mixed = lam != nullptr;
+  const float l0 = mixed ? lam[0] : 1.f, l1 = mixed ? lam[1] : 0.f;
+  const size_t ypi = (size_t)Hb * Wb * 64, cpi = (size_t)2 * npos * 64;      // elements per image
   // luma: 4 values per lane; chroma: 128 values, 2 per lane (identity sub-block conversion for 8x8 chroma patches)
-  auto fetch = [&](long long patch, f32x4& v, float& c0, float& c1) {
-    const int b = (int)(patch / (ph_n * pw_n));
-    const int rem = (int)(patch % (ph_n * pw_n));
-    const int ph = rem / pw_n, pw = rem % pw_n;
-    v = load4<TI>(y + ((((size_t)b * Hb + 2 * ph + pdh) * Wb) + 2 * pw + pdw) * 64 + l16 * 4);
-    const TI* cs = cbcr + ((((size_t)b * 2 + cc) * ph_n + ph) * pw_n + pw) * 64 + k;
-    c0 = to_f32(cs[0]);
-    c1 = to_f32(cs[1]);
+  // (inputs in flight are kept as loaded -- 3 registers per bf16 patch -- and widened where they are used)
+  struct alignas(2 * sizeof(TI)) TI2 { TI a, b; };
+  struct Raw { typename Vec4<TI>::type v; TI2 c; };
+  auto fetch = [&](int pos, int b, Raw& r) {
+    const int ph = pos / pw_n, pw = pos % pw_n;
+    r.v = *reinterpret_cast<const typename Vec4<TI>::type*>(y + b * ypi + ((size_t)(2 * ph + pdh) * Wb + 2 * pw + pdw) * 64 + l16 * 4);
+    r.c = *reinterpret_cast<const TI2*>(cbcr + b * cpi + (((size_t)cc * ph_n + ph) * pw_n + pw) * 64 + k);
   };
-  const long long stride = (long long)gridDim.x * 4;
-  long long patch = (long long)blockIdx.x * 4 + w;
-  if (patch >= npatch) return;
-  f32x4 v, vn = {0.f, 0.f, 0.f, 0.f};
-  float c0, c1, c0n = 0.f, c1n = 0.f;
-  fetch(patch, v, c0, c1);
-  for (; patch < npatch; patch += stride) {
-    if (patch + stride < npatch) fetch(patch + stride, vn, c0n, c1n);      // the next patch's values fly during this one's products
+  // (32-bit index arithmetic throughout, the launcher checks the sizes: 64-bit divisions by run-time values were a third of the
+  // kernel's instructions; the fetch cursor (fpos, fb) and the consume cursor (pos, b) are advanced, not re-derived)
+  const int nwaves = gridDim.x * 4, per = ((int)npatch + nwaves - 1) / nwaves;
+  const int q0 = (blockIdx.x * 4 + w) * per, q1 = min(q0 + per, (int)npatch);
+  if (q0 >= q1) return;
+  int pos = q0 / B, b = q0 - pos * B;
+  int fpos = pos, fb = b, fq = q0;
+  auto fetch_next = [&](Raw& r) {
+    if (fq < q1) fetch(fpos, fb, r);
+    ++fq;
+    if (++fb == B) { fb = 0; ++fpos; }
+  };
+  Raw r0 = {}, r1 = {}, r2 = {}, prev = {};
+  fetch_next(r0);
+  fetch_next(r1);
+  fetch_next(r2);
+  for (int q = q0; q < q1; ++q) {
+    const int patch = b * npos + pos;                           // row of feat: 'b h w'
+    Raw cur = r0;
+    r0 = r1;
+    r1 = r2;
+    fetch_next(r2);
+    if (mixed && (q == q0 || b == 0)) fetch(pos, b == 0 ? B - 1 : b - 1, prev);   // no predecessor in this run: load the partner
+    f32x4 v = {to_f32(cur.v[0]), to_f32(cur.v[1]), to_f32(cur.v[2]), to_f32(cur.v[3])};
+    float c0 = to_f32(cur.c.a), c1 = to_f32(cur.c.b);
+    if (mixed) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = to_f32(from_f32<TI>(mix2(v[e], to_f32(prev.v[e]), l0, l1)));
+      c0 = to_f32(from_f32<TI>(mix2(c0, to_f32(prev.c.a), l0, l1)));
+      c1 = to_f32(from_f32<TI>(mix2(c1, to_f32(prev.c.b), l0, l1)));
+      prev = cur;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) Xs[w][8 * pdh + p1][8 * pdw + p2 + e] = v[e];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the wave's own LDS rows (no other wave touches Xs[w])
@@ -78,7 +112,7 @@ __global__ __launch_bounds__(256) void subblock_embed_kernel(const TI* __restric
       pr.b = from_f32<T>(c1);
       *reinterpret_cast<Pair*>(dst + 256 + e0) = pr;
     }
-    v = vn; c0 = c0n; c1 = c1n;
+    if (++b == B) { b = 0; ++pos; }
   }
 }
 
@@ -221,7 +255,7 @@ __global__ void mixup_kernel(const TI* __restrict__ in, TO* __restrict__ out, co
     const f32x4 a = load4<TI>(in + i), c = load4<TI>(in + pb * per + r);
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = a[e] * l0 + c[e] * l1;
+    for (int e = 0; e < 4; ++e) o[e] = mix2(a[e], c[e], l0, l1);
     store4<TO>(out + i, o);
   }
 }
@@ -295,13 +329,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 extern "C" {
 
-int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* conv16,
-                         void* feat, int B, int Hb, int Wb, int transpose_a, void* stream) {
+int rgbnm_subblock_embed_mix(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* lam_dev, const float* conv16,
+                             void* feat, int B, int Hb, int Wb, int transpose_a, void* stream) {
   if (!y || !cbcr || !conv16 || !feat || B <= 0 || Hb <= 0 || Wb <= 0 || (Hb & 1) || (Wb & 1)) return RGBNM_EINVAL;
   const long long npatch = (long long)B * (Hb / 2) * (Wb / 2);
+  if (npatch * 384 >= (1LL << 31)) return RGBNM_EINVAL;                    // 32-bit index arithmetic in the kernel
   const dim3 grid((unsigned)min(cdivl(npatch, 4), 2048LL)), blk(256);      // 256 CUs x 8 workgroups: one round, waves loop
   hipStream_t st = (hipStream_t)stream;
-#define SB(TI, TO) hipLaunchKernelGGL((subblock_embed_kernel<TI, TO>), grid, blk, 0, st, (const TI*)y, (const TI*)cbcr, conv16, (TO*)feat, B, Hb, Wb, transpose_a)
+#define SB(TI, TO) hipLaunchKernelGGL((subblock_embed_kernel<TI, TO>), grid, blk, 0, st, (const TI*)y, (const TI*)cbcr, conv16, (TO*)feat, B, Hb, Wb, transpose_a, lam_dev)
   if (in_dtype == DT_F32 && out_dtype == DT_F32) SB(float, float);
   else if (in_dtype == DT_F32 && out_dtype == DT_BF16) SB(float, bf16);
   else if (in_dtype == DT_BF16 && out_dtype == DT_BF16) SB(bf16, bf16);
@@ -310,6 +345,11 @@ int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void*
 #undef SB
   LAUNCH_CHECK();
   return RGBNM_OK;
+}
+
+int rgbnm_subblock_embed(int in_dtype, int out_dtype, const void* y, const void* cbcr, const float* conv16,
+                         void* feat, int B, int Hb, int Wb, int transpose_a, void* stream) {
+  return rgbnm_subblock_embed_mix(in_dtype, out_dtype, y, cbcr, nullptr, conv16, feat, B, Hb, Wb, transpose_a, stream);
 }
 
 int rgbnm_softxent(int dl_dtype, const float* logits, const float* soft_target, const long long* hard_target,

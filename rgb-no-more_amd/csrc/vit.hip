@@ -355,16 +355,22 @@ int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* c, const rgbnm_block_acts* a, co
   return rgbnm_vit_blocks_bwd_dw(c, 1, &a, &g, &s, &dy, &part2, &part1, st);
 }
 
-int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* c, int in_dtype, const void* y, const void* cbcr, const float* conv16,
-                          const void* wpe, const float* bpe, const float* pos, void* feat, void* x0, int Hb, int Wb,
-                          void* st) {
+int rgbnm_patch_embed_fwd_mix(const rgbnm_vit_cfg* c, int in_dtype, const void* y, const void* cbcr, const float* lam_dev,
+                              const float* conv16, const void* wpe, const float* bpe, const float* pos, void* feat, void* x0, int Hb,
+                              int Wb, void* st) {
   if (!c) return RGBNM_EINVAL;
   const int M = c->B * c->N;
   if ((Hb / 2) * (Wb / 2) != c->N) return RGBNM_EINVAL;
-  TRY(rgbnm_subblock_embed(in_dtype, c->dtype, y, cbcr, conv16, feat, c->B, Hb, Wb, 0, st));
+  TRY(rgbnm_subblock_embed_mix(in_dtype, c->dtype, y, cbcr, lam_dev, conv16, feat, c->B, Hb, Wb, 0, st));
   TRY(rgbnm_gemm_nt(c->dtype, RGBNM_EPI_POS, feat, 384, wpe, 384, x0, c->E, bpe, 0, 0, 0, 0, pos, c->N, M, c->E, 384,
                     0, st));
   return RGBNM_OK;
+}
+
+int rgbnm_patch_embed_fwd(const rgbnm_vit_cfg* c, int in_dtype, const void* y, const void* cbcr, const float* conv16,
+                          const void* wpe, const float* bpe, const float* pos, void* feat, void* x0, int Hb, int Wb,
+                          void* st) {
+  return rgbnm_patch_embed_fwd_mix(c, in_dtype, y, cbcr, nullptr, conv16, wpe, bpe, pos, feat, x0, Hb, Wb, st);
 }
 
 int rgbnm_patch_embed_bwd(const rgbnm_vit_cfg* c, const void* dx0, const void* feat, float* dwpe, float* dbpe,

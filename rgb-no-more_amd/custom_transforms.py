@@ -754,7 +754,7 @@ def _params_to_device(t, host, dev):
     return pdev
 
 
-def apply_packed(transform, Yq, CbCrq, quant, packed, nops, y_off=None, c_off=None, grid=None):
+def apply_packed(transform, Yq, CbCrq, quant, packed, nops, y_off=None, c_off=None, grid=None, out=None):
     """Run the augment kernels with an AUG_DTYPE array produced by FastParamSampler.sample().
     y_off / c_off (device int64 (B,)) + grid=(Hy, Wy): Yq / CbCrq are the flat HOST-CROPPED buffers of
     dct_manip.read_coefficients_batch_crop (image b's crop box alone at Yq[y_off[b]:]); same output, bit for bit."""
@@ -775,8 +775,14 @@ def apply_packed(transform, Yq, CbCrq, quant, packed, nops, y_off=None, c_off=No
     wsb = L.lib().rgbnm_dct_augment_workspace_ex(B, S)
     if t._ws is None or t._ws.numel() < wsb or t._ws.device != dev:
         t._ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-    oy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=t.out_dtype)
-    oc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=t.out_dtype)
+    if out is None:
+        oy = torch.empty(B, 1, S, S, 8, 8, device=dev, dtype=t.out_dtype)
+        oc = torch.empty(B, 2, S // 2, S // 2, 8, 8, device=dev, dtype=t.out_dtype)
+    else:                                   # caller-owned outputs (static buffers of a captured HIP graph)
+        oy, oc = out
+        if (tuple(oy.shape) != (B, 1, S, S, 8, 8) or tuple(oc.shape) != (B, 2, S // 2, S // 2, 8, 8) or oy.dtype != t.out_dtype
+                or oc.dtype != t.out_dtype or not oy.is_contiguous() or not oc.is_contiguous()):
+            raise ValueError("out tensors must be contiguous (B,1,S,S,8,8) / (B,2,S/2,S/2,8,8) in the transform's out_dtype")
     if y_off is None:
         L.check(L.lib().rgbnm_dct_augment_ex(Yq.data_ptr(), L.ptr(CbCrq), quant.data_ptr(), pdev.data_ptr(),
                                              host.ctypes.data, t._conv16.data_ptr(), L.ptr(filt), oy.data_ptr(),

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "rgbnm_attention_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "rgbnm_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "rgbnm_subblock_embed": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rgbnm_subblock_embed_mix": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbnm_dct_augment_workspace": (_sz, [_i]),
     "rgbnm_dct_augment": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz,
                                _vp]),
@@ -151,6 +152,7 @@ PROTOTYPES = {
     "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
                                  _vp, _vp]),
     "rgbnm_patch_embed_fwd": (_i, [_P(VitCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "rgbnm_patch_embed_fwd_mix": (_i, [_P(VitCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "rgbnm_patch_embed_bwd": (_i, [_P(VitCfg), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rgbnm_head_fwd": (_i, [_P(VitCfg), _P(HeadParams), _P(HeadActs), _vp]),
     "rgbnm_head_bwd": (_i, [_P(VitCfg), _P(HeadParams), _P(HeadActs), _P(HeadGrads), _vp, _vp, _vp, _vp, _vp, _sz,

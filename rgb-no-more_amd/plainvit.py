@@ -23,6 +23,7 @@ from torch import nn
 
 from . import dct_ops as dops
 from . import lib as L
+from .cls_transforms import LazyMixed
 from .flatparams import FlatParamModule, align as _align
 
 
@@ -263,13 +264,14 @@ class _FwdState:
 # ------------------------------------------------------------------ autograd nodes
 class _PatchEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, cbcr, st, w, b):
+    def forward(ctx, y, cbcr, st, w, b, lam=None):
         m, a = st.model, st.arena
         Hb, Wb = y.shape[2], y.shape[3]
-        L.check(L.lib().rgbnm_patch_embed_fwd(C.byref(a.cfg), L.dt_of(y.dtype), y.data_ptr(), cbcr.data_ptr(),
-                                              m._conv16.data_ptr(), m._sh_ptr("pe", "ws"), b.data_ptr(),
-                                              m._pos.data_ptr(), a.feat.data_ptr(), a.xbuf(0).data_ptr(), Hb, Wb,
-                                              L.stream()), "patch_embed_fwd")
+        # lam: the device lambda of a cls_transforms.LazyMixed batch -- the mixup is applied while the sub-block kernel loads
+        L.check(L.lib().rgbnm_patch_embed_fwd_mix(C.byref(a.cfg), L.dt_of(y.dtype), y.data_ptr(), cbcr.data_ptr(), L.ptr(lam),
+                                                  m._conv16.data_ptr(), m._sh_ptr("pe", "ws"), b.data_ptr(),
+                                                  m._pos.data_ptr(), a.feat.data_ptr(), a.xbuf(0).data_ptr(), Hb, Wb,
+                                                  L.stream()), "patch_embed_fwd")
         ctx.st = st
         return a.xbuf(0).detach()   # fresh tensor object per call (arena buffers are reused across steps)
 
@@ -290,7 +292,7 @@ class _PatchEmbedFn(torch.autograd.Function):
         st.end_hold()
         if m._grad_sync is not None:            # last gradients of the step: flush the exchange (parallel.py)
             m._grad_sync.ready(st.gbuf, ["patchembed.projection.0.weight", "patchembed.projection.0.bias"], last=True)
-        return None, None, None, gw, gb
+        return None, None, None, gw, gb, None
 
 
 _PE2_NAMES = ["patchembed.projection_Y.1.weight", "patchembed.projection_Y.1.bias", "patchembed.projection_C.1.weight",
@@ -1069,6 +1071,16 @@ class ViT(FlatParamModule):
         """x: Y coefficients (B,1,28,28,8,8); cbcr: (B,2,14,14,8,8); fp32 or bf16 (reference: plainvit.py:601-611)."""
         if cbcr is None:
             raise ValueError("DCT path needs both Y and CbCr tensors")
+        lam = None
+        if isinstance(x, LazyMixed) or isinstance(cbcr, LazyMixed):
+            # a batch RandomMixup_DCT(lazy=True) left un-mixed: the group patch embedding mixes while it loads; every other
+            # embedding gets the mixed tensors the ordinary way
+            if (isinstance(x, LazyMixed) and isinstance(cbcr, LazyMixed) and x.lam.data_ptr() == cbcr.lam.data_ptr()
+                    and self.embed_kind == "group"):
+                lam, x, cbcr = x.lam, x.tensor, cbcr.tensor
+            else:
+                x = x.materialize() if isinstance(x, LazyMixed) else x
+                cbcr = cbcr.materialize() if isinstance(cbcr, LazyMixed) else cbcr
         L.require_cuda(x, cbcr)
         if x.dim() != 6 or x.shape[1:] != (1, 28, 28, 8, 8) or cbcr.shape[1:] != (2, 14, 14, 8, 8):
             raise ValueError(f"expected Y (B,1,28,28,8,8) and CbCr (B,2,14,14,8,8), got {tuple(x.shape)} {tuple(cbcr.shape)}")
@@ -1103,7 +1115,7 @@ class ViT(FlatParamModule):
         named = self._named
         if self.embed_kind == "group":
             h = _PatchEmbedFn.apply(x, cbcr, st, named["patchembed.projection.0.weight"],
-                                    named["patchembed.projection.0.bias"])
+                                    named["patchembed.projection.0.bias"], lam)
         elif self.embed_kind == "sep_sub":
             h = _PatchEmbed2Fn.apply(x, cbcr, st, *[named[n] for n in _PE2_NAMES])
         elif self.embed_kind == "sep":

@@ -592,6 +592,9 @@ class SwinTransformerV2(FlatParamModule):
     def forward(self, y, cbcr=None):
         if cbcr is None:
             raise ValueError("DCT path needs both Y and CbCr tensors")
+        from .cls_transforms import LazyMixed          # a batch RandomMixup_DCT(lazy=True) left un-mixed: mixed here, the ordinary way
+        y = y.materialize() if isinstance(y, LazyMixed) else y
+        cbcr = cbcr.materialize() if isinstance(cbcr, LazyMixed) else cbcr
         L.require_cuda(y, cbcr)
         B, _, Hb, Wb, _, _ = y.shape
         res = self.patches_resolution[0]

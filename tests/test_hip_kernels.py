@@ -308,6 +308,61 @@ def test_cross_entropy_scaled_backward():
     assert relerr(zz.grad, zr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B", [1, 2, 7])
+def test_subblock_embed_mix_equals_mixup_then_subblock_embed(dt, B):
+    """rgbnm_subblock_embed_mix (round 6): RandomMixup_DCT's roll-by-one applied while the sub-block kernel loads -- the same bits
+    as rgbnm_mixup (input dtype -> input dtype) followed by rgbnm_subblock_embed, for the luma tiles and the chroma halves; B = 1
+    mixes an image with itself, like torch.roll on a batch of one."""
+    y = dev(detfill.normalish((B, 1, 28, 28, 8, 8), 61), dt)
+    c = dev(detfill.normalish((B, 2, 14, 14, 8, 8), 62), dt)
+    lam = dev(np.array([0.8125, 0.1875], dtype=np.float32) if B != 7 else np.array([0.61803, 0.38197], dtype=np.float32))
+    A = rg.dct_ops.generate_conversion_matrix(8, 2).to(DEV).contiguous()
+    my, mc = torch.empty_like(y), torch.empty_like(c)
+    for t, o in ((y, my), (c, mc)):
+        L.check(L.lib().rgbnm_mixup(L.dt_of(dt), L.dt_of(dt), t.data_ptr(), o.data_ptr(), lam.data_ptr(), B, t.numel() // B, L.stream()))
+    for odt in DTS:
+        want = torch.empty(B * 196, 384, device=DEV, dtype=odt)
+        got = torch.full_like(want, 7.0)
+        L.check(L.lib().rgbnm_subblock_embed(L.dt_of(dt), L.dt_of(odt), my.data_ptr(), mc.data_ptr(), A.data_ptr(), want.data_ptr(),
+                                             B, 28, 28, 0, L.stream()))
+        L.check(L.lib().rgbnm_subblock_embed_mix(L.dt_of(dt), L.dt_of(odt), y.data_ptr(), c.data_ptr(), lam.data_ptr(), A.data_ptr(),
+                                                 got.data_ptr(), B, 28, 28, 0, L.stream()))
+        assert torch.equal(got, want)
+    # and the mixed values themselves against the reference expression (cls_transforms.py:165-176) in fp32
+    ref = y.float() * lam[0] + y.float().roll(1, 0) * lam[1]
+    assert (my.float() - ref).abs().max() <= (1e-6 if dt == torch.float32 else 2e-2)
+
+
+def test_lazy_mixup_through_the_model():
+    """RandomMixup_DCT(lazy=True): the model mixes while it loads; logits and every gradient the same bits as with the mixed tensors."""
+    B = 6
+    m = rg.ViT(3, 16, 192, depth=2, n_classes=1000, drop_p=0.0, device=DEV, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
+    m.compute_dtype = torch.bfloat16
+    y = dev(detfill.normalish((B, 1, 28, 28, 8, 8), 63), torch.bfloat16)
+    c = dev(detfill.normalish((B, 2, 14, 14, 8, 8), 64), torch.bfloat16)
+    lab = torch.from_numpy(detfill.integers((B,), 65, 0, 998, np.int64)).to(DEV)
+    lam = dev(np.array([0.7, 0.3], dtype=np.float32))
+    mix = rg.cls_transforms.RandomMixup_DCT(1000, alpha=0.2)
+    res = []
+    for lazy in (False, True):
+        mix.lazy = lazy
+        (my, mc), mt = mix((y, c), lab, lam=lam)
+        assert isinstance(my, rg.cls_transforms.LazyMixed) == lazy
+        m.zero_grad()
+        logits = m(my, mc)
+        rg.cls_transforms.cross_entropy(logits, mt, grad_dtype=torch.bfloat16).backward()
+        sync()
+        res.append((logits.detach().clone(), mt.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    bad = [n for n in res[0][2] if not torch.equal(res[0][2][n], res[1][2][n])]
+    assert not bad, bad[:4]
+    # a consumer that is not the group patch embedding gets the mixed tensor
+    mix.lazy = False
+    (ey, _), _ = mix((y, c), lab, lam=lam)
+    assert torch.equal(my.materialize(), ey)
+
+
 def test_mixup_golden(golden):
     g = golden("g13_mixup.npz")
     mix = rg.cls_transforms.RandomMixup_DCT(10, alpha=0.2)

@@ -1,4 +1,7 @@
 export TMPDIR=/tmp
-OUT=gpurun_out/r06_a; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_chain_fwd.py tests/test_vit_model.py tests/test_chain_bwd.py tests/test_held_reductions.py tests/test_fastpath_model.py tests/test_reentrancy.py tests/test_train_loop_amp.py -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest.txt
-bash tools/gpu.sh bench 3 2>&1 | tee $OUT/bench.txt
+OUT=gpurun_out/r06_c; mkdir -p $OUT
+for r in 1 2 3; do
+bash tools/gpu.sh bench 1 2>&1 | cut -c1-40 | sed 's/^/trace   /' | tee -a $OUT/bench2.txt
+bash tools/gpu.sh bench 1 --no-trace 2>&1 | cut -c1-40 | sed 's/^/notrace /' | tee -a $OUT/bench2.txt
+bash tools/gpu.sh bench 1 --no-trace --no-graph 2>&1 | cut -c1-40 | sed 's/^/nograph /' | tee -a $OUT/bench2.txt
+done
