@@ -277,7 +277,8 @@ def parity_check(arch, cdt, dev):
 
 def decode_leg(n=16):
     """Host entropy-decode cost of S-jpeg files (512x512, 4:2:0, q90) with the PRODUCT reader (a1 stays host C),
-    one thread: lets the CPU baseline be quoted decode-inclusive, like the reference's own end-to-end figure."""
+    one thread: lets the CPU baseline be quoted decode-inclusive, like the reference's own end-to-end figure.  (The reference's own
+    reader, oracle/_ref, is only loaded by the CPU test tests/test_reader_cpu.py: nothing built from the reference runs here.)"""
     try:
         import tempfile
         import numpy as np
@@ -301,22 +302,7 @@ def decode_leg(n=16):
     for p in paths:
         dm.read_coefficients(p)
     prod = (time.perf_counter() - t0) / n
-    # ... and the REFERENCE's own reader (oracle/_ref: its dct_manip.cpp compiled by oracle/build_ref.py; the prebuilt .so travels
-    # with the snapshot for exactly this leg) on the same files, same thread count: the a1 row's CPU figure is the reference's code
-    ref = None
-    try:
-        from oracle import build_ref
-        rmod = build_ref.load_ref()
-        if rmod is not None:
-            for p in paths[:2]:
-                rmod.read_coefficients(p)
-            t0 = time.perf_counter()
-            for p in paths:
-                rmod.read_coefficients(p)
-            ref = (time.perf_counter() - t0) / n
-    except Exception:       # noqa: BLE001  (the checker is optional on the box)
-        ref = None
-    return prod, ref
+    return prod
 
 
 def _cgroup_cpu_quota():
@@ -707,13 +693,17 @@ def main():
             if pick:
                 sync_schedule, fs.bucket_elems, use_graph = pick[0][0], pick[0][1], pick[0][2]
                 use_deferred = "next step's data stage" in sync_schedule
-    TAG_NT = 1
-    # every traced kernel class: (tag, key in profiles/pmc_traffic*.json, description)
-    TRACED = ((6, "chain_bwd", "vit_chain_bwd_kernel: the data path of the whole encoder backward, one launch, one workgroup per image"),
-              (5, "chain_fwd", "vit_chain_fwd_kernel: the whole encoder forward, one launch, one workgroup per image"),
-              (2, "gemm_tn", "gemm_tn_pipe: the four weight-gradient GEMMs of a block as one grouped launch"),
-              (1, "gemm_nt", "gemm_nt family (gemm_nt_wres / gemm_nt_kpipe / gemm_nt / fused MLP: nn.Linear forward + dX GEMMs with their fused epilogues)"))
-    TRACE_MASK = sum(1 << t for t, _, _ in TRACED)
+    # every traced kernel class: (tag, key in profiles/pmc_traffic*.json / pmc_mfma*.json, the roof SURVEY 8d names for it, description)
+    TRACED = ((6, "chain_bwd", "mfma", "vit_chain_bwd_kernel: the data path of the whole encoder backward, one launch, one workgroup per image"),
+              (5, "chain_fwd", "mfma", "vit_chain_fwd_kernel: the whole encoder forward, one launch, one workgroup per image"),
+              (2, "gemm_tn", "mfma", "gemm_tn_pipe: weight-gradient GEMMs as grouped launches"),
+              (1, "gemm_nt", "mfma", "gemm_nt family (gemm_nt_wres / gemm_nt_kpipe / gemm_nt / fused MLP: nn.Linear forward + dX GEMMs with their fused epilogues)"),
+              (3, "attn_fwd", "mfma", "attention forward (per-operation path)"),
+              (4, "attn_bwd", "mfma", "attention backward (per-operation path)"),
+              (7, "augment", "hbm", "dct_resize + dct_randaug: dequantise, crop, resize, flip, two RandAugment ops, ToRange (SURVEY 8d: crop box in, S x S image out)"),
+              (8, "subblock_embed", "hbm", "subblock_embed: batch mixup on load + sub-block reshuffle (SURVEY 8d: blocks in, 196 x 384 features out)"),
+              (9, "optimizer", "hbm", "sqnorm + adamw: clip_grad_norm_ + AdamW + WeightDecay over the flat buffers (28 B per parameter + the gradient again for the norm)"))
+    TRACE_MASK = sum(1 << t for t, _, _, _ in TRACED)
     trace_on = (not a.no_trace) and rank == 0
     # The set-up above left a few hundred thousand long-lived Python objects (modules, golden vectors, ctypes tables).  A full
     # collection of that heap takes the interpreter 70 - 100 ms, and the allocation count of the eager steps triggered one at a fixed
@@ -733,7 +723,7 @@ def main():
         step(eager=trace_on and i == 0)
         if trace_on and i == 0:
             lib.rgbnm_set_option(b"trace", 0)
-            for t_, _, _ in TRACED:
+            for t_, _, _, _ in TRACED:
                 lib.rgbnm_trace_collect(t_, None, None, None, None)
     if use_deferred:
         deferred.finish(opt.step)             # the timed region starts with nothing in flight: K exchanges and K optimizer steps in it
@@ -787,65 +777,81 @@ def main():
         roof_all = []
         whole = None
         if not a.no_trace:
-            # HBM bytes per launch from the PMC counters cannot be read inside this process: they come from separate
-            # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools/gpu.sh pass, corrected as
-            # MI355X_MICROARCH.md prescribes) whose summary is committed under profiles/
+            # HBM bytes per launch and the MFMA-op counters cannot be read inside this process: they come from separate `rocprofv3
+            # --pmc` passes of this same command (tools/gpu.sh pass, corrected as MI355X_MICROARCH.md prescribes) whose summaries are
+            # committed under profiles/ WITH the hash of the kernel sources they were measured on; a figure whose hash differs from
+            # the tree this process runs from is marked "stale": true
+            here = L.source_hash()
             tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.arch}.json")
             if not os.path.exists(tpath) and a.arch == "vitti":
                 tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             tjs = json.load(open(tpath)) if os.path.exists(tpath) else {}
-            # attainable peaks measured on an MI355X box by tools/calib.py (nominal peaks are what `frac` is priced against)
             mpath = os.path.join(ROOT, "profiles", "pmc_mfma.json" if a.arch == "vitti" else f"pmc_mfma_{a.arch}.json")
-            mjs = (json.load(open(mpath)).get("classes") or {}) if os.path.exists(mpath) else {}
+            mfile = json.load(open(mpath)) if os.path.exists(mpath) else {}
+            mjs = mfile.get("classes") or {}
+
+            def sourced(js, path):
+                at = (js.get("measured_at") or {}) if js else {}
+                return {"file": os.path.relpath(path, ROOT), "measured_at": at or None,
+                        "stale": (at.get("csrc_sha16") != here) if js else None}
+            tsrc, msrc = sourced(tjs, tpath), sourced(mfile, mpath)
+            # attainable peaks measured on an MI355X box by tools/calib.py (nominal peaks are what `frac` is priced against)
             attain = None
-            for cal in ("calibration.json", "r04_calibration.json", "r01_calibration.json"):
-                cpath = os.path.join(ROOT, "profiles", cal)
-                if os.path.exists(cpath):
-                    cj = json.load(open(cpath))
-                    attain = {"hbm_copy_GBs": cj.get("hbm_copy_GBps[1 GiB]"), "hbm_read_GBs": cj.get("hbm_read_GBps[1 GiB]"),
-                              "hbm_write_GBs": cj.get("hbm_write_GBps[1 GiB]"),
-                              "mfma_bf16_TFLOPs": cj.get("mfma_bf16_tflops[1 workgroup (4 waves) per CU]"), "source": "profiles/" + cal}
-                    break
+            cpath = os.path.join(ROOT, "profiles", "calibration.json")
+            if os.path.exists(cpath):
+                cj = json.load(open(cpath))
+                attain = {"hbm_copy_GBs": cj.get("hbm_copy_GBps[1 GiB]"), "hbm_read_GBs": cj.get("hbm_read_GBps[1 GiB]"),
+                          "hbm_write_GBs": cj.get("hbm_write_GBps[1 GiB]"),
+                          "mfma_bf16_TFLOPs": cj.get("mfma_bf16_tflops[1 workgroup (4 waves) per CU]"),
+                          "source": sourced(cj, cpath)}
+
+            def counter_bytes(key):
+                if key == "augment":
+                    parts = [tjs.get("dct_resize_bytes_per_launch"), tjs.get("dct_randaug_bytes_per_launch")]
+                elif key == "optimizer":
+                    parts = [tjs.get("sqnorm_bytes_per_launch"), tjs.get("adamw_bytes_per_launch")]
+                else:
+                    return tjs.get(key + "_bytes_per_launch")
+                return sum(parts) if all(v is not None for v in parts) else None
             byts_step = {}
-            for tag, key, desc in TRACED:
+            for tag, key, bound, desc in TRACED:
                 tms, fl, by, cnt = C.c_double(), C.c_double(), C.c_double(), C.c_int()
                 L.check(lib.rgbnm_trace_collect(tag, C.byref(tms), C.byref(fl), C.byref(by), C.byref(cnt)))
                 if not cnt.value:
                     continue
                 sec = tms.value / 1e3
                 gbs, tfs = by.value / sec / 1e9, fl.value / sec / 1e12
-                traffic = tjs.get(key + "_bytes_per_launch")
-                roof_all.append({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                 "traffic_source": (os.path.relpath(tpath, ROOT) + " (separate --pmc passes of this command)") if traffic else None,
-                                 "kernel": desc, "launches_per_step": cnt.value // max(1, traced_steps), "traced_steps": traced_steps,
-                                 "avg_launch_us": round(1e3 * tms.value / cnt.value, 2),
-                                 "us_per_step": round(1e3 * tms.value / max(1, traced_steps), 1),
-                                 "algorithmic_bytes_per_launch": round(by.value / cnt.value),
-                                 "algorithmic_flops_per_launch": round(fl.value / cnt.value),
-                                 "kernel_tflops": round(tfs, 1), "kernel_mfma_frac": round(tfs / peak, 4),
-                                 # the SAME kernel against the matrix-pipe roof (SURVEY 8d / north_star name it for the model step):
-                                 # useful FLOPs of the timed launches / dense peak, and the hardware-counter figure (MFMA ops issued,
-                                 # padding rows included) from the committed --pmc pass of this command
-                                 "mfma": {"bound": "mfma", "achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s",
-                                          "frac": round(tfs / peak, 4),
-                                          "counter_frac": (mjs.get(key) or {}).get("mfma_util_vs_2.5PF"),
-                                          "counter_source": (os.path.relpath(mpath, ROOT) + " (file-sourced: separate --pmc pass)") if key in mjs else None},
-                                 "attainable_peaks_measured": attain})
+                traffic = counter_bytes(key)
+                hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "algorithmic_bytes_per_launch": round(by.value / cnt.value),
+                       "counter_frac": round(traffic * cnt.value / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
+                mf = {"bound": "mfma", "achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tfs / peak, 4),
+                      "algorithmic_flops_per_launch": round(fl.value / cnt.value),
+                      # MFMA ops issued (hardware counter of the committed --pmc pass: padding rows and recomputed products included)
+                      "counter_frac": (mjs.get(key) or {}).get("mfma_util_vs_2.5PF"), "counter_source": msrc if key in mjs else None}
+                # the model step's kernels are priced against the dense MFMA roof (FLOPs: 2 x MAC, backward = 2 x forward,
+                # recompute NOT counted), the augment / embed / optimizer classes against HBM; the other view rides along
+                head_, other = (mf, hbm) if bound == "mfma" else (hbm, None)
+                rec = dict(head_)
+                rec.update({"traffic": traffic, "traffic_source": tsrc if traffic else None, "kernel": desc,
+                            "launches_per_step": round(cnt.value / max(1, traced_steps), 2), "traced_steps": traced_steps,
+                            "avg_launch_us": round(1e3 * tms.value / cnt.value, 2),
+                            "us_per_step": round(1e3 * tms.value / max(1, traced_steps), 1)})
+                if other is not None:
+                    rec["hbm"] = other
+                roof_all.append(rec)
                 byts_step[key] = by.value / max(1, traced_steps)
             roof_all.sort(key=lambda r: -r["us_per_step"])
             roof = roof_all[0] if roof_all else None       # the dominant kernel (largest share of the step)
+            if roof is not None:
+                roof["attainable_peaks_measured"] = attain
             # the whole step against both roofs: algorithmic bytes = the traced kernel classes (their C entries state them) + the
-            # data stage, patch embedding and optimizer from SURVEY 8d's per-image figures; counter bytes = every dispatch of a step in
-            # the committed FETCH / WRITE passes (file-sourced, like roofline.traffic)
-            nparam = sum(p.numel() for p in model.parameters())
-            small = (0 if a.no_augment else B * 0.73e6) + nparam * 28.0
+            # patch-embedding GEMM; counter bytes = every dispatch of a step in the committed FETCH / WRITE passes (file-sourced)
+            alg = sum(byts_step.values())
             if not swin:
-                small += B * 0.30e6 + B * 196 * (384 + 2 * emb) * 2.0
-            alg = sum(byts_step.values()) + small
+                alg += B * 196 * (384 + 2 * emb) * 2.0
             cnt_b = tjs.get("whole_step_bytes")
-            whole = {"algorithmic_bytes": round(alg), "counter_bytes": cnt_b,
-                     "counter_source": (os.path.relpath(tpath, ROOT) + " (file-sourced)") if cnt_b else None,
+            whole = {"algorithmic_bytes": round(alg), "counter_bytes": cnt_b, "counter_source": tsrc if cnt_b else None,
                      "frac_hbm": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "frac_hbm_counter": round(cnt_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if cnt_b else None,
                      "frac_mfma": round(step_tflops / peak, 4)}
@@ -882,19 +888,20 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(a.arch, a.cpu_baseline_images)
-            dleg = decode_leg()
-            dsec, dref = dleg if dleg is not None else (None, None)
-            if dref is not None:
-                cb["decode_ms_per_img_1thread_reference_reader"] = round(1e3 * dref, 3)      # oracle/_ref (kind "reference" for row a1)
+            dsec = decode_leg()
             if dsec is not None and cb.get("value"):
                 cb["decode_ms_per_img_1thread"] = round(1e3 * dsec, 3)
                 cb["value_incl_entropy_decode"] = round(1.0 / (1.0 / cb["value"] + dsec), 2)
                 cb["sample"] += ("; value_incl_entropy_decode adds the product reader's libjpeg coefficient read of 16 S-jpeg "
                                  "512x512 4:2:0 q90 files, one thread (BASELINE config 1 reads JPEG files)")
-            if a.arch == "vitti":
-                cb["reference_itself"] = {"value": 22.9, "unit": "images/sec", "cores": 8, "kind": "reference",
-                                          "where": "survey container (8 vCPU), the reference's own dct_manip + PyTorch CPU path on 64 "
-                                                   "S-jpeg files, batch 8, entropy decode included (BASELINE.md); it cannot run on the GPU box"}
+            # the reference ITSELF cannot run on the GPU box; tools/time_reference_cpu.py times it (BASELINE config 1) in the build
+            # container and commits the result -- quoted here as data, with where and when it was measured
+            rpath = os.path.join(ROOT, "profiles", "reference_cpu.json")
+            if a.arch == "vitti" and os.path.exists(rpath):
+                rj = json.load(open(rpath))
+                cb["reference_itself"] = {k: rj.get(k) for k in ("value", "unit", "cores", "kind", "sample", "where", "model_only_value",
+                                                                 "data_path_ms_per_img_1thread", "measured_at")}
+                cb["reference_itself"]["source"] = "profiles/reference_cpu.json (tools/time_reference_cpu.py)"
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -58,7 +58,8 @@ int rgbnm_abi_version(void);
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
 /* With option "trace" = (1 << tag) the launchers bracket kernels of that class with HIP events recorded on the launch
- * stream (tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd, 5 one-launch encoder forward, 6 one-launch encoder backward).  collect() synchronises those events and
+ * stream (tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd, 5 one-launch encoder forward, 6 one-launch encoder backward,
+ * 7 augment stage, 8 sub-block embed, 9 clip + AdamW + WeightDecay).  collect() synchronises those events and
  * returns their summed elapsed ms plus the algorithmic FLOPs / bytes of the bracketed launches, then forgets them. */
 int rgbnm_trace_collect(int tag, double* ms_total, double* flops_total, double* bytes_total, int* count);
 /* Create the events of the next n_events / 2 bracketed launches NOW (call outside a timed region: the runtime grows its signal
@@ -99,6 +100,14 @@ int rgbnm_gemm_tn_group_end(void* stream);
  * writes dW / db itself: no partial sums, no reduction.  The operands of a queued call must stay alive and unmodified, and its
  * dW / db hold nothing, until _end returns. */
 void rgbnm_gemm_tn_group_begin_n(int max_jobs);
+/* Brackets nest by joining: a _begin inside an open bracket (also the ones rgbnm_head_bwd / rgbnm_vit_block_bwd open internally)
+ * only counts, its _end neither launches nor closes anything; the jobs run at the OUTERMOST _end.  A _begin on a thread whose queue
+ * still holds jobs of a pass that died before its _end starts from an empty queue (those jobs are dropped, never launched).
+ * _begin_id names the bracket (id != 0): rgbnm_gemm_tn_group_abort(id), callable from ANY host thread, makes the thread that owns
+ * the bracket drop its queue without launching, the next time it touches it -- for callers whose backward nodes run on an autograd
+ * worker thread while the pass is found abandoned on another one (swinv2.py).  Reference: none (torch launches every GEMM at once). */
+void rgbnm_gemm_tn_group_begin_id(int max_jobs, unsigned long long id);
+void rgbnm_gemm_tn_group_abort(unsigned long long id);
 
 /* One nn.Linear in the flat fp32 master buffer and where its shadows go (offsets in elements). */
 typedef struct rgbnm_linear_desc {

@@ -14,6 +14,7 @@
 //                             LDS (147 KB): ops are applied in order (geometric ones as register-staged gathers,
 //                             photometric ones with an exact integer DC reduction), then ToRange -> fp32/bf16.
 #include "common.h"
+#include "internal.h"
 #include "../../include/rgbnm.h"
 
 #define AUG_NS aug28

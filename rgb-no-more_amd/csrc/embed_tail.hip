@@ -6,6 +6,7 @@
 //   clip_adamw_wd  : global-norm clip + AdamW(wd=0) + schedule-relative WeightDecay in one pass over flat
 //                    fp32 buffers (train.py:163-165, utils/custom_optims.py:37-42)
 #include "common.h"
+#include "internal.h"
 #include "../../include/rgbnm.h"
 
 namespace {
@@ -336,6 +337,8 @@ int rgbnm_subblock_embed_mix(int in_dtype, int out_dtype, const void* y, const v
   if (npatch * 384 >= (1LL << 31)) return RGBNM_EINVAL;                    // 32-bit index arithmetic in the kernel
   const dim3 grid((unsigned)min(cdivl(npatch, 4), 2048LL)), blk(256);      // 256 CUs x 8 workgroups: one round, waves loop
   hipStream_t st = (hipStream_t)stream;
+  // algorithmic bytes: the 28 x 28 + 2 x 14 x 14 blocks in, 196 x 384 features out, per image
+  const int tslot = rgbnm_trace_begin(TR_EMBED, 4.0 * npatch * 16 * 16 * 16, (double)npatch * 384 * ((in_dtype == DT_F32 ? 4.0 : 2.0) + (out_dtype == DT_F32 ? 4.0 : 2.0)), st);
 #define SB(TI, TO) hipLaunchKernelGGL((subblock_embed_kernel<TI, TO>), grid, blk, 0, st, (const TI*)y, (const TI*)cbcr, conv16, (TO*)feat, B, Hb, Wb, transpose_a, lam_dev)
   if (in_dtype == DT_F32 && out_dtype == DT_F32) SB(float, float);
   else if (in_dtype == DT_F32 && out_dtype == DT_BF16) SB(float, bf16);
@@ -343,6 +346,7 @@ int rgbnm_subblock_embed_mix(int in_dtype, int out_dtype, const void* y, const v
   else if (in_dtype == DT_BF16 && out_dtype == DT_F32) SB(bf16, float);
   else return RGBNM_EINVAL;
 #undef SB
+  rgbnm_trace_end(tslot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }
@@ -422,6 +426,8 @@ int rgbnm_clip_adamw_wd_step(float* p, const float* g, float* m, float* v, const
   if (workspace_bytes < NORM_BLOCKS * sizeof(float)) return RGBNM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
+  // algorithmic bytes: 28 B per parameter (p, g, m, v read; p, m, v written) + the gradient once more for the norm
+  const int tslot = rgbnm_trace_begin(TR_OPT, 0.0, 32.0 * (double)n, st);
   hipLaunchKernelGGL(sqnorm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, g, n, part);
   LAUNCH_CHECK();
   AdamArgs a;
@@ -432,6 +438,7 @@ int rgbnm_clip_adamw_wd_step(float* p, const float* g, float* m, float* v, const
   a.wd_factor = wd_factor; a.max_norm = max_norm;
   const int grid = (int)min(4096LL, n / 256);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, a);
+  rgbnm_trace_end(tslot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;
 }

@@ -12,6 +12,8 @@
 // 128 B of the reduction axis + 16 B pad (144 B pitch): ds_read_b128 of 32 rows at one k-offset is
 // bank-conflict free (9*i mod 16 distinct).
 #include "common.h"
+#include <mutex>
+#include <vector>
 #include "../../include/rgbnm.h"
 #include "internal.h"
 
@@ -539,6 +541,27 @@ constexpr int TN_QMAX = 48;
 thread_local TnPending g_tn_q[TN_QMAX];
 thread_local int g_tn_n = 0, g_tn_cap = 4;
 thread_local int g_tn_tiles = 0;          // output tiles of the queued jobs (gemm_tn_pipe.hip: 128 x 192 tiles, one workgroup each)
+thread_local int g_tn_depth = 0;          // begin / end pairs opened INSIDE the open bracket: they join it (see rgbnm_tn_defer_begin_n)
+// A bracket may be abandoned from ANOTHER host thread than the one whose queue holds its jobs (swinv2.py: a backward pass that
+// never reached its last node is noticed by the next forward, on the caller's thread, while the queue is thread_local to the
+// autograd worker): the abandoning thread names the bracket (rgbnm_gemm_tn_group_abort), the owning thread drops the queue -- its
+// operands may be freed by then: they are never launched -- the next time it touches it.
+thread_local unsigned long long g_tn_id = 0;
+std::mutex g_tn_abort_mu;
+std::vector<unsigned long long> g_tn_aborted;
+void tn_check_abort() {
+  if (!g_tn_id) return;
+  std::lock_guard<std::mutex> lk(g_tn_abort_mu);
+  for (size_t i = 0; i < g_tn_aborted.size(); ++i)
+    if (g_tn_aborted[i] == g_tn_id) {
+      g_tn_aborted.erase(g_tn_aborted.begin() + i);
+      g_tn_n = g_tn_tiles = g_tn_depth = 0;
+      g_tn_defer = false;
+      g_tn_cap = 4;
+      g_tn_id = 0;
+      return;
+    }
+}
 
 int tn_flush(hipStream_t st) {
   const int n = g_tn_n;
@@ -584,6 +607,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
   p.ctiles = nb3 ? p.Ki / 192 : cdiv(p.Ki, 128);
   const int tiles = p.rtiles * p.ctiles;
   if constexpr (sizeof(T) == 2) {
+    tn_check_abort();
     if (g_tn_defer && tn_groupable(p)) {
       // a grouped launch has one workgroup per output tile and at most 256 of them (rgbnm_launch_tn_pipe_group): what is queued
       // runs before a job that would take the queue past that, or that has another row count (the queue used to fail
@@ -723,11 +747,25 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
 
 }  // namespace
 
-void rgbnm_tn_defer_begin() { g_tn_defer = true; g_tn_cap = 4; }
-void rgbnm_tn_defer_begin_n(int max_jobs) { g_tn_defer = true; g_tn_cap = max_jobs < 1 ? 1 : (max_jobs > TN_QMAX ? TN_QMAX : max_jobs); }
+// Brackets nest by JOINING: a begin inside an open bracket (rgbnm_head_bwd or rgbnm_vit_block_bwd called by somebody who has
+// opened rgbnm_gemm_tn_group_begin_n) only counts, and its flush neither launches nor closes anything -- the jobs wait for the
+// outer end (the inner flush used to close the caller's bracket silently).  A begin on a thread whose queue still holds
+// jobs starts from an EMPTY queue: they are leftovers of a pass that died between begin and end, their operands may be gone.
+void rgbnm_tn_defer_begin_n(int max_jobs) {
+  tn_check_abort();
+  if (g_tn_defer) { ++g_tn_depth; return; }
+  g_tn_n = g_tn_tiles = g_tn_depth = 0;
+  g_tn_id = 0;
+  g_tn_defer = true;
+  g_tn_cap = max_jobs < 1 ? 1 : (max_jobs > TN_QMAX ? TN_QMAX : max_jobs);
+}
+void rgbnm_tn_defer_begin() { rgbnm_tn_defer_begin_n(4); }
 int rgbnm_tn_defer_flush(hipStream_t st) {
+  tn_check_abort();
+  if (g_tn_depth > 0) { --g_tn_depth; return RGBNM_OK; }
   g_tn_defer = false;
   g_tn_cap = 4;
+  g_tn_id = 0;
   return tn_flush(st);
 }
 
@@ -775,6 +813,18 @@ int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, fl
 
 void rgbnm_gemm_tn_group_begin(void) { rgbnm_tn_defer_begin(); }
 void rgbnm_gemm_tn_group_begin_n(int max_jobs) { rgbnm_tn_defer_begin_n(max_jobs); }
+void rgbnm_gemm_tn_group_begin_id(int max_jobs, unsigned long long id) {
+  const bool outer = !g_tn_defer;
+  rgbnm_tn_defer_begin_n(max_jobs);
+  if (outer) g_tn_id = id;
+}
+void rgbnm_gemm_tn_group_abort(unsigned long long id) {
+  if (!id) return;
+  if (id == g_tn_id) { tn_check_abort(); g_tn_n = g_tn_tiles = g_tn_depth = 0; g_tn_defer = false; g_tn_cap = 4; g_tn_id = 0; return; }   // own thread: now
+  std::lock_guard<std::mutex> lk(g_tn_abort_mu);
+  if (g_tn_aborted.size() > 1024) g_tn_aborted.erase(g_tn_aborted.begin());      // (ids nobody came back for)
+  g_tn_aborted.push_back(id);
+}
 
 int rgbnm_gemm_tn_group_end(void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -37,8 +37,9 @@ int rgbnm_launch_attn_proj_fwd(const void* qkv, void* out, float* lse, const voi
                                int heads, float scale, hipStream_t st);
 
 // per-kernel HIP-event tracing (vit.hip); tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd, 5 / 6 the one-launch encoder
-// forward / backward (vit_chain.hip, vit_chain_bwd.hip)
-enum { TR_NT = 1, TR_TN = 2, TR_ATTN_FWD = 3, TR_ATTN_BWD = 4, TR_CHAIN_FWD = 5, TR_CHAIN_BWD = 6 };
+// forward / backward (vit_chain.hip, vit_chain_bwd.hip); the HBM-bound classes of SURVEY 8d: 7 augment stage (dct_resize +
+// dct_randaug as one bracket), 8 sub-block embed, 9 clip + AdamW + WeightDecay (sqnorm + adamw as one bracket)
+enum { TR_NT = 1, TR_TN = 2, TR_ATTN_FWD = 3, TR_ATTN_BWD = 4, TR_CHAIN_FWD = 5, TR_CHAIN_BWD = 6, TR_AUG = 7, TR_EMBED = 8, TR_OPT = 9 };
 // Weight-resident K = 192 bf16 NT GEMM (gemm_nt_wres.hip).  Returns RGBNM_OK / error, or 1 if the shape is not eligible.
 int rgbnm_launch_nt_wres(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                          const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st);

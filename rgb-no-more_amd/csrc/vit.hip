@@ -251,6 +251,7 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   char* wsb = (char*)s->ws;
 #define WS(i) (wsb + off[i]), (off[(i) + 1] - off[i])
   rgbnm_reduce_defer_begin();     // the 12 partial reductions of this block run as one launch at the end
+  bool tn_open = false;           // a grouping opened below and not yet closed (only an error leaves it so)
   const int rc = [&]() -> int {
   // ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ------------------------------------
   // tn_group: the four dW GEMMs run one per launch (0), as pairs fc2 + fc1 / proj + qkv (1) or all in one launch at the
@@ -260,7 +261,7 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   // outputs it reads) the JPEG-S step is 1 % faster (13.26 -> 13.13 ms, interleaved)
   int group = rgbnm_get_option("tn_group");
   if (group == 2 && E > 192) group = 1;
-  if (group) rgbnm_tn_defer_begin();
+  if (group) { rgbnm_tn_defer_begin(); tn_open = true; }
   TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
   // du = (dy . W2) * gelu'(u) and dx_mid = dy + LN2'(du . W1) in ONE launch when eligible (mlp_fused.hip, option mlp_bwd)
   const bool mlp_bwd_fused = fused_mlp_bwd(dt, dy, p->w2_t, p->w1_t, a->u, s->du, a->x_mid, p->ln2_g, a->mean2, a->rstd2,
@@ -269,7 +270,7 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
     TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_DGELU, dy, E, p->w2_t, E, s->du, 4 * E, 0, a->u, 4 * E, 0, 0, 0, 0, M, 4 * E, E, 0,
                       st));
   TRY(rgbnm_gemm_tn(dt, s->du, 4 * E, a->xn2, E, g->dw1, g->db1, M, 4 * E, E, 0, 0, WS(1), st));
-  if (group == 1) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
+  if (group == 1) { tn_open = false; TRY(rgbnm_tn_defer_flush((hipStream_t)st)); }
   // dx_mid = dy + LN2'(du . W1): LayerNorm backward fused into the GEMM epilogue when eligible
   if (mlp_bwd_fused) {
   } else if (!fused_dx_lnbwd(dt, s->du, 4 * E, p->w1_t, 4 * E, a->x_mid, p->ln2_g, a->mean2, a->rstd2, dy, s->dx_mid,
@@ -280,12 +281,12 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
                             M, E, 0, WS(4), st));
   }
   // ---- attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in)))) -------------------------------
-  if (group == 1) rgbnm_tn_defer_begin();
+  if (group == 1) { rgbnm_tn_defer_begin(); tn_open = true; }
   TRY(rgbnm_gemm_tn(dt, s->dx_mid, E, a->attn, I, g->dwproj, g->dbproj, M, E, I, 0, 0, WS(2), st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dx_mid, E, p->wproj_t, E, s->dattn, I, 0, 0, 0, 0, 0, 0, 0, M, I, E, 0, st));
   TRY(rgbnm_attention_bwd(dt, a->qkv, a->attn, s->dattn, a->lse, s->dqkv, c->B, c->N, c->heads, c->attn_scale, st));
   TRY(rgbnm_gemm_tn(dt, s->dqkv, 3 * I, a->xn1, E, g->dwqkv, g->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
-  if (group) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
+  if (group) { tn_open = false; TRY(rgbnm_tn_defer_flush((hipStream_t)st)); }
   if (!fused_dx_lnbwd(dt, s->dqkv, 3 * I, p->wqkv_t, 3 * I, a->x_in, p->ln1_g, a->mean1, a->rstd1, s->dx_mid, dx,
                       g->dln1_g, g->dln1_b, M, E, 3 * I, WS(5), (hipStream_t)st)) {
     TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, s->dqkv, 3 * I, p->wqkv_t, 3 * I, s->dxn, E, 0, 0, 0, 0, 0, 0, 0, M, E,
@@ -296,7 +297,7 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   return RGBNM_OK;
   }();
 #undef WS
-  const int rt = rgbnm_tn_defer_flush((hipStream_t)st);      // no-op unless an error left the queue open
+  const int rt = tn_open ? rgbnm_tn_defer_flush((hipStream_t)st) : RGBNM_OK;      // only an error leaves the grouping open
   const int rf = rgbnm_reduce_defer_flush((hipStream_t)st);
   return rc != RGBNM_OK ? rc : (rt != RGBNM_OK ? rt : rf);
 }
@@ -318,9 +319,10 @@ int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* c, int n, const rgbnm_block_act
       if (s[k]->ws == s[i]->ws) return RGBNM_EINVAL;          // the partial sums of the grouped blocks live side by side
   }
   rgbnm_reduce_defer_begin();
+  bool tn_open = false;
   const int rc = [&]() -> int {
     const int group = rgbnm_get_option("tn_group");
-    if (group) rgbnm_tn_defer_begin_n(group == 1 ? 2 : 4 * n);
+    if (group) { rgbnm_tn_defer_begin_n(group == 1 ? 2 : 4 * n); tn_open = true; }
     for (int i = 0; i < n; ++i) {
       char* wsb = (char*)s[i]->ws;
 #define WS(k) (wsb + off[k]), (off[(k) + 1] - off[k])
@@ -330,7 +332,7 @@ int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* c, int n, const rgbnm_block_act
       TRY(rgbnm_gemm_tn(dt, s[i]->dqkv, 3 * I, a[i]->xn1, E, g[i]->dwqkv, g[i]->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
 #undef WS
     }
-    if (group) TRY(rgbnm_tn_defer_flush((hipStream_t)st));
+    if (group) { tn_open = false; TRY(rgbnm_tn_defer_flush((hipStream_t)st)); }
     for (int i = 0; i < n; ++i) {       // per-image partial sums of the LayerNorm parameter gradients (one panel per image)
       RgbnmReduceJob j;
       j.stride = 2LL * E; j.n = E; j.S = c->B; j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
@@ -345,7 +347,7 @@ int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* c, int n, const rgbnm_block_act
     }
     return RGBNM_OK;
   }();
-  const int rt = rgbnm_tn_defer_flush((hipStream_t)st);
+  const int rt = tn_open ? rgbnm_tn_defer_flush((hipStream_t)st) : RGBNM_OK;
   const int rf = rgbnm_reduce_defer_flush((hipStream_t)st);
   return rc != RGBNM_OK ? rc : (rt != RGBNM_OK ? rt : rf);
 }

@@ -1078,11 +1078,12 @@ int rgbnm_vit_chain_bwd(const rgbnm_vit_cfg* c, const rgbnm_chain_bwd_block* blo
       return RGBNM_ELAUNCH;
     attr.done();
   }
-  // algorithmic work per block and token: the dX products of the four Linears and the five attention products that a backward
-  // needs (S recomputed once, dP, dV, dK, dQ); bytes that must cross HBM: gelu', x_mid, x_in, qkv, attn in, du, d(x_mid), d(qkv), dx
+  // algorithmic work per block and token (backward = 2 x forward per GEMM, recompute NOT counted): the dX products of
+  // the four Linears and the four attention-gradient products dP, dV, dK, dQ = 0.23241 GFLOP per image and block (the kernel also
+  // recomputes S = Q K^T: +6 % of MFMA work that no roofline figure is credited with); bytes that must cross HBM: gelu', x_mid, x_in, qkv, attn in, du, d(x_mid), d(qkv), dx
   // out (the d(attention output) scratch and the d(qkv) re-read are L2 hand-offs of one CU, not counted) + the weights once
   const double tok = (double)c->B * NTOK;
-  const double flops = depth * tok * 2.0 * (2.0 * E * HID + INNER * E + 3.0 * INNER * E + 5.0 * NTOK * INNER);
+  const double flops = depth * tok * 2.0 * (2.0 * E * HID + INNER * E + 3.0 * INNER * E + 4.0 * NTOK * INNER);
   const double bytes = depth * (tok * ((2.0 * HID + 5.0 * E + 2.0 * 3.0 * INNER) * 2.0 + 4 * 4 + HEADS * 4) + 36.0 * SLOT) + tok * E * 2.0;
   const int slot = rgbnm_trace_begin(TR_CHAIN_BWD, flops, bytes, (hipStream_t)stream);
   hipLaunchKernelGGL(vit_chain_bwd_kernel, dim3(c->B), dim3(NTHREADS), SMEM, (hipStream_t)stream, p);

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "rgbnm_set_option": (_i, [C.c_char_p, _i]),
     "rgbnm_gemm_tn_group_begin": (None, []),
     "rgbnm_gemm_tn_group_begin_n": (None, [_i]),
+    "rgbnm_gemm_tn_group_begin_id": (None, [_i, C.c_ulonglong]),
+    "rgbnm_gemm_tn_group_abort": (None, [C.c_ulonglong]),
     "rgbnm_gemm_tn_group_end": (_i, [_vp]),
     "rgbnm_get_option": (_i, [C.c_char_p]),
     "rgbnm_trace_collect": (_i, [_i, _vp, _vp, _vp, _vp]),
@@ -185,6 +187,22 @@ def lib():
             raise RgbnmError("rgbnm_chain_block layout mismatch between librgbnm.so and lib.py")
         _lib = L
     return _lib
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.inc, *.h, reader.c and
+    include/rgbnm.h, in name order): profiles/*.json files that hold counter figures measured in separate rocprofv3 passes carry the
+    hash they were measured at, and bench.py marks them `stale` when it differs from the tree it runs from."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc", ".h", ".c")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "rgbnm.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc, what=""):

@@ -11,6 +11,8 @@ Round 1: correct and complete for training; window attention on the MFMA pipe (c
 on the generic GEMM tiles.
 """
 import ctypes as C
+import itertools
+import threading
 import math
 
 import numpy as np
@@ -61,13 +63,21 @@ class _DwBracket:
     bracket off).  Row-paired layers (stage 1) finish their gradients with tensor arithmetic on the spot: what is queued runs
     first, they run the old way."""
 
+    _ids = itertools.count(1)
+
     def __init__(self):
         self.active = False
         self.keep = []
+        self.id = 0
+        self.thread = None
 
     def begin(self):
         if not self.active:
-            L.lib().rgbnm_gemm_tn_group_begin_n(48)
+            # a NAMED bracket: the queue is thread_local to the autograd worker that runs the backward nodes; should the pass never
+            # reach its last node, the next forward -- on another thread -- can only name it (abandon)
+            self.id = next(self._ids)
+            self.thread = threading.get_ident()
+            L.lib().rgbnm_gemm_tn_group_begin_id(48, self.id)
             self.active, self.keep = True, []
 
     def end(self):
@@ -77,11 +87,22 @@ class _DwBracket:
             self.keep = []
             L.check(rc, "gemm_tn_group_end")
 
+    def abandon(self):
+        """Called where a bracket is found still open AFTER its backward pass is over (a node other than a Linear raised, or a
+        partial backward never reached the patch embedding): the queued jobs must never run -- their operands die with `keep`.  On
+        the thread that opened it the queue is dropped at once, from any other thread the library is told its name and the owning
+        thread drops it the next time it touches its queue (end() on the caller's thread used to do nothing there,
+        and the stale jobs ran behind the next pass's)."""
+        if self.active:
+            self.active = False
+            L.lib().rgbnm_gemm_tn_group_abort(self.id)
+            self.keep = []
+
     def pause(self):
         L.check(L.lib().rgbnm_gemm_tn_group_end(L.stream()), "gemm_tn_group_end")
 
     def resume(self):
-        L.lib().rgbnm_gemm_tn_group_begin_n(48)
+        L.lib().rgbnm_gemm_tn_group_begin_id(48, self.id)
 
 
 _ACTIVE = [None]        # the bracket of the backward pass that is running (its nodes run one after the other on one autograd thread)
@@ -627,7 +648,7 @@ class SwinTransformerV2(FlatParamModule):
             br = self.__dict__.setdefault("_dw_bracket", _DwBracket())
             if br.active:                       # a backward pass that never reached the patch embedding
                 _ACTIVE[0] = None
-                br.end()
+                br.abandon()
         x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias, sh["patch_embed.projection.0"], False,
                             None if br is None else ("close", br))
         x = _LNFn.apply(x, pe.norm.weight, pe.norm.bias, None, None, 1)

@@ -408,3 +408,70 @@ def test_backward_wide_weight_gradient_bracket_equals_per_linear_launches(B):
     for n in g0:
         scale = g0[n].abs().max().item() + 1e-30
         assert (g2[n] - 2 * g1[n]).abs().max().item() / scale < 1e-4, n
+
+
+@pytest.mark.gpu
+def test_abandoned_weight_gradient_bracket_is_dropped_not_launched():
+    """a backward pass that dies in a node which is not a Linear (here: the window attention) leaves the backward-wide
+    bracket open with jobs queued on the AUTOGRAD WORKER's thread-local queue; the next forward runs on the caller's thread and frees
+    the jobs' operands.  The stale jobs must never be launched (they would read freed memory and write into the next pass's
+    gradients): the next step must give exactly the gradients of an undisturbed step, and so must a partial backward
+    (torch.autograd.grad onto the logits' input side only) followed by a normal step."""
+    from rgb_no_more_amd import swinv2 as SW
+    B = 8
+    m, img, depths, heads, _ = _model("swt", DEV)
+    nb = img // 8
+    y = torch.from_numpy(detfill.normalish((B, 1, nb, nb, 8, 8), 281)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, nb // 2, nb // 2, 8, 8), 282)).to(DEV)
+    tgt = detfill.uniform((B, 1000), 283, 0.0, 1.0)
+    tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+    m.eval()
+    m.compute_dtype = torch.bfloat16
+    m.group_dw_backward = True
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        rg.cls_transforms.cross_entropy(m(y, c), tgt, grad_dtype=torch.bfloat16).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    want = step()
+    # (1) the window attention's backward raises in the middle of the pass
+    orig = SW._WinAttnFn.backward
+    calls = {"n": 0}
+
+    def boom(ctx, *g):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise RuntimeError("injected failure in the window attention backward")
+        return orig(ctx, *g)
+
+    SW._WinAttnFn.backward = staticmethod(boom)
+    try:
+        m.zero_grad(set_to_none=True)
+        loss = rg.cls_transforms.cross_entropy(m(y, c), tgt, grad_dtype=torch.bfloat16)
+        with pytest.raises(RuntimeError, match="injected failure"):
+            loss.backward()
+    finally:
+        SW._WinAttnFn.backward = staticmethod(orig)
+    torch.cuda.synchronize()
+    assert m._dw_bracket.active                      # left open by the pass that died ...
+    got = step()                                     # ... found and abandoned by this forward; its jobs never run
+    assert not m._dw_bracket.active and SW._ACTIVE[0] is None
+    bad = [n for n in want if not torch.equal(want[n], got[n])]
+    assert not bad, bad[:5]
+    # (2) junk where the dead pass's operands used to be, then another step: still the same bits
+    junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(8)]
+    del junk
+    got = step()
+    bad = [n for n in want if not torch.equal(want[n], got[n])]
+    assert not bad, bad[:5]
+    # (3) a ViT backward on the same worker thread afterwards (its internal groupings must not meet stale jobs)
+    v = rg.ViT(3, 16, 192, depth=1, n_classes=1000, drop_p=0.0, device=DEV, num_heads=3, head_size=64, pixel_space="DCT", ver=1)
+    v.compute_dtype = torch.bfloat16
+    yv = torch.from_numpy(detfill.normalish((2, 1, 28, 28, 8, 8), 71)).to(DEV)
+    cv = torch.from_numpy(detfill.normalish((2, 2, 14, 14, 8, 8), 72)).to(DEV)
+    lv = torch.from_numpy(detfill.integers((2,), 74, 0, 998, np.int64)).to(DEV)
+    rg.cls_transforms.cross_entropy(v(yv, cv), lv, grad_dtype=torch.bfloat16).backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in v.parameters())

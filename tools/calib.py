@@ -42,6 +42,7 @@ def main():
             best = max(best, traffic / t / 1e9)
         out[f"hbm_{name}_GBps[1 GiB]"] = round(best, 0)
     out["device"] = torch.cuda.get_device_name(0)
+    out["measured_at"] = {"csrc_sha16": L.source_hash()}
     print(json.dumps(out))
 
 

@@ -14,6 +14,26 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _head():
+    import subprocess
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:       # noqa: BLE001
+        return None
+
+
+def _stamp_head(path):
+    """measured_at.head = the commit checked out when the summary was copied (the GPU box has no .git; the source hash the box
+    computed is what bench.py checks, HEAD is for the reader)."""
+    try:
+        d = json.load(open(path))
+        if isinstance(d, dict):
+            d.setdefault("measured_at", {})["head"] = _head()
+            json.dump(d, open(path, "w"), indent=1)
+    except Exception:       # noqa: BLE001
+        pass
+
+
 def main(tag, name):
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
@@ -33,6 +53,7 @@ def main(tag, name):
         if os.path.exists(t) and os.path.getsize(t) > 0:
             out = f"{stem}.json" if arch == "vitti" else f"{stem}_{arch}.json"
             shutil.copy(t, os.path.join(dst, out))
+            _stamp_head(os.path.join(dst, out))
             print("profiles/" + out)
 
 

@@ -17,6 +17,18 @@ import sys
 
 import pandas as pd
 
+
+def _measured_at():
+    """The tree these counters were measured on: hash of the kernel sources (rgb_no_more_amd.lib.source_hash) -- bench.py compares
+    it with the tree it runs from and marks file-sourced figures `stale` when they differ; tools/collect_profiles.py adds HEAD."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from rgb_no_more_amd import lib as L
+        return {"csrc_sha16": L.source_hash()}
+    except Exception as e:       # noqa: BLE001
+        return {"csrc_sha16": None, "error": str(e)}
+
+
 PEAK = 2.5e15
 CLASSES = (("chain_fwd", r"vit_chain_fwd_kernel"), ("chain_bwd", r"vit_chain_bwd_kernel"), ("mlp_fused", r"mlp_fwd_kernel|mlp_bwd_kernel"), ("gemm_nt", r"gemm_nt_"), ("gemm_tn", r"gemm_tn_"), ("attn_fwd", r"attn[23]_fwd"), ("attn_bwd", r"attn[23]_bwd"),
            ("layernorm", r"ln_|layernorm|pool_"), ("augment", r"dct_"), ("embed", r"subblock|embed"),
@@ -64,6 +76,7 @@ def main(d, out):
         summarise(piv[m], name)
     summarise(piv[~used], "other")
     summarise(piv, "whole_run")
+    res["measured_at"] = _measured_at()
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["classes"].items():
         print(f"{k:10s} n={v['dispatches']:5d} t={v.get('kernel_time_ms', 0):9.3f} ms  mfma_flops={v['mfma_flops']:.3e} "
