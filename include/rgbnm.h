@@ -37,24 +37,36 @@ extern "C" {
 #define RGBNM_EPI_DTANH 6  /* C = (A.W^T) * (1 - R^2)                                             */
 
 int rgbnm_abi_version(void);
-/* runtime switches (A/B testing, profiling; every alternative path is parity-tested):
- *   "nt_staged" 1   coalesced LDS-staged GEMM epilogue          "nt_wres"  1  weight-resident persistent NT GEMM (K = 192)
- *   "nt_kpipe"  1   row-panel NT GEMM with the k-tile DMA ring   "ln_fuse"  1  LayerNorm fwd / bwd in the GEMM epilogues
- *   "tn_tr"     1   ds_read_b64_tr_b16 fragments in the dW GEMM  "tn_pipe"  1  pipelined dW GEMM
- *   "tn_group"  2   dW GEMMs of a block: 0 one per launch, 1 pairs, 2 all four in one launch
- *   "tn_square" 0   192 x 192 dW tile                            "attn_v2"  1  second-generation attention kernels
- *   "attn_persist" 1  persistent attention fwd / bwd with a DMA wave (>= 256 (image, head) pairs)
- *   "nt_dmawave" 0  row-panel GEMM with a dedicated DMA wave (measured: no gain there)
- *   "trace"     0   see rgbnm_trace_collect                      "tn_wgs" 512  workgroup budget of the generic dW GEMM
- *   "kp_split"  0   row-panel NT GEMM as two 4-wave workgroups per CU (80 KB LDS each, 2-stage ring) instead of one 7-wave
- *                   workgroup (measured 5.5 % slower on the whole step: kept as a parity-tested alternative)
- *   "mlp_fuse"  1   FeedForwardBlock forward (fc1 + GELU + fc2 + residual [+ next LayerNorm]) as one launch (bf16, E = 192)
- *   "mlp_bwd"   1   its backward data path (dGELU product + fc1 dX + LayerNorm backward) as one launch (bf16, E = 192)
- *   "nt_small"  1   NT GEMMs with at most 512 rows (the classification head) on 32 x 32 tiles with an in-workgroup split of K
- *   "mlp_dmast" 1   fused MLP kernels: the DMA wave stores the saved-tensor tiles of waves 4-6 (the critical wave of each SIMD pair)
- *   "nt_kstream" 0  streaming row-panel GEMM (csrc/gemm_nt_kstream.hip: a finished tile leaves under the next tile's reduction) for
- *                   N >= 384, K >= 384: 1 = the fc1 + GELU epilogue only, 2 = every eligible shape.  The bits of the default kernels
- *                   (tests/test_kstream.py); faster stand-alone, slower inside the training step: kept opt-in */
+/* Runtime switches: every one selects between parity-tested kernels (tests/ run both sides); defaults in the middle column.
+ * Round 6 removed the switches whose alternative had measured slower in every configuration and nothing else used
+ * (tn_square, nt_dmawave, kp_split, nt_kstream, attn_proj -- numbers in DESIGN.md 7).
+ *   GEMM  C = A . W^T (nn.Linear forward, dX)
+ *   "nt_staged"    1  coalesced LDS-staged epilogue of the generic tile kernel (0: direct fragment stores)
+ *   "nt_wres"      1  K = 192 layers on the weight-resident persistent kernel (csrc/gemm_nt_wres.hip)
+ *   "nt_kpipe"     1  N % 192 == 0, K >= 256 on the row-panel kernel with the k-tile DMA ring (csrc/gemm_nt_kpipe.hip)
+ *   "kp8"          1  ... its 8-wave / 256-row geometry for row counts that are multiples of 256 (the SwinV2 stages)
+ *   "kp_persist"   1  ... its persistent form for several column tiles (JPEG-S: E = 384)
+ *   "nt_small"     1  at most 512 rows (the classification head) on 32 x 32 tiles with an in-workgroup split of K
+ *   "ln_fuse"      1  LayerNorm forward / backward in the row-panel kernel's epilogues (E = 192)
+ *   GEMM  dW = dY^T . X (weight gradients)
+ *   "tn_pipe"      1  pipelined kernel (csrc/gemm_tn_pipe.hip; 0: the generic one)     "tn_tr"  1  its ds_read_b64_tr_b16 fragments
+ *   "tn_group"     2  dW GEMMs of a ViT block: 0 one per launch, 1 pairs, 2 all four in one launch
+ *   "tn_direct"    1  a grouped launch that ends up without a token split writes dW / db itself (no partial sums, no reduction)
+ *   "tn_pack"      1  ... and places its tiles so that no GEMM straddles two XCDs (L2 locality)
+ *   "tn_wgs"     512  workgroup budget of the generic kernel's token split
+ *   attention
+ *   "attn_v2"      1  LDS-DMA / transpose-read attention kernels (0: first-generation kernels, also used for 294 tokens)
+ *   "attn_persist" 1  persistent forward / backward with a DMA wave (>= 256 (image, head) pairs)
+ *   FeedForwardBlock, E = 192
+ *   "mlp_fuse"     1  fc1 + GELU + fc2 + residual [+ next LayerNorm] as one launch          "mlp_bwd"  1  its backward data path as one
+ *   "mlp_dmast"    1  ... the DMA wave stores the saved-tensor tiles of waves 4-6           "nt_cold"  0  ... non-temporal hint on them
+ *   "gelu_table"   1  table GELU in the bf16 kernels once rgbnm_gelu_table_init has run (0: the erf arithmetic; same bits)
+ *   the one-launch encoder (E = 192, 3 heads, 196 tokens, bf16)
+ *   "fwd_chain"    1  rgbnm_vit_chain_fwd eligible        "bwd_chain"  1  rgbnm_vit_chain_bwd eligible (0: the per-operation kernels)
+ *   SwinV2
+ *   "ln_rows"      1  lanes-per-row LayerNorm kernels for the four stage widths            "win_xcd"  1  XCD-aware window walk
+ *   measurement
+ *   "trace"        0  bit mask of kernel classes to bracket with HIP events, see rgbnm_trace_collect */
 int rgbnm_set_option(const char* name, int value);
 int rgbnm_get_option(const char* name);
 /* With option "trace" = (1 << tag) the launchers bracket kernels of that class with HIP events recorded on the launch

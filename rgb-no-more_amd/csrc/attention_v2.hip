@@ -1057,293 +1057,8 @@ __global__ __launch_bounds__(NTHREADS3) void attn3_fwd_kernel(const bf16* __rest
   }
 }
 
-// ------------------------------------------------------------------------ forward + output projection, one image per visit
-// MultiHeadAttention.forward to its end (models/plainvit.py:445-464) plus the ResidualAdd and the LayerNorm that follow it
-// (:475-479, :513) for heads = 3 (E = 192), 196 tokens:
-//     attn = softmax(q k^T / sqrt(E)) v  ;  x_mid = x_in + attn . Wp^T + bp  ;  xn2 = LayerNorm(x_mid)
-// The persistent forward above walks the (image, head) pairs image-major here, so a workgroup meets the three heads of one
-// image back to back: each head's 32 x 64 output tile, already parked in the wave's private LDS tile for its row stores, is read
-// back as MFMA operand fragments and multiplied into the wave's 32 x 192 projection accumulators (24 MFMAs per head, weight
-// fragments straight from L2: every workgroup reads the same 72 KB), and after the third head the rows go through the
-// residual + LayerNorm arithmetic of gemm_nt_kpipe's EPI_RES_LN a 64-feature third at a time through the same private tile.
-// What it removes: the read of attn (19 MB) by a separate projection launch and that launch's start.  Same operand rounding,
-// same k order, same row arithmetic as the two launches: the same bits (tests/test_fastpath_model.py with the option on).
-// MEASURED (B = 256): 47.7 us against 24.5 + 19.2 us for the two launches -- at one image per workgroup nothing of the next
-// image can overlap this image's memory-bound epilogue, the weight fragments come from L2 per wave (504 KB per CU), and the
-// residual rows cannot be requested early (no registers).  Option attn_proj, default OFF.
-struct AttnProjArgs {
-  const bf16* qkv; bf16* out; float* lse;
-  const bf16* Wp; const float* bp; const bf16* R; bf16* X; const float* gamma; const float* beta; bf16* Y2; float* mean_o; float* rstd_o;
-  float eps, scale;
-  int nimg;
-};
-
-__global__ __launch_bounds__(NTHREADS3) void attn3_proj_fwd_kernel(AttnProjArgs p) {
-  constexpr int N = 196, heads = 3, E = 192;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int inner = heads * HD, ld = 3 * inner;
-  const LaneGeo L = lane_geo();
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int img0 = blockIdx.x;
-  if (img0 >= p.nimg) return;
-  const bf16* qkv = p.qkv;
-  // pair sequence of this workgroup: (img0, 0), (img0, 1), (img0, 2), (img0 + grid, 0), ...
-  auto next_pair = [&](int img, int h, int& nimg_, int& nh_) {
-    if (h + 1 < heads) { nimg_ = img; nh_ = h + 1; }
-    else { nimg_ = img + gridDim.x; nh_ = 0; }
-    return nimg_ < p.nimg;
-  };
-
-  if (w == NTILE) {                                     // ---- DMA wave: K,V of the next pair while the current one is computed
-    auto issue_kv = [&](int img, int h, int buf) {
-      const bf16* Q = qkv + (size_t)img * N * ld + h * HD;
-      dma_matrix_all(Q + inner, ld, N, smem + buf * 2 * ARR, L.lane);
-      dma_matrix_all(Q + 2 * inner, ld, N, smem + buf * 2 * ARR + ARR, L.lane);
-    };
-    int buf = 0, img = img0, h = 0;
-    issue_kv(img, h, 0);
-    for (;;) {
-      int ni, nh;
-      const bool more = next_pair(img, h, ni, nh);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      buf ^= 1;
-      if (!more) break;
-      issue_kv(ni, nh, buf);
-      img = ni; h = nh;
-    }
-    return;
-  }
-
-  unsigned char* stg = smem + 4 * ARR + w * STG_WAVE;
-  const int q = w * 32 + L.l31;
-  const bool active = w * 32 < N;
-  const float c2 = p.scale * 1.4426950408889634f;
-  u32x4 qraw[4];
-  auto load_own = [&](int img, int h) {
-    const int lane_ = lane_id_here();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int r = w * 32 + i * 8 + (lane_ >> 3);
-      r = r < N ? r : N - 1;
-      qraw[i] = *reinterpret_cast<const u32x4*>(qkv + ((size_t)img * N + r) * ld + h * HD + (lane_ & 7) * 8);
-    }
-  };
-  if (active) load_own(img0, 0);
-  int buf = 0;
-  f32x16 accy[6];
-  for (int img = img0, h = 0;;) {
-    int ni, nh;
-    const bool more = next_pair(img, h, ni, nh);
-    const unsigned char* Ks = smem + buf * 2 * ARR;
-    const unsigned char* Vs = Ks + ARR;
-    buf ^= 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own Q rows (and the previous pair's stores)
-    __builtin_amdgcn_s_barrier();
-    if (active) {
-      if (h == 0) {
-#pragma unroll
-        for (int b = 0; b < 6; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) accy[b][r] = 0.f;
-      }
-      Frag<bf16> qf[4];
-      {
-        const int rl = L.lane >> 3, seg = L.lane & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16) = qraw[i];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          qf[c].v = *reinterpret_cast<const bf16x8*>(stg + L.l31 * STG_PITCH + (2 * c + L.g) * 16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      if (more) load_own(ni, nh);
-      unsigned rb = (unsigned)(L.l31 * ROWB + ((L.g ^ L.fl) << 4)), tr = L.tr0;
-      asm volatile("" : "+v"(rb), "+v"(tr));
-
-      float m = -INFINITY;
-      TileLoop<NTILE>::run([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        if (tile_on<N, t>(N)) {
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          row_mma4(acc, Ks, rb, t, qf);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[r];
-            if (tile_ragged<N, t>(N) && t * 32 + acc_row(r, L.lane) >= N) v = -INFINITY;
-            m = fmaxf(m, v);
-          }
-        }
-      });
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      const float mc2 = m * c2;
-      float sum = 0.f;
-      f32x16 o[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-      const unsigned vt = (unsigned)(size_t)Vs + tr;
-      TileLoop<NTILE>::run([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        if (tile_on<N, t>(N)) {
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          row_mma4(acc, Ks, rb, t, qf);
-          float pr[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            pr[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mc2));
-            if (tile_ragged<N, t>(N) && t * 32 + acc_row(r, L.lane) >= N) pr[r] = 0.f;
-            sum += pr[r];
-          }
-          Frag<bf16> vv[4];
-          tfrag4<t>(vt, vv);
-          Frag<bf16> pf = pfrag(pr, 0);
-          mma(o[0], vv[0], pf);
-          mma(o[1], vv[1], pf);
-          pf = pfrag(pr, 1);
-          mma(o[0], vv[2], pf);
-          mma(o[1], vv[3], pf);
-        }
-      });
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.f / sum;
-      if (L.g == 0 && q < N) p.lse[((size_t)img * heads + h) * N + q] = m * p.scale + __logf(sum);
-      // this head's weight fragments for the first output tile: requested before the park so that they fly during it
-      const bf16* wrow = p.Wp + (size_t)L.l31 * inner + h * HD + L.g * 8;      // row (32 b + l31), k = 64 h + 16 c + 8 g
-      Frag<bf16> wf[2][4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) wf[0][c] = load_frag<bf16>(wrow + c * 16);
-      // output rows: private tile -> (a) 4 row pieces per lane for the global store, (b) operand fragments of the projection
-      tile_park_private(stg, o, inv, L);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      u32x4 orow[4];
-      Frag<bf16> of[4];
-      {
-        const int lane_ = lane_id_here();
-        const int rl = lane_ >> 3, seg = lane_ & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) orow[i] = *reinterpret_cast<const u32x4*>(stg + (i * 8 + rl) * STG_PITCH + seg * 16);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          of[c].v = *reinterpret_cast<const bf16x8*>(stg + (lane_ & 31) * STG_PITCH + (2 * c + (lane_ >> 5)) * 16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      // x_mid += attn_h . Wp[:, 64 h : 64 h + 64]^T : D rows = output features, D cols = tokens; k ascending as in the GEMM
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        if (b + 1 < 6) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) wf[(b + 1) & 1][c] = load_frag<bf16>(wrow + (size_t)(b + 1) * 32 * inner + c * 16);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mma(accy[b], wf[b & 1][c], of[c]);
-      }
-      {   // the attention output rows (saved for the projection's weight gradient): whole 128-byte lines, issued last
-        const int lane_ = lane_id_here();
-        const int rl = lane_ >> 3, seg = lane_ & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = i * 8 + rl;
-          if (w * 32 + r < N)
-            *reinterpret_cast<u32x4*>(p.out + ((size_t)img * N + w * 32 + r) * inner + h * HD + seg * 8) = orow[i];
-        }
-      }
-      if (h == heads - 1) {
-#pragma clang fp contract(off)
-        // ---------------- epilogue of the image: x_mid = accy + bp + x_in, xn2 = LayerNorm(x_mid) -- gemm_nt_kpipe's EPI_RES_LN
-        // arithmetic (8 lanes per row, 24 elements per lane, same summation order), a 64-feature third at a time
-        const int lane_ = lane_id_here();
-        const int rl = lane_ >> 3, l8 = lane_ & 7;
-        float xv[4][3][8];
-        const size_t row0 = (size_t)img * N + w * 32;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-          bf16x8 lr[4];        // (requested a head earlier they cost 48 registers the kernel does not have: 196 B of scratch, +11 us)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            int r = w * 32 + i * 8 + rl;
-            r = r < N ? r : N - 1;
-            lr[i] = *reinterpret_cast<const bf16x8*>(p.R + ((size_t)img * N + r) * E + v * 64 + l8 * 8);
-          }
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              const int nl = 64 * v + 32 * dt + 8 * rq + 4 * L.g;
-              f32x4 t4 = {accy[2 * v + dt][rq * 4 + 0], accy[2 * v + dt][rq * 4 + 1], accy[2 * v + dt][rq * 4 + 2], accy[2 * v + dt][rq * 4 + 3]};
-              t4 += *reinterpret_cast<const f32x4*>(p.bp + nl);
-              store4<bf16>(reinterpret_cast<bf16*>(stg + L.l31 * STG_PITCH) + dt * 32 + rq * 8 + L.g * 4, t4);
-            }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = i * 8 + rl;
-            const bf16x8 cv = *reinterpret_cast<const bf16x8*>(stg + r * STG_PITCH + l8 * 16);
-            bf16x8 xb;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              xb[e] = (bf16)((float)cv[e] + (float)lr[i][e]);        // the residual stream is bf16 ...
-              xv[i][v][e] = (float)xb[e];                            // ... and LayerNorm sees those values
-            }
-            if (w * 32 + r < N) *reinterpret_cast<bf16x8*>(p.X + (row0 + r) * E + v * 64 + l8 * 8) = xb;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        f32x4 gm[3][2], bt[3][2];
-#pragma unroll
-        for (int v = 0; v < 3; ++v)
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            gm[v][hf] = *reinterpret_cast<const f32x4*>(p.gamma + v * 64 + l8 * 8 + hf * 4);
-            bt[v][hf] = *reinterpret_cast<const f32x4*>(p.beta + v * 64 + l8 * 8 + hf * 4);
-          }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = i * 8 + rl;
-          float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-          for (int v = 0; v < 3; ++v) {
-            s0 += xv[i][v][0] + xv[i][v][1] + xv[i][v][2] + xv[i][v][3];
-            s1 += xv[i][v][4] + xv[i][v][5] + xv[i][v][6] + xv[i][v][7];
-          }
-          const float mu = group8_pair_sum(s0, s1) * (1.f / E);
-          float q0 = 0.f, q1 = 0.f;
-#pragma unroll
-          for (int v = 0; v < 3; ++v)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float d0 = xv[i][v][e] - mu, d1 = xv[i][v][4 + e] - mu;
-              q0 = __builtin_fmaf(d0, d0, q0);
-              q1 = __builtin_fmaf(d1, d1, q1);
-            }
-          const float rs = rsqrtf(__builtin_fmaf(group8_pair_sum(q0, q1), 1.f / E, p.eps));
-          if (w * 32 + r < N) {
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-              bf16x8 ob;
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                ob[e] = (bf16)__builtin_fmaf((xv[i][v][e] - mu) * rs, gm[v][e >> 2][e & 3], bt[v][e >> 2][e & 3]);
-              *reinterpret_cast<bf16x8*>(p.Y2 + (row0 + r) * E + v * 64 + l8 * 8) = ob;
-            }
-            if (l8 == 0) {
-              p.mean_o[row0 + r] = mu;
-              p.rstd_o[row0 + r] = rs;
-            }
-          }
-        }
-      }
-    }
-    if (!more) break;
-    img = ni; h = nh;
-  }
-}
+// (Round 6 pruned attn3_proj_fwd_kernel, option attn_proj: attention + output projection + LayerNorm of an image in one launch,
+// bit-equal but 47.7 us against 24.5 + 19.2 us for the two launches; the one-launch encoder kernels superseded it.)
 
 constexpr int SMEM_FWD = 2 * ARR;
 constexpr int SMEM_FWD3 = 4 * ARR + NTILE * STG_WAVE;
@@ -1385,30 +1100,6 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
   else
     hipLaunchKernelGGL(attn2_fwd_kernel<0>, dim3(B * heads), dim3(NTHREADS), SMEM_FWD, st, (const bf16*)qkv, (bf16*)out, lse,
                        N, heads, scale);
-  rgbnm_trace_end(slot, st);
-  LAUNCH_CHECK();
-  return RGBNM_OK;
-}
-
-// attention forward + projection + residual + LayerNorm in one launch; 1 = not eligible (the caller runs the launches apart)
-int rgbnm_launch_attn_proj_fwd(const void* qkv, void* out, float* lse, const void* Wp, const float* bp, const void* R, void* X,
-                               const float* gamma, const float* beta, void* Y2, float* mean, float* rstd, float eps, int B, int N,
-                               int heads, float scale, hipStream_t st) {
-  if (N != 196 || heads != 3 || B < 64 || !rgbnm_get_option("attn_persist") || !rgbnm_get_option("attn_proj")) return 1;
-  if (!qkv || !out || !lse || !Wp || !bp || !R || !X || !gamma || !beta || !Y2 || !mean || !rstd) return RGBNM_EINVAL;
-  static DevOnce attr;
-  if (attr.need()) {
-    if (hipFuncSetAttribute((const void*)attn3_proj_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWD3) != hipSuccess)
-      return RGBNM_ELAUNCH;
-    attr.done();
-  }
-  AttnProjArgs p;
-  p.qkv = (const bf16*)qkv; p.out = (bf16*)out; p.lse = lse; p.Wp = (const bf16*)Wp; p.bp = bp; p.R = (const bf16*)R; p.X = (bf16*)X;
-  p.gamma = gamma; p.beta = beta; p.Y2 = (bf16*)Y2; p.mean_o = mean; p.rstd_o = rstd; p.eps = eps; p.scale = scale; p.nimg = B;
-  const double bhn = (double)B * heads * N, M = (double)B * N;
-  // attention (q, k, v in; out) + projection (residual in; x_mid, xn2 out; the weight matrix once)
-  const int slot = rgbnm_trace_begin(TR_ATTN_FWD, 4.0 * bhn * N * HD + 2.0 * M * 192 * 192, bhn * HD * 2.0 * 4.0 + M * 192 * 2.0 * 3.0 + 2.0 * 192 * 192, st);
-  hipLaunchKernelGGL(attn3_proj_fwd_kernel, dim3(B < 256 ? B : 256), dim3(NTHREADS3), SMEM_FWD3, st, p);
   rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;

@@ -10,6 +10,15 @@ typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Timing experiments that produce WRONG numbers (kernels without their stores, their GELU, their LayerNorm ...: the sensitivity
+// builds of DESIGN_NOTES.md 9) exist as -D switches in the kernel sources; a build that defines one must also say
+// -DRGBNM_EXPERIMENTS, so that no release or test build can carry one by accident.
+#if (defined(X_NOLN) || defined(X_NOGELU) || defined(X_NOEXP) || defined(X_NOSAVE) || defined(X_HALFW) || defined(X_NOATTN) || \
+     defined(X_NOMLP) || defined(X_NOPIPE) || defined(KPX_NOGELU) || defined(KPX_NOC2) || defined(KPX_NOSTORE)) &&             \
+    !defined(RGBNM_EXPERIMENTS)
+#error "a wrong-numbers timing switch (X_NO* / X_HALFW / KPX_NO*) is defined without -DRGBNM_EXPERIMENTS"
+#endif
+
 #define RGBNM_OK 0
 #define RGBNM_EINVAL (-1)
 #define RGBNM_ELAUNCH (-2)

@@ -1,7 +1,7 @@
 // Table GELU for epilogues that hold bf16 pre-activations as packed pairs (mlp_fused.hip builds the table and documents it above
 // gelu_full_kernel: the library's own GELU arithmetic evaluated for all 65 536 bf16 inputs, a compact image of it -- 13 328 bytes --
 // at LDS offset 0, closed forms outside the image's window; tests/test_gelu_table.py).  Shared by the row-panel GEMM epilogues
-// (gemm_nt_kpipe_body.inc) and the streaming GEMM (gemm_nt_kstream.hip); the fused MLP and the chain kernels carry their own copy of
+// (gemm_nt_kpipe_body.inc); the fused MLP and the chain kernels carry their own copy of
 // the same instruction sequence.
 #pragma once
 #include "common.h"

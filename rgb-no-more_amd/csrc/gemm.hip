@@ -593,7 +593,7 @@ int tn_flush(hipStream_t st) {
 }
 
 bool tn_groupable(const GemmTN& p) {
-  return rgbnm_get_option("tn_pipe") && !rgbnm_get_option("tn_square") && p.M % 64 == 0 && p.M >= 64 &&
+  return rgbnm_get_option("tn_pipe") && p.M % 64 == 0 && p.M >= 64 &&
          p.Ki % 192 == 0 && p.No % 8 == 0 && p.ldy % 8 == 0 && p.ldx % 8 == 0;
 }
 

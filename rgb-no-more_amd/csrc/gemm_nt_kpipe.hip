@@ -23,15 +23,6 @@
 #undef KP_NWAVES
 #undef KP_NSTAGE
 #undef KP_BIAS_LDS
-#define KP_NS kp4
-#define KP_NWAVES 4
-#define KP_NSTAGE 2
-#define KP_BIAS_LDS false
-#include "gemm_nt_kpipe_body.inc"
-#undef KP_NS
-#undef KP_NWAVES
-#undef KP_NSTAGE
-#undef KP_BIAS_LDS
 
 // kp8: 8 waves x 32 rows = 256-row panels, 2-stage ring (112 KB), plain epilogues only.  For row counts that are multiples of
 // 256 but not of 224 -- the SwinV2-T stages at B = 256 (M = 2^20, 2^18, 2^16, 2^14) -- every round of workgroups is full:
@@ -59,16 +50,11 @@ static bool use_kp8(int M, int N, int) {
   return r8 * 105 < r7 * 100;
 }
 
-// Geometry choice: option "kp_split" = 1 runs the two-workgroups-per-CU geometry (kp4) for the single-column-tile shapes
-// (N = 192: proj / fc2 with the LayerNorm epilogue, the dX GEMMs with the LayerNorm backward); 0 = one 7-wave workgroup per CU.
-static bool use_split(int N) { return N == 192 && rgbnm_get_option("kp_split") != 0; }
-
 // x = A . W^T + bias + R ; y = LayerNorm(x): fc2 (+ the next block's LN1) and proj (+ LN2) in one launch each.
 int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* R,
                                  int ldr, void* x, int ldc, const float* gamma, const float* beta, void* y, int ldy,
                                  float* mean, float* rstd, float eps, int M, int N, int K, hipStream_t st) {
-  return use_split(N) ? kp4::launch_res_ln(A, lda, W, ldw, bias, R, ldr, x, ldc, gamma, beta, y, ldy, mean, rstd, eps, M, N, K, st)
-                      : kp7::launch_res_ln(A, lda, W, ldw, bias, R, ldr, x, ldc, gamma, beta, y, ldy, mean, rstd, eps, M, N, K, st);
+  return kp7::launch_res_ln(A, lda, W, ldw, bias, R, ldr, x, ldc, gamma, beta, y, ldy, mean, rstd, eps, M, N, K, st);
 }
 
 // dx = [dres +] LayerNorm'(A . W^T): the dX GEMM of fc1 / qkv with the LayerNorm backward fused into its epilogue
@@ -77,23 +63,14 @@ int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw,
 int rgbnm_launch_nt_kpipe_lnbwd(const void* A, int lda, const void* W, int ldw, const void* X, int ldx,
                                 const float* gamma, const float* mean, const float* rstd, const void* dres, int ldr,
                                 void* dx, int ldc, float* part, int* npanels_out, int M, int N, int K, hipStream_t st) {
-  return use_split(N) ? kp4::launch_lnbwd(A, lda, W, ldw, X, ldx, gamma, mean, rstd, dres, ldr, dx, ldc, part, npanels_out, M, N, K, st)
-                      : kp7::launch_lnbwd(A, lda, W, ldw, X, ldx, gamma, mean, rstd, dres, ldr, dx, ldc, part, npanels_out, M, N, K, st);
+  return kp7::launch_lnbwd(A, lda, W, ldw, X, ldx, gamma, mean, rstd, dres, ldr, dx, ldc, part, npanels_out, M, N, K, st);
 }
 
 // returns 1 when the shape is not eligible (caller falls back to the tile-per-workgroup kernel)
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st) {
-  // nt_kstream: 1 = the fc1 + GELU epilogue only (where it wins: 157 -> 125 us at E = 384, M = 50176), 2 = every eligible shape
-  // (the plain epilogues measure 10 - 15 % slower than the kernels below: its 32-wide k-tiles pay two barriers where they pay one)
-  const int ksopt = rgbnm_get_option("nt_kstream");
-  if (ksopt >= 2 || (ksopt == 1 && epi == 2)) {
-    const int rc = rgbnm_launch_nt_kstream(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
-    if (rc != 1) return rc;
-  }
   if (use_kp8(M, N, epi)) return kp8::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
-  return use_split(N) ? kp4::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st)
-                      : kp7::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
+  return kp7::launch_plain(epi, A, lda, W, ldw, C, ldc, bias, R, ldr, C2, ldc2, M, N, K, st);
 }
 
 #ifdef KP_PROF

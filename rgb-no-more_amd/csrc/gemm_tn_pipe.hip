@@ -349,174 +349,17 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// 192 x 192 output tile, 6 waves as 3(M) x 2(N), wave tile 64 x 96 (2 x 3 MFMA tiles).  The 128 x 192 kernel above
-// moves 640 B per token per workgroup from L2 and the chip-wide L2 -> CU traffic (193-257 MB per launch, 7-8 TB/s) is
-// what was suspected to bound it; the square tile moves 768 B per token for 1.5x the outputs (-35 % L2 traffic) and
-// needs 10 transpose reads per 6 MFMAs instead of 8 per 3.  MEASURED (B = 256): no faster (fc 30.8 vs 26-31 us, qkv
-// 26.0 vs 26 us) and the larger split count makes the partial reduction slower, so it is OFF by default
-// (option tn_square); kept as the parity-tested alternative for shapes where the 128-row tiling leaves a ragged tile.  Both operands use the 384-byte-row layout (64-byte segment ^ ((row>>1)&1)).
-constexpr int Q_ROW = 384;
-constexpr int Q_HALF = TK * Q_ROW;             // 24 KB per operand per stage
-constexpr int Q_STAGE = 2 * Q_HALF;            // 48 KB
-constexpr int Q_NSTAGE = 3;
-constexpr int Q_SMEM = Q_NSTAGE * Q_STAGE;     // 144 KB
-
-template <int C>
-__device__ __forceinline__ void tr_chunk_q(unsigned aA0, unsigned aA1, unsigned aB0, unsigned aB1, unsigned aB2,
-                                           Frag<bf16> (&fa)[2], Frag<bf16> (&fb)[3]) {
-  u32x2 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h, b2l, b2h;
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %10 offset:%15\n\t"
-      "ds_read_b64_tr_b16 %1, %10 offset:%16\n\t"
-      "ds_read_b64_tr_b16 %2, %11 offset:%15\n\t"
-      "ds_read_b64_tr_b16 %3, %11 offset:%16\n\t"
-      "ds_read_b64_tr_b16 %4, %12 offset:%15\n\t"
-      "ds_read_b64_tr_b16 %5, %12 offset:%16\n\t"
-      "ds_read_b64_tr_b16 %6, %13 offset:%15\n\t"
-      "ds_read_b64_tr_b16 %7, %13 offset:%16\n\t"
-      "ds_read_b64_tr_b16 %8, %14 offset:%15\n\t"
-      "ds_read_b64_tr_b16 %9, %14 offset:%16\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h), "=&v"(b2l),
-        "=&v"(b2h)
-      : "v"(aA0), "v"(aA1), "v"(aB0), "v"(aB1), "v"(aB2), "i"(C * 16 * Q_ROW), "i"(C * 16 * Q_ROW + 4 * Q_ROW)
-      : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  fa[0].v = pack8(a0l, a0h);
-  fa[1].v = pack8(a1l, a1h);
-  fb[0].v = pack8(b0l, b0h);
-  fb[1].v = pack8(b1l, b1h);
-  fb[2].v = pack8(b2l, b2h);
-}
-
-__global__ __launch_bounds__(384) void gemm_tn_pipe_q_kernel(TnPipe p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int ntile = p.rtiles * p.ctiles;
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int tile = jj % ntile, s = (jj / ntile) * 8 + xcd;
-  if (s >= p.S) return;
-  const int rt = tile / p.ctiles, ct = tile % p.ctiles;
-  const int r0 = rt * 192, c0 = ct * 192;
-  const int kt0 = s * p.kt_per_split;
-  const int T = min(p.kt_per_split, p.M / TK - kt0);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  const int l31 = lane & 31, g = lane >> 5;
-
-  // ---- global source offsets of this wave's 4 + 4 LDS-DMA instructions per token tile (24 per operand)
-  int offA[4], offB[4];
-  const int vmaxA = (min(p.No - r0, 192) >> 3) - 1;     // clamp feature vectors of a ragged last row tile
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int pidx = (w + 6 * j) * 64 + lane;
-    const int row = pidx / 24, pv = pidx % 24;
-    int v = (((pv >> 2) ^ ((row >> 1) & 1)) << 2) | (pv & 3);
-    offB[j] = row * p.ldx + c0 + v * 8;
-    v = v < vmaxA ? v : vmaxA;
-    offA[j] = row * p.ldy + r0 + v * 8;
-  }
-  const bf16* gA = p.dY + (size_t)kt0 * TK * p.ldy;
-  const bf16* gB = p.X + (size_t)kt0 * TK * p.ldx;
-  const size_t stepA = (size_t)TK * p.ldy, stepB = (size_t)TK * p.ldx;
-  auto issue = [&](int stage) {
-    unsigned char* st = smem + stage * Q_STAGE + w * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(gA + offA[j]), (lds_ptr)(st + j * 6144), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(gB + offB[j]), (lds_ptr)(st + Q_HALF + j * 6144), 16, 0, 0);
-    gA += stepA;
-    gB += stepB;
-  };
-
-  // ---- per-lane LDS byte offsets of the transpose reads
-  const int k = (lane >> 2) & 3;
-  const int within = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
-  const int kb = (k >> 1) & 1;
-  const unsigned lds0 = (unsigned)(size_t)smem;
-  const unsigned rowo = (8 * g + k) * Q_ROW + within;
-  const unsigned oA0 = rowo + (((2 * wm + 0) ^ kb) << 6), oA1 = rowo + (((2 * wm + 1) ^ kb) << 6);
-  const unsigned oB0 = Q_HALF + rowo + (((3 * wn + 0) ^ kb) << 6);
-  const unsigned oB1 = Q_HALF + rowo + (((3 * wn + 1) ^ kb) << 6);
-  const unsigned oB2 = Q_HALF + rowo + (((3 * wn + 2) ^ kb) << 6);
-
-  f32x16 acc[2][3], accb[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; acc[a][2][r] = 0.f; accb[a][r] = 0.f;
-    }
-  }
-  const bool do_bias = (p.bpart != nullptr) && (ct == 0) && (wn == 0);
-  Frag<bf16> ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones.v[e] = (bf16)1.0f;
-
-  int st_issue = 0, st_comp = 0;
-  issue(0);
-  st_issue = 1;
-  if (T > 1) {
-    issue(1);
-    st_issue = 2;
-  }
-  for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();     // tile t landed for every wave; every wave is done with tile t-1
-    if (t + 2 < T) {
-      issue(st_issue);
-      st_issue = st_issue == Q_NSTAGE - 1 ? 0 : st_issue + 1;
-    }
-    const unsigned sb = lds0 + st_comp * Q_STAGE;
-    st_comp = st_comp == Q_NSTAGE - 1 ? 0 : st_comp + 1;
-    Frag<bf16> fa[2], fb[3];
-#define CHUNKQ(C)                                                              \
-    tr_chunk_q<C>(sb + oA0, sb + oA1, sb + oB0, sb + oB1, sb + oB2, fa, fb);   \
-    mma(acc[0][0], fa[0], fb[0]); mma(acc[0][1], fa[0], fb[1]); mma(acc[0][2], fa[0], fb[2]); \
-    mma(acc[1][0], fa[1], fb[0]); mma(acc[1][1], fa[1], fb[1]); mma(acc[1][2], fa[1], fb[2]); \
-    if (do_bias) { mma(accb[0], fa[0], ones); mma(accb[1], fa[1], ones); }
-    CHUNKQ(0) CHUNKQ(1) CHUNKQ(2) CHUNKQ(3)
-#undef CHUNKQ
-  }
-
-  float* part = p.part + (size_t)s * p.No * p.Ki;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const int col = c0 + wn * 96 + b * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = r0 + wm * 64 + a * 32 + acc_row(r, lane);
-        if (row < p.No) part[(size_t)row * p.Ki + col] = acc[a][b][r];
-      }
-    }
-  if (do_bias && l31 == 0) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = r0 + wm * 64 + a * 32 + acc_row(r, lane);
-        if (row < p.No) p.bpart[(size_t)s * p.No + row] = accb[a][r];
-      }
-  }
-}
+// (Round 6 pruned the 192 x 192 / 6-wave variant, option tn_square: measured no faster at B = 256 and slower in its reduction.)
 
 }  // namespace
 
 namespace {
 
-int tn_fill(TnPipe& p, const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No, int Ki,
-            bool square) {
+int tn_fill(TnPipe& p, const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No, int Ki) {
   if (M % TK || Ki % 192 || No % 8 || ldy % 8 || ldx % 8 || M < TK) return 1;
   p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.part = part; p.bpart = bpart;
   p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki;
-  p.rtiles = cdiv(No, square ? 192 : 128);
+  p.rtiles = cdiv(No, 128);
   p.ctiles = Ki / 192;
   return 0;
 }
@@ -540,7 +383,7 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
     const RgbnmTnJob& j = jobs[i];
     if (j.M != jobs[0].M) return 1;
     TnPipe t;
-    if (tn_fill(t, j.dY, j.ldy, j.X, j.ldx, j.part, j.bpart, j.M, j.No, j.Ki, false)) return 1;
+    if (tn_fill(t, j.dY, j.ldy, j.X, j.ldx, j.part, j.bpart, j.M, j.No, j.Ki)) return 1;
     tiles += t.rtiles * t.ctiles;
     TnJobK& q = g.j[i];
     q.dY = t.dY; q.X = t.X; q.part = t.part; q.bpart = t.bpart; q.ldy = t.ldy; q.ldx = t.ldx; q.No = t.No; q.Ki = t.Ki;
@@ -609,35 +452,8 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
 
 int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
                          int Ki, int* S_out, hipStream_t st) {
-  const bool square = rgbnm_get_option("tn_square") && cdiv(No, 192) * (Ki / 192) >= 3;
-  if (!square) {
-    RgbnmTnJob j;
-    j.dY = dY; j.X = X; j.part = part; j.bpart = bpart; j.ldy = ldy; j.ldx = ldx; j.M = M; j.No = No; j.Ki = Ki;
-    j.dW = nullptr; j.db = nullptr; j.perm_heads = 0; j.accumulate = 0;
-    return rgbnm_launch_tn_pipe_group(&j, 1, S_out, st);
-  }
-  TnPipe p;
-  if (tn_fill(p, dY, ldy, X, ldx, part, bpart, M, No, Ki, true)) return 1;
-  const int tiles = p.rtiles * p.ctiles;
-  const int ktiles = M / TK;
-  int S = 256 / tiles;
-  if (S >= 8) S = S / 8 * 8;
-  if (S < 1) S = 1;
-  if (S > RGBNM_TN_MAX_SPLIT) S = RGBNM_TN_MAX_SPLIT;
-  if (S > ktiles) S = ktiles;
-  p.kt_per_split = cdiv(ktiles, S);
-  S = cdiv(ktiles, p.kt_per_split);
-  p.S = S;
-  *S_out = S;
-  const int slot = rgbnm_trace_begin(TR_TN, 2.0 * M * (double)No * Ki, ((double)M * No + (double)M * Ki) * 2.0 + (double)No * Ki * 4.0, st);
-  static DevOnce attr_q;
-  if (attr_q.need()) {
-    if (hipFuncSetAttribute((const void*)gemm_tn_pipe_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM) != hipSuccess)
-      return RGBNM_ELAUNCH;
-    attr_q.done();
-  }
-  hipLaunchKernelGGL(gemm_tn_pipe_q_kernel, dim3(tiles * ((S + 7) / 8) * 8), dim3(384), Q_SMEM, st, p);
-  rgbnm_trace_end(slot, st);
-  LAUNCH_CHECK();
-  return RGBNM_OK;
+  RgbnmTnJob j;
+  j.dY = dY; j.X = X; j.part = part; j.bpart = bpart; j.ldy = ldy; j.ldx = ldx; j.M = M; j.No = No; j.Ki = Ki;
+  j.dW = nullptr; j.db = nullptr; j.perm_heads = 0; j.accumulate = 0;
+  return rgbnm_launch_tn_pipe_group(&j, 1, S_out, st);
 }

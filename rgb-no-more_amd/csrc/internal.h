@@ -30,12 +30,6 @@ int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N,
 int rgbnm_launch_attn2_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
                            int N, int heads, float scale, hipStream_t st);
 
-// attention forward + output projection + residual + LayerNorm of one ViT block in one launch (attention_v2.hip: 196 tokens,
-// 3 heads, bf16); 1 = not eligible.
-int rgbnm_launch_attn_proj_fwd(const void* qkv, void* out, float* lse, const void* Wp, const float* bp, const void* R, void* X,
-                               const float* gamma, const float* beta, void* Y2, float* mean, float* rstd, float eps, int B, int N,
-                               int heads, float scale, hipStream_t st);
-
 // per-kernel HIP-event tracing (vit.hip); tags: 1 gemm_nt, 2 gemm_tn, 3 attention fwd, 4 attention bwd, 5 / 6 the one-launch encoder
 // forward / backward (vit_chain.hip, vit_chain_bwd.hip); the HBM-bound classes of SURVEY 8d: 7 augment stage (dct_resize +
 // dct_randaug as one bracket), 8 sub-block embed, 9 clip + AdamW + WeightDecay (sqnorm + adamw as one bracket)
@@ -46,10 +40,6 @@ int rgbnm_launch_nt_wres(int epi, const void* A, int lda, const void* W, int ldw
 // Row-panel N = 192 bf16 NT GEMM with a pipelined reduction (gemm_nt_kpipe.hip).  Same return convention.
 int rgbnm_launch_nt_kpipe(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
                           const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st);
-// Streaming row-panel GEMM for N >= 384 (gemm_nt_kstream.hip): a unit's epilogue and stores run under the next unit's reduction.
-// Same arguments and return convention as rgbnm_launch_nt_kpipe.
-int rgbnm_launch_nt_kstream(int epi, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
-                            const void* R, int ldr, void* C2, int ldc2, int M, int N, int K, hipStream_t st);
 // Linear + bias + residual + LayerNorm of the result in one launch (gemm_nt_kpipe.hip); 1 = not eligible.
 int rgbnm_launch_nt_kpipe_res_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* R,
                                  int ldr, void* x, int ldc, const float* gamma, const float* beta, void* y, int ldy,

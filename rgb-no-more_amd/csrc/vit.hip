@@ -32,7 +32,7 @@ hipEvent_t take_event() {
 // process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
 // they select between parity-tested kernels and are meant to be set before work is enqueued
 struct Opt { const char* name; std::atomic<int> value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_square", 0}, {"nt_dmawave", 0}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"kp_split", 0}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"attn_proj", 0}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}, {"bwd_chain", 1}, {"tn_direct", 1}, {"tn_pack", 1}, {"nt_kstream", 0}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}, {"bwd_chain", 1}, {"tn_direct", 1}, {"tn_pack", 1}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -119,7 +119,7 @@ static bool fused_dx_lnbwd(int dt, const void* A, int lda, const void* Wt, int l
                            const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
                            float* dbeta, int M, int E, int K, void* ws, size_t ws_bytes, hipStream_t st) {
   if (dt != RGBNM_DT_BF16 || E != 192 || !rgbnm_get_option("ln_fuse") || !rgbnm_get_option("nt_kpipe")) return false;
-  if (ws_bytes < (size_t)cdiv(M, cdiv(M, 512)) * 2 * E * sizeof(float)) return false;    // up to 512 row panels (kp_split)
+  if (ws_bytes < (size_t)cdiv(M, cdiv(M, 512)) * 2 * E * sizeof(float)) return false;    // up to 512 row panels
   int npanels = 0;
   const int rc = rgbnm_launch_nt_kpipe_lnbwd(A, lda, Wt, ldw, x, E, gamma, mean, rstd, dres, E, dx, E, (float*)ws,
                                              &npanels, M, E, K, st);
@@ -194,19 +194,9 @@ int rgbnm_vit_block_fwd_chain(const rgbnm_vit_cfg* c, const rgbnm_block_params* 
     TRY(rgbnm_layernorm_fwd(dt, a->x_in, p->ln1_g, p->ln1_b, a->xn1, a->mean1, a->rstd1, M, E, c->ln_eps, st));
   TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_NONE, a->xn1, E, p->wqkv, E, a->qkv, 3 * I, p->bqkv_perm, 0, 0, 0, 0, 0, 0, M,
                     3 * I, E, 0, st));
-  // attention + projection + residual + LN2 in ONE launch when eligible (attention_v2.hip, option attn_proj)
-  bool attn_done = false;
-  if (chain && dt == RGBNM_DT_BF16 && E == 192) {
-    const int rc = rgbnm_launch_attn_proj_fwd(a->qkv, a->attn, a->lse, p->wproj, p->bproj, a->x_in, a->x_mid, p->ln2_g, p->ln2_b,
-                                              a->xn2, a->mean2, a->rstd2, c->ln_eps, c->B, c->N, c->heads, c->attn_scale,
-                                              (hipStream_t)st);
-    if (rc < 0) return rc;
-    attn_done = rc == RGBNM_OK;
-  }
-  if (!attn_done) TRY(rgbnm_attention_fwd(dt, a->qkv, a->attn, a->lse, c->B, c->N, c->heads, c->attn_scale, st));
+  TRY(rgbnm_attention_fwd(dt, a->qkv, a->attn, a->lse, c->B, c->N, c->heads, c->attn_scale, st));
   // x_mid = x_in + proj(attn) ; xn2 = LN2(x_mid): one launch when chaining is on
-  if (attn_done) {
-  } else if (!chain || rgbnm_launch_nt_kpipe_res_ln(a->attn, I, p->wproj, I, p->bproj, a->x_in, E, a->x_mid, E, p->ln2_g,
+  if (!chain || rgbnm_launch_nt_kpipe_res_ln(a->attn, I, p->wproj, I, p->bproj, a->x_in, E, a->x_mid, E, p->ln2_g,
                                              p->ln2_b, a->xn2, E, a->mean2, a->rstd2, c->ln_eps, M, E, I,
                                              (hipStream_t)st) != RGBNM_OK) {
     TRY(rgbnm_gemm_nt(dt, RGBNM_EPI_RES, a->attn, I, p->wproj, I, a->x_mid, E, p->bproj, a->x_in, E, 0, 0, 0, 0, M, E,

@@ -13,6 +13,7 @@ on the generic GEMM tiles.
 import ctypes as C
 import itertools
 import threading
+import warnings
 import math
 
 import numpy as np
@@ -589,10 +590,7 @@ class SwinTransformerV2(FlatParamModule):
         # weight gradients then exist only when backward() has returned, which torch DDP's reducer hooks do not wait for
         self.group_dw_backward = False
         self._conv = None
-        # set-up call (synchronises once per device, so not inside a graph capture): the GELU table of the fc1 + GELU epilogues
-        # (rgbnm.h rgbnm_gelu_table_init; without it those epilogues use the arithmetic form -- the same bits, more instructions)
-        if torch.cuda.is_available():
-            L.check(L.lib().rgbnm_gelu_table_init(L.stream()), "gelu_table_init")
+        self._table_devs = set()                    # devices whose GELU table this model has made sure of (forward, lazily)
 
     @staticmethod
     def _init_weights(m):
@@ -617,6 +615,19 @@ class SwinTransformerV2(FlatParamModule):
         y = y.materialize() if isinstance(y, LazyMixed) else y
         cbcr = cbcr.materialize() if isinstance(cbcr, LazyMixed) else cbcr
         L.require_cuda(y, cbcr)
+        if y.device.index not in self._table_devs:
+            # set-up call, once per device the model actually runs on (it synchronises, so it must not fall into a graph capture:
+            # run one eager forward first, as bench.py does): the GELU table of the fc1 + GELU epilogues (rgbnm.h
+            # rgbnm_gelu_table_init; without it those epilogues use the arithmetic form -- the same bits, more instructions)
+            if not torch.cuda.is_current_stream_capturing():
+                with torch.cuda.device(y.device):
+                    L.check(L.lib().rgbnm_gelu_table_init(L.stream()), "gelu_table_init")
+                self._table_devs.add(y.device.index)
+            elif not getattr(self, "_warned_table", False):
+                self._warned_table = True
+                warnings.warn("rgb-no-more_amd: first SwinTransformerV2 forward on this device is being captured into a graph: the "
+                              "GELU table cannot be set up here, the fc1 + GELU epilogues run their arithmetic form (same bits, "
+                              "slower); run one eager forward before capturing", RuntimeWarning, stacklevel=2)
         B, _, Hb, Wb, _, _ = y.shape
         res = self.patches_resolution[0]
         if y.dim() != 6 or (2 * Hb, 2 * Wb) != (res, res) or tuple(cbcr.shape) != (B, 2, Hb // 2, Wb // 2, 8, 8):

@@ -25,11 +25,12 @@ def _free_port():
     return p
 
 
-def _run(extra, timeout=900, **more_env):
+def _run(extra, timeout=900, nproc=2, **more_env):
     env = dict(os.environ, RGBNM_BENCH_SAME_DEVICE="1", RGBNM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **more_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.update(more_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "4", "--warmup", "1",
            "--prewarm-sec", "0.2", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:            # one more try on a fresh port: the probe-then-bind of _free_port can lose a race on a busy box
@@ -87,4 +88,21 @@ def test_bench_two_ranks_swinv2_gathered_flat_exchange():
     assert d["n_gpus"] == 2 and d["config"]["grad_sync"].startswith("flat-gathered"), d["config"]["grad_sync"]
     assert d["config"]["global_batch"] == 64
     loss = d["config"]["loss"]
+    assert loss == loss and 0 < loss < 20
+
+
+def test_bench_eight_ranks_at_the_world_size_of_config_3():
+    """BASELINE config 3 names 8 ranks.  No 8-GPU node exists here, so the EIGHT-way code path runs on the lease's one MI355X
+    (per-rank batch 32 so that eight processes fit, gloo): process group of 8, the 8 per-rank shards (seed + rank), the
+    flat-exchange self-check against one blocking all-reduce on every rank, the six-schedule calibration with its MIN / MAX
+    reductions over 8 ranks, max-over-ranks timing and the one JSON line.  Reference: train.py:137, :145-176, datasets.py:533-535."""
+    d = _run(["--batch", "32", "--no-parity-check", "--no-trace"], timeout=1500, nproc=8, OMP_NUM_THREADS="1")
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak"
+    cfg = d["config"]
+    assert cfg["global_batch"] == 8 * cfg["per_gpu_batch"] == 256 and cfg["parallelism"] == "dp8"
+    assert cfg["grad_sync"].startswith("flat"), cfg["grad_sync"]
+    cal = cfg["grad_sync_calibration_ms_per_step"]
+    assert len(cal) == 6 and all(v > 0 for v in cal.values()), cal
+    assert d["value"] > 0 and abs(d["value"] - 256 / (d["ms_per_step"] / 1e3)) < 0.01 * d["value"]
+    loss = cfg["loss"]
     assert loss == loss and 0 < loss < 20

@@ -246,117 +246,6 @@ def test_fused_mlp_forward_equals_the_two_gemm_path():
         L.check(lib.rgbnm_set_option(b"mlp_dmast", old))
 
 
-def test_fused_mlp_backward_equals_the_two_gemm_path():
-    """mlp_bwd_kernel (dGELU product + fc1 dX + LayerNorm backward in one launch, du kept in registers for the second product)
-    against gemm_nt_wres<DGELU> + gemm_nt_kpipe<LNBWD>: same roundings (du = bf16(bf16(acc) * gelu')), same k order, the same
-    LayerNorm-backward helpers (common.h ln_bwd_acc / ln_bwd_dx: explicit FMAs, opaque products) and panel partition, so every
-    gradient -- including the dW1 GEMM that reads the du this kernel writes, and LN2's dgamma / dbeta from its panel partial
-    sums -- must agree bit for bit."""
-    lib = L.lib()
-    m, sd, y, c, tgt = build("ti_d2_b64", torch.bfloat16)
-    m.train()
-
-    def grads():
-        m.zero_grad()
-        logits = m(y, c)
-        ar = logits.grad_fn.st.arena
-        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
-        torch.cuda.synchronize()
-        out = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
-        out["scratch.du"], out["scratch.dx_mid"] = ar.du.clone(), ar.dx_mid.clone()      # block 0's (processed last)
-        return out
-
-    assert lib.rgbnm_get_option(b"mlp_bwd") == 1
-    fused = grads()
-    try:
-        L.check(lib.rgbnm_set_option(b"mlp_bwd", 0))
-        plain = grads()
-    finally:
-        L.check(lib.rgbnm_set_option(b"mlp_bwd", 1))
-    for n in fused:
-        assert torch.equal(fused[n], plain[n]), n
-    old = lib.rgbnm_get_option(b"mlp_dmast")               # du tiles of waves 4-6 through the DMA wave: same bits, every time
-    try:
-        L.check(lib.rgbnm_set_option(b"mlp_dmast", 1 - old))
-        for rep in range(3):
-            other = grads()
-            for n in other:
-                assert torch.equal(other[n], plain[n]), (n, rep)
-    finally:
-        L.check(lib.rgbnm_set_option(b"mlp_dmast", old))
-
-
-def test_row_panel_gemm_two_workgroups_per_cu_equals_one():
-    """gemm_nt_kpipe in its two geometries (option kp_split: 4-wave workgroups, two per CU, 2-stage ring / one 7-wave workgroup
-    per CU, 3-stage ring): per row the arithmetic is the same (k order, bf16 staging, LayerNorm butterflies), so logits, saved
-    activations and every gradient that does not depend on the panel count are bit-identical; the LayerNorm gamma / beta
-    gradients are sums over a different number of panel partials (fp32 rounding only)."""
-    lib = L.lib()
-    m, sd, y, c, tgt = build("ti_d2_b64", torch.bfloat16)
-    m.train()
-
-    def snapshot():
-        m.zero_grad()
-        logits = m(y, c)
-        ar = logits.grad_fn.st.arena
-        snap = {"x1": ar.x[1].clone(), "xn2_0": ar.blk[0]["xn2"].clone(), "xn1_1": ar.blk[1]["xn1"].clone(),
-                "rstd1_1": ar.blk[1]["rstd1"].clone(), "logits": logits.detach().clone()}
-        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
-        snap["grads"] = {n: p.grad.clone() for n, p in m.named_parameters()}
-        return snap
-
-    assert lib.rgbnm_get_option(b"kp_split") == 0       # default: one workgroup per CU (measured faster)
-    one = snapshot()
-    try:
-        L.check(lib.rgbnm_set_option(b"kp_split", 1))
-        two = snapshot()
-    finally:
-        L.check(lib.rgbnm_set_option(b"kp_split", 0))
-    for k in ("x1", "xn2_0", "xn1_1", "rstd1_1", "logits"):
-        assert torch.equal(two[k], one[k]), k
-    for n in two["grads"]:
-        a, b = two["grads"][n], one["grads"][n]
-        if "lrnorm" in n and "classhead" not in n:
-            assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), n
-        else:
-            assert torch.equal(a, b), n
-
-
-@pytest.mark.parametrize("tag", ["ti_d2_b64", "ti_d12_b256"])
-def test_fused_attention_projection_equals_the_separate_launches(tag):
-    """attn3_proj_fwd_kernel (option attn_proj, default off: measured slower): attention of the three heads of an image, the
-    output projection, the residual add and LayerNorm 2 in one launch -- same operand rounding, same k order, same row
-    arithmetic as attn3_fwd + gemm_nt_kpipe<EPI_RES_LN>, so the saved attention output, the log-sum-exp, x_mid, LN2's output and
-    statistics, the logits and every gradient agree bit for bit."""
-    lib = L.lib()
-    m, sd, y, c, tgt = build(tag, torch.bfloat16)
-    m.train()
-
-    def snapshot():
-        m.zero_grad()
-        logits = m(y, c)
-        ar = logits.grad_fn.st.arena
-        torch.cuda.synchronize()
-        b0, bl = ar.blk[0], ar.blk[-1]
-        snap = {"attn0": b0["attn"].clone(), "lse0": b0["lse"].clone(), "x_mid0": b0["x_mid"].clone(), "xn2_0": b0["xn2"].clone(),
-                "mean2_0": b0["mean2"].clone(), "rstd2_0": b0["rstd2"].clone(), "x_mid_last": bl["x_mid"].clone(),
-                "logits": logits.detach().clone()}
-        rg.cls_transforms.cross_entropy(logits, tgt, grad_dtype=torch.bfloat16).backward()
-        snap["grads"] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
-        return snap
-
-    old = lib.rgbnm_get_option(b"attn_proj")
-    try:
-        L.check(lib.rgbnm_set_option(b"attn_proj", 0))
-        plain = snapshot()
-        L.check(lib.rgbnm_set_option(b"attn_proj", 1))
-        fused = snapshot()
-    finally:
-        L.check(lib.rgbnm_set_option(b"attn_proj", old))
-    for k in fused:
-        assert torch.equal(fused[k], plain[k]), k
-
-
 @pytest.mark.parametrize("compute", [torch.bfloat16, torch.float32])
 def test_jpeg_s_at_the_timed_batch_256_vs_reference_golden(golden, compute):
     """g21 (make_golden_r4.py): the reference JPEG-S (E = 384, depth 12) at B = 256 -- the batch bench.py --arch vits times, where

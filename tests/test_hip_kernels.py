@@ -548,11 +548,6 @@ def test_gemm_nt_bf16_row_panel_path(option, M, K):
     assert relerr(outs[1][2], base + b + R.float()) < 6e-3
     for _ in range(3):
         assert torch.equal(gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], outs[1][2])
-    # nt_dmawave=1: an eighth wave issues the ring's LDS-DMAs (measured: no faster, the kernel is bounded by the L2 -> CU
-    # fabric, not by vmem issue; kept as a parity-tested alternative)
-    option("nt_dmawave", 1)
-    assert torch.equal(gemm_nt(dt, L.EPI_RES, A, W, b, R=R)[0], outs[1][2])
-    assert torch.equal(gemm_nt(dt, L.EPI_NONE, A, W, b)[0], outs[1][1])
 
 
 @pytest.mark.parametrize("M,N,K", [(224 * 40 + 17, 384, 384), (50176, 1152, 384), (12544, 1536, 384), (9000, 384, 1536),
@@ -590,10 +585,8 @@ def test_attention_bf16_backward_schedules(option, persist):
         test_attention_fwd_bwd(torch.bfloat16, *shp)
 
 
-@pytest.mark.parametrize("sq", [0, 1])
-def test_gemm_tn_bf16_square_tile_path(option, sq):
-    """tn_square=1: 192 x 192 output tiles (6 waves) for weight gradients with >= 3 such tiles; 0: 128 x 192 tiles."""
-    option("tn_square", sq)
+def test_gemm_tn_bf16_large_and_ragged_shapes():
+    """The pipelined weight-gradient kernel (128 x 192 tiles) on the shapes of the ViT / JPEG-S blocks, the head and ragged rows."""
     for shp in [(50176, 768, 192, 0), (50176, 192, 768, 0), (50176, 576, 192, 3), (64 * 49, 576, 192, 3),
                 (256, 1000, 192, 0), (64 * 100, 1152, 384, 6), (64 * 30, 384, 384, 0)]:
         test_gemm_tn(torch.bfloat16, *shp)

@@ -34,7 +34,7 @@ def main():
         M = int(sys.argv[3])
     lib = L.lib()
     L.check(lib.rgbnm_gelu_table_init(L.stream()))      # as the model constructors do: the fc1 + GELU epilogue's table form
-    for kv in sys.argv[4:]:                      # library options, e.g. kp_split=2
+    for kv in sys.argv[4:]:                      # library options, e.g. kp_persist=0
         k, v = kv.split("=")
         L.check(lib.rgbnm_set_option(k.encode(), int(v)))
     dt = torch.bfloat16

@@ -27,7 +27,7 @@ def timeit(fn, n=20):
 def main():
     E, M = int(sys.argv[1]), int(sys.argv[2])
     lib = L.lib()
-    for kv in sys.argv[3:]:                      # library options, e.g. tn_square=1
+    for kv in sys.argv[3:]:                      # library options, e.g. tn_pack=0
         k, v = kv.split("=")
         L.check(lib.rgbnm_set_option(k.encode(), int(v)))
     dt = torch.bfloat16
