@@ -397,6 +397,7 @@ def main():
         model.defer_grad_reduction = True
     if swin and world == 1 and not a.no_defer_reduce:
         model.group_dw_backward = True          # SwinTransformerV2: the weight-gradient GEMMs of the whole backward in one bracket
+        model.hold_reductions = os.environ.get("RGBNM_SWIN_HOLD", "1") == "1"     # ... and its split-sum reductions as one launch
     net = model
     grad_sync = "none"
     if world > 1:
@@ -520,8 +521,16 @@ def main():
                     torch.cuda.synchronize()
                     gv_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
                     if not torch.equal(gv_loss.detach(), v_loss) or not torch.equal(gv_grad, v_grad):
+                        off, worst = 0, []
+                        for n_, p_ in model.named_parameters():          # which gradients: the message names the three worst
+                            d_ = (gv_grad[off:off + p_.numel()] - v_grad[off:off + p_.numel()]).abs().max().item()
+                            off += p_.numel()
+                            if d_ > 0:
+                                worst.append((d_, n_))
+                        worst.sort(reverse=True)
                         raise RuntimeError("graph replay (DropPath off) does not reproduce the eager pass bit for bit: max |d grad| "
-                                           f"{(gv_grad - v_grad).abs().max().item():.3e}")
+                                           f"{(gv_grad - v_grad).abs().max().item():.3e}; {len(worst)} gradients differ, worst {worst[:3]}; "
+                                           f"loss {float(gv_loss):.6f} vs {float(v_loss):.6f}")
                     del gv, gv_loss, gv_grad, v_grad
                 finally:
                     model.train()

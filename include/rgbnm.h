@@ -94,6 +94,10 @@ int rgbnm_gemm_nt(int dtype, int epi, const void* A, int lda, const void* W, int
  * perm_heads > 0: rows of dW/db are written in the reference's interleaved '(h d qkv)' order
  * (plainvit.py:447) although dY's columns are [q|k|v] blocks.  accumulate != 0: += into dW/db. */
 size_t rgbnm_gemm_tn_workspace(int M, int No, int Ki);
+/* ... or room for `splits` (1 .. 128) slices of fp32 partial sums only: rgbnm_gemm_tn takes any workspace of at least one slice and
+ * splits the token axis no further than the workspace allows (a job queued in a group bracket is split at most 256 / its own
+ * 128 x 192 output tiles ways: swinv2.py sizes its queued jobs' workspaces by that -- 13 GB of scratch per backward before) */
+size_t rgbnm_gemm_tn_workspace_splits(int No, int Ki, int splits);
 int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int No,
                   int Ki, int perm_heads, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -138,6 +142,11 @@ typedef struct rgbnm_linear_desc {
                           96-wide Linear (SwinV2-T stage 1) then runs on the kernels tuned for 192-wide rows            */
   int chain_kind;      /* rgbnm_prep_weights_chain: 0, or which Linear of an encoder block this is: 1 qkv, 2 projection, 3 fc1, 4 fc2 */
   long long chain_off; /* ... and the element offset of that block's image inside the forward / backward chain images */
+  int bias_mode;       /* bias_perm[bperm_off ..] also receives (perm_heads == 0): 1 the bias b_off as it is; 2 the SwinV2 qkv bias
+                          q_bias | 0 | v_bias (swinv2.py:150-152: k has no bias), q_bias at b_off, v_bias at b2_off, N / 3 each.
+                          With `pair` the N values are written twice (the operand of the row-paired GEMM): 2N floats */
+  int _pad2;
+  long long b2_off;
 } rgbnm_linear_desc;
 
 /* master fp32 -> per-step operand shadows for every Linear (descs_dev: device array of ndesc descriptors). */
@@ -434,7 +443,9 @@ int rgbnm_gelu_table_info(int* win16, unsigned* full65536);
  * bits).  `table` is a device buffer and `table_host` a HOST buffer of the same size, both owned by the caller, allocated
  * together (table_host zero-filled) and freed together, untouched between steps: table_host records what the device table
  * holds, and the job table is uploaded only when it differs from that record (so a graph capture of a steady-state pass
- * contains no copy; a pass whose table changed returns RGBNM_EINVAL when the stream is capturing).  The partial sums live in
+ * contains no copy; a pass whose table changed while the stream is capturing is captured WITH its upload when table_host is
+ * page-locked -- the copy node reads table_host at every replay, so it must stay untouched while the graph lives -- and returns
+ * RGBNM_EINVAL when it is pageable).  The partial sums live in
  * the workspaces until _end: regions must not be shared between the calls of one bracket.  One bracket per host thread:
  * _begin inside an open bracket returns RGBNM_EINVAL.  rgbnm_reduce_hold_cancel() leaves the mode without running anything
  * (error paths). */
@@ -501,14 +512,34 @@ int rgbnm_ln_generic_bwd(int dtype, const void* dy, const void* x, const float* 
  * qkv [B, res*res, 3C] (q | k | v, heads of 32), bias [heads, 64, 64] fp32 (= 16 sigmoid(cpb_mlp(table))[index]),
  * scale [heads] fp32 (= exp(min(logit_scale, ln 100))), shift in {0, 4}: window 8x8, cosine attention, shift mask -100.
  * out [B, res*res, C]; lse [B * nW * heads * 64] saved for backward.  Backward writes dbias (per-wave partials in the
- * workspace, deterministic reduction) and one partial d(scale) per (window, head) into dscale_part [B * nW * heads]. */
+ * workspace, deterministic reduction), one partial d(scale) per (window, head) into dscale_part [B * nW * heads] and -- when
+ * dscale is not NULL -- their sum into dscale [heads] (a job of the same batched reduction). */
 int rgbnm_window_attention_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, float* lse,
                                int B, int res, int C, int heads, int shift, void* stream);
 size_t rgbnm_window_attention_bwd_workspace(int B, int res, int heads);
 int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
-                               const float* bias_t /* [heads,64(key),64(query)]: bias transposed */, const float* scale,
-                               const float* lse, void* dqkv, float* dbias, float* dscale_part, int B, int res, int C,
-                               int heads, int shift, void* workspace, size_t workspace_bytes, void* stream);
+                               float* dscale /* [heads] or NULL */, const float* scale, const float* lse, void* dqkv,
+                               float* dbias, float* dscale_part, int B, int res, int C, int heads, int shift, void* workspace,
+                               size_t workspace_bytes, void* stream);
+/* Continuous position bias + logit scale of EVERY WindowAttention of the model (swinv2.py:158-168: cpb_mlp on the 15 x 15
+ * relative_coords_table, gathered by relative_position_index, 16 sigmoid; exp of the clamped logit_scale) in two launches per
+ * direction.  blocks: HOST array (copied into the kernels' arguments; any count, heads <= 24).  Per block: w1 [512,2], b1 [512],
+ * w2 [heads,512], ls [heads] fp32 parameters; forward writes bias [heads,64,64] and scale [heads]; backward reads dbias
+ * [heads,64,64] and dscale [heads] and writes dw1, db1, dw2, dls.  coords [225,2] fp32; index [4096] int32 (= relative_position_index);
+ * inv_index [225,64] int32: the positions that read each table entry, ascending, padded with 4096 (fixed summation order: run-to-run
+ * identical bits).  table / dtable: caller-owned fp32 scratch of rgbnm_swin_cpb_table_elems(nblocks) elements; `table` carries the
+ * forward's MLP outputs to the backward. */
+typedef struct rgbnm_cpb_block {
+  const float *w1, *b1, *w2, *ls;
+  float *bias, *scale;
+  const float *dbias, *dscale;
+  float *dw1, *db1, *dw2, *dls;
+  int heads, _pad;
+} rgbnm_cpb_block;
+size_t rgbnm_swin_cpb_table_elems(int nblocks);
+int rgbnm_swin_cpb_fwd(const rgbnm_cpb_block* blocks, int nblocks, const float* coords, const int* index, float* table, void* stream);
+int rgbnm_swin_cpb_bwd(const rgbnm_cpb_block* blocks, int nblocks, const float* coords, const int* inv_index, const float* table,
+                       float* dtable, void* stream);
 /* PatchMerging's concat (swinv2.py:357-362): [B, res*res, C] -> [B, (res/2)^2, 4C] (inverse != 0: the reverse copy). */
 int rgbnm_merge_gather(int dtype, const void* in, void* out, int B, int res, int C, int inverse, void* stream);
 /* mean over tokens [B,N,C] -> [B,C] (backward != 0: [B,C] -> [B,N,C], dy / N). */

@@ -575,6 +575,7 @@ int tn_flush(hipStream_t st) {
     jobs[i].ldy = p.ldy; jobs[i].ldx = p.ldx; jobs[i].M = p.M; jobs[i].No = p.No; jobs[i].Ki = p.Ki;
     jobs[i].dW = g_tn_q[i].dW; jobs[i].db = g_tn_q[i].db; jobs[i].perm_heads = g_tn_q[i].perm_heads;
     jobs[i].accumulate = g_tn_q[i].accumulate;
+    jobs[i].smax = p.S;
   }
   int S = 0, direct = 0;
   const int rc = rgbnm_launch_tn_pipe_group(jobs, n, &S, st, rgbnm_get_option("tn_direct") ? &direct : nullptr);
@@ -621,7 +622,7 @@ int launch_tn(GemmTN p, float* dW, float* db, int perm_heads, int accumulate, hi
     if (rgbnm_get_option("tn_pipe")) {
       int Sp = 0;
       const int rc = rgbnm_launch_tn_pipe(p.dY, p.ldy, p.X, p.ldx, p.part, db ? p.bpart : nullptr, p.M, p.No, p.Ki,
-                                          &Sp, st);
+                                          &Sp, st, p.S);
       if (rc < 0) return rc;
       if (rc == 0) {
         return submit_tn_reduce(p, dW, db, Sp, perm_heads, accumulate, st);
@@ -702,6 +703,16 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
   if (bias_out && d.perm_heads > 0 && blockIdx.x < 3)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < d.N; i += 3 * 256)
       bias_out[d.bperm_off + i] = master[d.b_off + qkv_row(i, d.perm_heads)];
+  if (bias_out && d.perm_heads <= 0 && d.bias_mode && blockIdx.x < 3) {     // prepared bias operands (SwinV2: see rgbnm_linear_desc)
+    const int third = d.N / 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.N; i += 3 * 256) {
+      float v;
+      if (d.bias_mode == 1) v = master[d.b_off + i];
+      else v = i < third ? master[d.b_off + i] : (i < 2 * third ? 0.f : master[d.b2_off + i - 2 * third]);
+      bias_out[d.bperm_off + i] = v;
+      if (d.pair) bias_out[d.bperm_off + d.N + i] = v;
+    }
+  }
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
   const int tr = (d.N + 31) / 32, tc = (d.K + 31) / 32;
   const int kind = (chain_fwd || chain_bwd) ? d.chain_kind : 0;
@@ -795,15 +806,25 @@ size_t rgbnm_gemm_tn_workspace(int M, int No, int Ki) {
   // worst case split count
   return (size_t)RGBNM_TN_MAX_SPLIT * ((size_t)No * Ki + No) * sizeof(float);
 }
+size_t rgbnm_gemm_tn_workspace_splits(int No, int Ki, int splits) {
+  if (splits < 1) splits = 1;
+  if (splits > RGBNM_TN_MAX_SPLIT) splits = RGBNM_TN_MAX_SPLIT;
+  return (size_t)splits * ((size_t)No * Ki + No) * sizeof(float);
+}
 
 int rgbnm_gemm_tn(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int No,
                   int Ki, int perm_heads, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   if (!dY || !X || !dW || !workspace) return RGBNM_EINVAL;
-  if (workspace_bytes < rgbnm_gemm_tn_workspace(M, No, Ki)) return RGBNM_EWORKSPACE;
+  // the workspace holds smax split slices (part[s][No][Ki] then bpart[s][No]): the full rgbnm_gemm_tn_workspace gives 128, a caller
+  // that knows better (rgbnm_gemm_tn_workspace_splits) brings fewer and the token axis is split no further than that
+  if (No <= 0 || Ki <= 0) return RGBNM_EINVAL;
+  size_t smax = workspace_bytes / (((size_t)No * Ki + No) * sizeof(float));
+  if (smax < 1) return RGBNM_EWORKSPACE;
+  if (smax > (size_t)RGBNM_TN_MAX_SPLIT) smax = RGBNM_TN_MAX_SPLIT;
   GemmTN p;
-  p.dY = dY; p.X = X; p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki; p.S = RGBNM_TN_MAX_SPLIT;
+  p.dY = dY; p.X = X; p.ldy = ldy; p.ldx = ldx; p.M = M; p.No = No; p.Ki = Ki; p.S = (int)smax;
   p.part = reinterpret_cast<float*>(workspace);
-  p.bpart = db ? p.part + (size_t)RGBNM_TN_MAX_SPLIT * No * Ki : nullptr;
+  p.bpart = db ? p.part + smax * No * Ki : nullptr;
   p.tok_per_split = 0; p.rtiles = p.ctiles = 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) return launch_tn<bf16>(p, dW, db, perm_heads, accumulate, st);

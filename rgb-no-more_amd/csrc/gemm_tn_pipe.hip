@@ -397,6 +397,8 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   // one workgroup per CU (120 KB LDS) and at most 256 of them: a 257th would wait for a whole first round
   int S = 256 / tiles;
   if (S > RGBNM_TN_MAX_SPLIT) S = RGBNM_TN_MAX_SPLIT;
+  for (int i = 0; i < n; ++i)
+    if (jobs[i].smax > 0 && S > jobs[i].smax) S = jobs[i].smax;      // a job that brought a workspace for fewer slices
   if (S > ktiles) S = ktiles;
   const int kt_per = cdiv(ktiles, S);
   S = cdiv(ktiles, kt_per);
@@ -451,9 +453,9 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
 }
 
 int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
-                         int Ki, int* S_out, hipStream_t st) {
+                         int Ki, int* S_out, hipStream_t st, int smax) {
   RgbnmTnJob j;
   j.dY = dY; j.X = X; j.part = part; j.bpart = bpart; j.ldy = ldy; j.ldx = ldx; j.M = M; j.No = No; j.Ki = Ki;
-  j.dW = nullptr; j.db = nullptr; j.perm_heads = 0; j.accumulate = 0;
+  j.dW = nullptr; j.db = nullptr; j.perm_heads = 0; j.accumulate = 0; j.smax = smax;
   return rgbnm_launch_tn_pipe_group(&j, 1, S_out, st);
 }

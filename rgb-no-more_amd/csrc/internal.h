@@ -13,6 +13,7 @@ struct RgbnmTnJob {
   // (S == 1) and accumulate == 0 the kernel writes dW / db itself -- rows permuted as the reduction would (perm_heads) -- instead
   // of partials that a reduction launch only copies
   float* dW; float* db; int perm_heads, accumulate;
+  int smax;      // > 0: the job's workspace holds at most this many split slices (part[s], bpart[s]): the launch splits no further
 };
 // *direct_out (may be null) = 1 when the kernel wrote dW / db of every job itself: the caller submits no reductions
 int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStream_t st, int* direct_out = nullptr);
@@ -22,7 +23,7 @@ void rgbnm_tn_defer_begin();
 void rgbnm_tn_defer_begin_n(int max_jobs);     // the same with room for up to max_jobs (<= 48) jobs per launch: the GEMMs of several blocks
 int rgbnm_tn_defer_flush(hipStream_t st);
 int rgbnm_launch_tn_pipe(const void* dY, int ldy, const void* X, int ldx, float* part, float* bpart, int M, int No,
-                         int Ki, int* S_out, hipStream_t st);
+                         int Ki, int* S_out, hipStream_t st, int smax = 0);
 
 // bf16 attention with LDS-DMA tiles and transpose reads (attention_v2.hip)
 int rgbnm_launch_attn2_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, float scale,

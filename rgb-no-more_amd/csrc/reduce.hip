@@ -227,16 +227,26 @@ int rgbnm_reduce_hold_end(void* table_dev, void* table_host, size_t table_bytes,
   // zeroed record and is uploaded again, whichever host thread gets here.
   if (memcmp(table_host, &g_held, used) != 0) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-      g_held.njobs = 0;
-      return RGBNM_EINVAL;                       // a changed table cannot be uploaded from inside a graph capture: run one eager pass first
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { g_held.njobs = 0; return RGBNM_ELAUNCH; }
+    if (cap != hipStreamCaptureStatusNone) {
+      // inside a graph capture the upload becomes a node of the graph whose SOURCE is table_host itself: that needs a page-locked
+      // table_host that stays as it is while the graph lives (rgbnm.h) -- callers whose buffers differ between the eager passes
+      // and the capture (swinv2.py: fresh tensors from the graph's pool).  A pageable table_host cannot be captured: EINVAL.
+      memcpy(table_host, &g_held, used);
+      if (hipMemcpyAsync(table_dev, table_host, used, hipMemcpyHostToDevice, st) != hipSuccess) {
+        (void)hipGetLastError();
+        memset(table_host, 0, used);
+        g_held.njobs = 0;
+        return RGBNM_EINVAL;                     // run one eager pass with the same buffers first, or pin table_host
+      }
+    } else {
+      // pageable source: the runtime stages it before returning, so g_held may be reused at once; stream-ordered on st
+      if (hipMemcpyAsync(table_dev, &g_held, used, hipMemcpyHostToDevice, st) != hipSuccess) {
+        g_held.njobs = 0;
+        return RGBNM_ELAUNCH;
+      }
+      memcpy(table_host, &g_held, used);
     }
-    // pageable source: the runtime stages it before returning, so g_held may be reused at once; stream-ordered on st
-    if (hipMemcpyAsync(table_dev, &g_held, used, hipMemcpyHostToDevice, st) != hipSuccess) {
-      g_held.njobs = 0;
-      return RGBNM_ELAUNCH;
-    }
-    memcpy(table_host, &g_held, used);
   }
   g_held.njobs = 0;
   hipLaunchKernelGGL(reduce_table_kernel, dim3(total), dim3(256), 0, st, (const HeldTable*)table_dev);

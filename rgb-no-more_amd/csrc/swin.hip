@@ -13,6 +13,8 @@
 #include "../../include/rgbnm.h"
 #include "internal.h"
 
+#define TRYRC(x) do { const int rc__ = (x); if (rc__ != RGBNM_OK) return rc__; } while (0)
+
 namespace {
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
@@ -444,6 +446,120 @@ __global__ void token_mean_bwd_scalar_kernel(const T* __restrict__ dy, T* __rest
     dx[(size_t)b * N * C + i] = from_f32<T>(to_f32(dy[(size_t)b * C + i % C]) / N);
 }
 
+
+// ------------------------------------------------------------------------------------------------ continuous position bias
+// WindowAttention's parameter-only part (models/swinv2.py:158-168) for EVERY block of the model in two launches per direction:
+//   table[h][e] = cpb_mlp(relative_coords_table[e])[h]        (Linear(2, 512) -> ReLU -> Linear(512, heads, no bias); e < 225)
+//   bias[h][i][k] = 16 sigmoid(table[h][relative_position_index[i][k]])     scale[h] = exp(min(logit_scale[h], ln 100))
+// The reference runs this as ~20 tiny torch kernels forward and as many backward per block; batched per stage it still was 150
+// launches and 1.3 ms of a SwinV2-T step.  Sums run in a fixed order (no atomics): run-to-run identical bits.
+constexpr int CPB_E = 225, CPB_HID = 512, CPB_POS = 4096, CPB_MAXH = 24, CPB_MAXB = 16, CPB_EPS = 8, CPB_SPLIT = (CPB_E + CPB_EPS - 1) / CPB_EPS;
+struct CpbArgs { rgbnm_cpb_block blk[CPB_MAXB]; const float* coords; const int* index; const int* inv; float* table; float* dtable; };
+
+// grid (nblocks, CPB_SPLIT): CPB_EPS table entries per workgroup (29 x 12 workgroups for SwinV2-T); their hidden activations in LDS
+__global__ __launch_bounds__(256) void cpb_table_kernel(CpbArgs a) {
+  __shared__ float hid[CPB_EPS][CPB_HID];
+  const rgbnm_cpb_block& b = a.blk[blockIdx.x];
+  const int e0 = blockIdx.y * CPB_EPS, ne = min(CPB_EPS, CPB_E - e0), tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (ne <= 0) return;
+  for (int i = tid; i < ne * CPB_HID; i += 256) {
+    const int e = i / CPB_HID, j = i % CPB_HID;
+    const float v = fmaf(b.w1[2 * j + 1], a.coords[2 * (e0 + e) + 1], fmaf(b.w1[2 * j], a.coords[2 * (e0 + e)], b.b1[j]));
+    hid[e][j] = v > 0.f ? v : 0.f;
+  }
+  __syncthreads();
+  float* t = a.table + (size_t)blockIdx.x * CPB_MAXH * CPB_E;
+  for (int pr = w; pr < b.heads * ne; pr += 4) {           // one (head, entry) dot product of length 512 per wave and turn
+    const int h = pr / ne, e = pr % ne;
+    const float* w2 = b.w2 + (size_t)h * CPB_HID;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPB_HID / 64; ++k) acc = fmaf(w2[lane + 64 * k], hid[e][lane + 64 * k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) t[h * CPB_E + e0 + e] = acc;
+  }
+}
+
+// grid (nblocks, CPB_MAXH): bias of one head (4096 positions) + the head's logit scale
+__global__ __launch_bounds__(256) void cpb_bias_kernel(CpbArgs a) {
+  const rgbnm_cpb_block& b = a.blk[blockIdx.x];
+  const int h = blockIdx.y;
+  if (h >= b.heads) return;
+  const float* t = a.table + ((size_t)blockIdx.x * CPB_MAXH + h) * CPB_E;
+  for (int p = threadIdx.x; p < CPB_POS; p += 256)
+    b.bias[(size_t)h * CPB_POS + p] = 16.f / (1.f + expf(-t[a.index[p]]));
+  if (threadIdx.x == 0) b.scale[h] = expf(fminf(b.ls[h], 4.605170185988092f));       // ln(1 / 0.01)
+}
+
+// grid (nblocks, CPB_MAXH): d table[h][e] = 16 s (1 - s) * sum of d bias over the <= 64 positions that read entry e (inv: [225][64],
+// padded with 4096), ascending position order; d logit_scale
+__global__ __launch_bounds__(256) void cpb_dtable_kernel(CpbArgs a) {
+  const rgbnm_cpb_block& b = a.blk[blockIdx.x];
+  const int h = blockIdx.y, e = threadIdx.x;
+  if (h >= b.heads) return;
+  if (e < CPB_E) {
+    const float* db = b.dbias + (size_t)h * CPB_POS;
+    int pos[64];
+    float val[64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                       // the entry's position list first, then 64 INDEPENDENT gathers, then the sum in order
+      const int4 v = *reinterpret_cast<const int4*>(a.inv + e * 64 + 4 * q);
+      pos[4 * q] = v.x; pos[4 * q + 1] = v.y; pos[4 * q + 2] = v.z; pos[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) val[q] = pos[q] < CPB_POS ? db[pos[q]] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) acc += val[q];
+    const float s = 1.f / (1.f + expf(-a.table[((size_t)blockIdx.x * CPB_MAXH + h) * CPB_E + e]));
+    a.dtable[((size_t)blockIdx.x * CPB_MAXH + h) * CPB_E + e] = acc * 16.f * s * (1.f - s);
+  }
+  if (e == 255) b.dls[h] = b.ls[h] <= 4.605170185988092f ? b.dscale[h] * expf(b.ls[h]) : 0.f;    // clamp passes its gradient inside the range
+}
+
+// grid (nblocks, 16): 32 hidden units per workgroup, EIGHT lanes per unit, each walking an eighth of the 225 entries; the eight partial
+// sums are combined by xor-shuffles (fixed tree): d W2[h][j], d W1[j][0..1], d b1[j]
+__global__ __launch_bounds__(256) void cpb_mlp_bwd_kernel(CpbArgs a) {
+  __shared__ float dts[CPB_MAXH][CPB_E + 3];
+  __shared__ float cs[CPB_E][2];
+  const rgbnm_cpb_block& b = a.blk[blockIdx.x];
+  const int H = b.heads, j = blockIdx.y * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+  for (int i = threadIdx.x; i < H * CPB_E; i += 256) dts[i / CPB_E][i % CPB_E] = a.dtable[(size_t)blockIdx.x * CPB_MAXH * CPB_E + i];
+  for (int i = threadIdx.x; i < CPB_E * 2; i += 256) cs[i >> 1][i & 1] = a.coords[i];
+  __syncthreads();
+  const float wa = b.w1[2 * j], wb = b.w1[2 * j + 1], bj = b.b1[j];
+  float w2[CPB_MAXH], dw2[CPB_MAXH];
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h) { w2[h] = h < H ? b.w2[(size_t)h * CPB_HID + j] : 0.f; dw2[h] = 0.f; }
+  float da = 0.f, dbb = 0.f, dbias = 0.f;
+  constexpr int PER = (CPB_E + 7) / 8;                  // 29
+  const int e1 = min(CPB_E, (part + 1) * PER);
+  for (int e = part * PER; e < e1; ++e) {
+    const float v = fmaf(wb, cs[e][1], fmaf(wa, cs[e][0], bj));
+    const float hv = v > 0.f ? v : 0.f;
+    float dh = 0.f;
+#pragma unroll
+    for (int h = 0; h < CPB_MAXH; ++h) {
+      const float d = h < H ? dts[h][e] : 0.f;
+      dw2[h] = fmaf(d, hv, dw2[h]);
+      dh = fmaf(d, w2[h], dh);
+    }
+    if (v > 0.f) { da = fmaf(dh, cs[e][0], da); dbb = fmaf(dh, cs[e][1], dbb); dbias += dh; }
+  }
+  auto red8 = [](float x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); return x; };
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h) {
+    const float r = red8(dw2[h]);
+    if (h < H && part == 0) b.dw2[(size_t)h * CPB_HID + j] = r;
+  }
+  da = red8(da); dbb = red8(dbb); dbias = red8(dbias);
+  if (part == 0) {
+    b.dw1[2 * j] = da;
+    b.dw1[2 * j + 1] = dbb;
+    b.db1[j] = dbias;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -559,6 +675,55 @@ int rgbnm_token_mean(int dtype, const void* in, void* out, int B, int N, int C, 
   else return RGBNM_EINVAL;
 #undef TM
   LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+
+size_t rgbnm_swin_cpb_table_elems(int nblocks) { return (size_t)(nblocks > 0 ? nblocks : 0) * CPB_MAXH * CPB_E; }
+
+static int cpb_fill(CpbArgs& a, const rgbnm_cpb_block* blocks, int n, const float* coords, const int* index, const int* inv,
+                    float* table, float* dtable, bool bwd) {
+  for (int i = 0; i < n; ++i) {
+    const rgbnm_cpb_block& b = blocks[i];
+    if (b.heads < 1 || b.heads > CPB_MAXH || !b.w1 || !b.b1 || !b.w2 || !b.ls) return RGBNM_EINVAL;
+    if (!bwd && (!b.bias || !b.scale)) return RGBNM_EINVAL;
+    if (bwd && (!b.dbias || !b.dscale || !b.dw1 || !b.db1 || !b.dw2 || !b.dls)) return RGBNM_EINVAL;
+    a.blk[i] = b;
+  }
+  for (int i = n; i < CPB_MAXB; ++i) a.blk[i] = blocks[0];
+  a.coords = coords; a.index = index; a.inv = inv; a.table = table; a.dtable = dtable;
+  return RGBNM_OK;
+}
+
+int rgbnm_swin_cpb_fwd(const rgbnm_cpb_block* blocks, int nblocks, const float* coords, const int* index, float* table, void* stream) {
+  if (!blocks || nblocks < 1 || !coords || !index || !table) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int b0 = 0; b0 < nblocks; b0 += CPB_MAXB) {
+    const int n = nblocks - b0 < CPB_MAXB ? nblocks - b0 : CPB_MAXB;
+    CpbArgs a;
+    TRYRC(cpb_fill(a, blocks + b0, n, coords, index, nullptr, table + (size_t)b0 * CPB_MAXH * CPB_E, nullptr, false));
+    hipLaunchKernelGGL(cpb_table_kernel, dim3(n, CPB_SPLIT), dim3(256), 0, st, a);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(cpb_bias_kernel, dim3(n, CPB_MAXH), dim3(256), 0, st, a);
+    LAUNCH_CHECK();
+  }
+  return RGBNM_OK;
+}
+
+int rgbnm_swin_cpb_bwd(const rgbnm_cpb_block* blocks, int nblocks, const float* coords, const int* inv_index, const float* table,
+                       float* dtable, void* stream) {
+  if (!blocks || nblocks < 1 || !coords || !inv_index || !table || !dtable) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int b0 = 0; b0 < nblocks; b0 += CPB_MAXB) {
+    const int n = nblocks - b0 < CPB_MAXB ? nblocks - b0 : CPB_MAXB;
+    CpbArgs a;
+    TRYRC(cpb_fill(a, blocks + b0, n, coords, nullptr, inv_index, const_cast<float*>(table) + (size_t)b0 * CPB_MAXH * CPB_E,
+                   dtable + (size_t)b0 * CPB_MAXH * CPB_E, true));
+    hipLaunchKernelGGL(cpb_dtable_kernel, dim3(n, CPB_MAXH), dim3(256), 0, st, a);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3(n, CPB_HID / 32), dim3(256), 0, st, a);
+    LAUNCH_CHECK();
+  }
   return RGBNM_OK;
 }
 

@@ -830,7 +830,7 @@ template <typename T> HeadGrid bwd_grid(long long nwin, int heads) {
 
 template <typename T>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* bias, const float* scale, const float* lse,
-               void* dqkv, float* dbias, float* dscale_part, float* dpart, int B, int res, int C, int heads, int shift,
+               void* dqkv, float* dbias, float* dscale_part, float* dscale, float* dpart, int B, int res, int C, int heads, int shift,
                hipStream_t st) {
   if (set_attrs<T>() != RGBNM_OK) return RGBNM_ELAUNCH;
   const long long nwin = (long long)B * (res / WS) * (res / WS);
@@ -842,6 +842,10 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   RgbnmReduceJob j;
   j.part = dpart; j.stride = (long long)heads * WT * WT; j.out = dbias; j.n = heads * WT * WT; j.S = g.slots * WA<T>::BWD_WAVES;
   j.cols = 1; j.perm_heads = 0; j.accumulate = 0; j.epw = 8;
+  const int rc = rgbnm_reduce_submit(j, st);
+  if (rc != RGBNM_OK || !dscale) return rc;
+  // d(scale)[h] = sum over the (window, head) partials: another job of the same batched, fixed-order reduction
+  j.part = dscale_part; j.stride = heads; j.out = dscale; j.n = heads; j.S = (int)((long long)B * (res / WS) * (res / WS));
   return rgbnm_reduce_submit(j, st);
 }
 
@@ -869,19 +873,19 @@ size_t rgbnm_window_attention_bwd_workspace(int B, int res, int heads) {
 }
 
 int rgbnm_window_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* bias,
-                               const float* bias_t, const float* scale, const float* lse, void* dqkv, float* dbias,
+                               float* dscale, const float* scale, const float* lse, void* dqkv, float* dbias,
                                float* dscale_part, int B, int res, int C, int heads, int shift, void* workspace,
                                size_t workspace_bytes, void* stream) {
-  if (!qkv || !out || !dout || !bias || !bias_t || !scale || !lse || !dqkv || !dbias || !dscale_part || !workspace ||
+  if (!qkv || !out || !dout || !bias || !scale || !lse || !dqkv || !dbias || !dscale_part || !workspace ||
       B <= 0 || res % WS || C != heads * HD || shift < 0 || shift >= WS)
     return RGBNM_EINVAL;
   if (workspace_bytes < rgbnm_window_attention_bwd_workspace(B, res, heads)) return RGBNM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* dpart = (float*)workspace;
   if (dtype == DT_BF16)
-    return launch_bwd<bf16>(qkv, out, dout, bias, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads, shift, st);
+    return launch_bwd<bf16>(qkv, out, dout, bias, scale, lse, dqkv, dbias, dscale_part, dscale, dpart, B, res, C, heads, shift, st);
   if (dtype == DT_F32)
-    return launch_bwd<float>(qkv, out, dout, bias, scale, lse, dqkv, dbias, dscale_part, dpart, B, res, C, heads, shift, st);
+    return launch_bwd<float>(qkv, out, dout, bias, scale, lse, dqkv, dbias, dscale_part, dscale, dpart, B, res, C, heads, shift, st);
   return RGBNM_EINVAL;
 }
 

@@ -20,7 +20,7 @@ HOST_WAIT = {"sec": 0.0}
 class LinearDesc(C.Structure):
     _fields_ = [("w_off", _ll), ("b_off", _ll), ("ws_off", _ll), ("wst_off", _ll), ("bperm_off", _ll),
                 ("N", _i), ("K", _i), ("perm_heads", _i), ("add_identity", _i), ("ldn", _i), ("pair", _i),
-                ("chain_kind", _i), ("chain_off", _ll)]
+                ("chain_kind", _i), ("chain_off", _ll), ("bias_mode", _i), ("_pad2", _i), ("b2_off", _ll)]
 
 
 class VitCfg(C.Structure):
@@ -60,6 +60,11 @@ class HeadGrads(C.Structure):
     _fields_ = [(n, _vp) for n in ("dln_g", "dln_b", "dw1", "db1", "dw2", "db2")]
 
 
+class CpbBlock(C.Structure):
+    _fields_ = [(n, _vp) for n in ("w1", "b1", "w2", "ls", "bias", "scale", "dbias", "dscale", "dw1", "db1", "dw2", "dls")] + \
+               [("heads", _i), ("_pad", _i)]
+
+
 class ChainBlock(C.Structure):
     _fields_ = [(n, _vp) for n in ("wimg", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "bqkv_perm", "bproj", "b1", "b2", "xn1", "mean1",
                                    "rstd1", "qkv", "lse", "attn", "x_mid", "xn2", "mean2", "rstd2", "u", "gl", "x_out")]
@@ -88,6 +93,7 @@ PROTOTYPES = {
     "rgbnm_trace_reserve": (_i, [_i]),
     "rgbnm_gemm_nt": (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbnm_gemm_tn_workspace": (_sz, [_i, _i, _i]),
+    "rgbnm_gemm_tn_workspace_splits": (_sz, [_i, _i, _i]),
     "rgbnm_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "rgbnm_prep_weights": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
     "rgbnm_prep_weights_chain": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -133,6 +139,9 @@ PROTOTYPES = {
     "rgbnm_window_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rgbnm_window_attention_bwd_workspace": (_sz, [_i, _i, _i]),
     "rgbnm_window_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "rgbnm_swin_cpb_table_elems": (_sz, [_i]),
+    "rgbnm_swin_cpb_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "rgbnm_swin_cpb_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rgbnm_merge_gather": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbnm_token_mean": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rgbnm_calib_mfma_bf16": (_i, [_i, _i, _vp, _vp]),

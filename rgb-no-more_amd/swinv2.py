@@ -28,8 +28,91 @@ WS = 8
 
 
 # ------------------------------------------------------------------ autograd nodes over the C ABI
+class _HoldBracket:
+    """The split-sum reductions of a WHOLE backward pass as one launch (rgbnm.h rgbnm_reduce_hold_*; ViT.defer_grad_reduction's
+    counterpart for SwinTransformerV2.group_dw_backward): opened by the head's backward node, closed by the patch embedding's.  While
+    it is open every reduction of the pass (weight-gradient partials, LayerNorm parameter sums, window attention's d(bias) /
+    d(scale)) is only recorded; each call therefore gets scratch of its own (_ws hands out fresh tensors, kept alive here), and
+    whoever must READ a reduced value before the end -- the position-bias backward -- flushes first.  post: work that needs reduced
+    values and can wait for the end (the row-paired layers' fold of their 2N x 2K product)."""
+
+    def __init__(self):
+        self.active, self.keep, self.post = False, [], []
+        self.table = self.table_host = self.ftable = self.ftable_host = None
+        self._tabs = {}
+
+    def begin(self, dev):
+        # one (device table, page-locked host record) pair per device AND per launch mode: a HIP-graph capture carries the upload of
+        # its table as a copy node that reads the host record at every replay, so eager passes in between (other buffers, another
+        # table) must not write that record
+        if torch.cuda.is_current_stream_capturing():         # every capture its own pair, alive as long as this model
+            spare = self._tabs.get(("spare", dev)) or []
+            if not spare:
+                return False                                 # (page-locked memory cannot be allocated inside a capture: reserve() first)
+            pair = spare.pop()
+            self._tabs.setdefault("captured", []).append(pair)
+        else:
+            self.reserve(dev)
+            pair = self._tabs[dev]
+        (self.ftable, self.ftable_host), (self.table, self.table_host) = pair
+        if L.lib().rgbnm_reduce_hold_begin() != 0:      # left open by a pass that died on this thread
+            L.lib().rgbnm_reduce_hold_cancel()
+            L.check(L.lib().rgbnm_reduce_hold_begin(), "reduce_hold_begin")
+        self.active, self.keep, self.post = True, [], []
+        return True
+
+    def reserve(self, dev):
+        """Tables for this device's eager passes and two spare pairs for captures (called from eager code: forward())."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        n = L.lib().rgbnm_reduce_hold_table_bytes()
+        # a set = TWO (device table, host record) pairs: one for the mid-pass flush, one for the end -- inside a capture both uploads are
+        # copy nodes that read their host record at every replay, so the two must not share one
+        one = lambda: (torch.zeros(n, device=dev, dtype=torch.uint8), torch.zeros(n, dtype=torch.uint8).pin_memory())  # noqa: E731
+        mk = lambda: (one(), one())  # noqa: E731
+        if dev not in self._tabs:
+            self._tabs[dev] = mk()
+        spare = self._tabs.setdefault(("spare", dev), [])
+        while len(spare) < 2:
+            spare.append(mk())
+
+    def flush(self):
+        """Run what has been recorded so far and keep recording (somebody needs reduced values now)."""
+        if self.active:
+            L.check(L.lib().rgbnm_reduce_hold_end(self.ftable.data_ptr(), self.ftable_host.data_ptr(), self.ftable.numel(), L.stream()),
+                    "reduce_hold_end")
+            post, self.post = self.post, []
+            for f in post:
+                f()
+            L.check(L.lib().rgbnm_reduce_hold_begin(), "reduce_hold_begin")
+
+    def end(self):
+        if self.active:
+            self.active = False
+            rc = L.lib().rgbnm_reduce_hold_end(self.table.data_ptr(), self.table_host.data_ptr(), self.table.numel(), L.stream())
+            post, self.post, self.keep = self.post, [], []
+            L.check(rc, "reduce_hold_end")
+            for f in post:
+                f()
+
+    def cancel(self):
+        if self.active:
+            self.active = False
+            L.lib().rgbnm_reduce_hold_cancel()
+            self.keep, self.post = [], []
+
+
+_HOLD = [None]          # the open _HoldBracket of the backward pass that is running (one autograd thread runs its nodes in turn)
+
+
 def _ws(dev, nbytes, slot=0):
-    """Scratch per (device, slot): calls whose partial sums must coexist (grouped dW GEMMs) take different slots."""
+    """Scratch per (device, slot): calls whose partial sums must coexist (grouped dW GEMMs) take different slots.  Inside a held
+    backward (_HoldBracket) every call gets a region of its own: its partial sums live until the bracket's one reduction launch."""
+    hb = _HOLD[0]
+    if hb is not None and hb.active:
+        t = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        hb.keep.append(t)
+        return t
     t = _ws.cache.get((dev, slot))
     if t is None or t.numel() < nbytes:
         t = torch.empty(nbytes, device=dev, dtype=torch.uint8)
@@ -81,12 +164,20 @@ class _DwBracket:
             L.lib().rgbnm_gemm_tn_group_begin_id(48, self.id)
             self.active, self.keep = True, []
 
-    def end(self):
+    def end(self, hold=None):
+        """hold: the pass's open _HoldBracket -- the queued jobs' reductions are recorded there and READ the jobs' partial sums when it
+        closes, so it closes before their workspaces are let go."""
         if self.active:
             self.active = False
             rc = L.lib().rgbnm_gemm_tn_group_end(L.stream())
-            self.keep = []
+            try:
+                if hold is not None:
+                    hold.end()
+            finally:
+                self.keep = []
             L.check(rc, "gemm_tn_group_end")
+        elif hold is not None:
+            hold.end()
 
     def abandon(self):
         """Called where a bracket is found still open AFTER its backward pass is over (a node other than a Linear raised, or a
@@ -114,10 +205,21 @@ def _gemm_tn(dY, X, want_bias, slot=0, keep=None):
     Ki = X.shape[1]
     dW = torch.empty(No, Ki, device=dY.device, dtype=torch.float32)
     db = torch.empty(No, device=dY.device, dtype=torch.float32) if want_bias else None
-    wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
     if keep is None:
+        hb = _HOLD[0]
+        if hb is not None and hb.active and Ki % 192 == 0:
+            # held: scratch of its own; a single launch splits the tokens at most 256 / its own 128 x 192 tiles ways
+            wsb = L.lib().rgbnm_gemm_tn_workspace_splits(No, Ki, max(1, 256 // (((No + 127) // 128) * (Ki // 192))))
+        else:
+            wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
         ws = _ws(dY.device, wsb, slot)
-    else:                               # queued: the call's own workspace and its operands live until the bracket closes
+    else:                               # queued: the call's own workspace and its operands live until the bracket closes; a grouped
+        # launch splits the token axis 256 / (tiles of the group) ways, i.e. no further than 256 / this job's own tiles: room for
+        # that many slices is all the job can use (the worst-case size pinned ~13 GB of scratch per backward)
+        if Ki % 192 == 0:
+            wsb = L.lib().rgbnm_gemm_tn_workspace_splits(No, Ki, max(1, 256 // (((No + 127) // 128) * (Ki // 192))))
+        else:
+            wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
         ws = torch.empty(wsb, device=dY.device, dtype=torch.uint8)
         keep.append((dY, X, ws))
     L.check(L.lib().rgbnm_gemm_tn(L.dt_of(dY.dtype), dY.data_ptr(), No, X.data_ptr(), Ki, dW.data_ptr(), L.ptr(db), M, No,
@@ -132,14 +234,19 @@ def _paired(sh, W):
     return sh[0].shape[0] == 2 * W.shape[0]
 
 
-def _nt(epi, x, Wsh, pair, bias=None, R=None, want_c2=False):
+def _nt(epi, x, Wsh, pair, bias=None, R=None, want_c2=False, bias_prep=None):
+    """bias_prep: the layer's bias operand as rgbnm_prep_weights laid it out this step (fp32, [N]; [2N] for a row-paired layer)."""
+    if bias is not None and bias_prep is not None:
+        bias = bias_prep
     if not pair:
         return _gemm_nt(epi, x, Wsh, bias, R, want_c2)
     M = x.shape[0]
     if M % 2:
         raise ValueError("row pairing needs an even number of rows")
     N2 = Wsh.shape[0]
-    y, c2 = _gemm_nt(epi, x.view(M // 2, -1), Wsh, None if bias is None else torch.cat((bias, bias)),
+    if bias is not None and bias.numel() != N2:
+        bias = torch.cat((bias, bias))
+    y, c2 = _gemm_nt(epi, x.view(M // 2, -1), Wsh, bias,
                      None if R is None else R.view(M // 2, N2), want_c2)
     return y.view(M, N2 // 2), None if c2 is None else c2.view(M, N2 // 2)
 
@@ -155,10 +262,29 @@ def _tn_issue(dy, x, want_bias, pair, slot=0):
     return _gemm_tn(dy.view(M // 2, 2 * N), x.view(M // 2, 2 * K), want_bias, slot) + (N, K)   # [[e.e, e.o], [o.e, o.o]] row parities
 
 
+def _alias(t):
+    """A second tensor over t's memory that is NOT a view of t (no reference to t's TensorImpl)."""
+    return torch.empty(0, device=t.device, dtype=t.dtype).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+
+
 def _tn_finish(t):
     dW2, db2, N, K = t
     if N == 0:
         return dW2, db2
+    hb = _HOLD[0]
+    if hb is not None and hb.active:
+        # the product's reduction is held: the fold of its diagonal blocks waits for the bracket's end; the gradients handed to
+        # autograd now are filled then (nobody reads a gradient before backward() returns: the bracket's contract)
+        dW = torch.empty(N, K, device=dW2.device, dtype=dW2.dtype)
+        db = None if db2 is None else torch.empty(N, device=dW2.device, dtype=dW2.dtype)
+        # (the deferred fold writes through ALIASES of the storages: a reference to dW / db themselves would keep AccumulateGrad from
+        # adopting them -- it would copy their still unwritten contents into .grad instead)
+        dWa = _alias(dW)
+        hb.post.append(lambda: torch.add(dW2[:N, :K], dW2[N:, K:], out=dWa))
+        if db is not None:
+            dba = _alias(db)
+            hb.post.append(lambda: torch.add(db2[:N], db2[N:], out=dba))
+        return dW, db
     return dW2[:N, :K] + dW2[N:, K:], None if db2 is None else db2[:N] + db2[N:]
 
 
@@ -177,6 +303,21 @@ def _fbias(b):
     return None if b is None else b.detach().float().contiguous()
 
 
+class _QkvBiasFn(torch.autograd.Function):
+    """The qkv Linear's bias vector q_bias | 0 | v_bias (swinv2.py:150-152) WITHOUT building it: rgbnm_prep_weights has written it
+    this step (rgbnm_linear_desc.bias_mode 2); this node only routes the gradient of the vector back to its two parameters."""
+
+    @staticmethod
+    def forward(ctx, q_bias, v_bias, prepared):
+        ctx.c = q_bias.numel()
+        return prepared[:3 * ctx.c].detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        c = ctx.c
+        return g[:c], g[2 * c:3 * c], None
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b  (x [M,K] in the compute dtype, W fp32 master [N,K], b fp32 or None).  sh = (W, W^T) in the
     compute dtype from the per-step shadow buffer (rgbnm_prep_weights): no per-layer cast / transpose kernels."""
@@ -187,7 +328,7 @@ class _LinearFn(torch.autograd.Function):
         dX GEMM's residual epilogue instead of costing autograd an [M,C] add kernel at the fork (24 per SwinV2-T step).
         role: ("open", bracket) for the classification head, ("close", bracket) for the patch embedding (_DwBracket)."""
         pair = _paired(sh, W)
-        y, _ = _nt(L.EPI_NONE, x, sh[0], pair, _fbias(b))
+        y, _ = _nt(L.EPI_NONE, x, sh[0], pair, _fbias(b), bias_prep=sh[2] if len(sh) > 2 else None)
         ctx.save_for_backward(x)
         ctx.sh, ctx.has_b, ctx.pair, ctx.role = sh, b is not None, pair, role
         return (y, x) if fork else y
@@ -202,16 +343,22 @@ class _LinearFn(torch.autograd.Function):
             # returns, i.e. before a queued GEMM has run: such a pass runs the old way)
             role[1].begin()
             _ACTIVE[0] = role[1]
+            if len(role) > 3 and role[3] is not None and role[3].begin(dy.device):   # ... and the pass's reductions as one launch
+                _HOLD[0] = role[3]
         try:
             dW, db = _tn(dy, x, ctx.has_b, ctx.pair)
         except BaseException:
+            hb, _HOLD[0] = _HOLD[0], None
             if _ACTIVE[0] is not None:
                 br, _ACTIVE[0] = _ACTIVE[0], None
-                br.end()
+                br.end(hb)
+            elif hb is not None:
+                hb.end()
             raise
         if role is not None and role[0] == "close" and _ACTIVE[0] is role[1]:    # the last node: what is still queued runs now
             _ACTIVE[0] = None
-            role[1].end()
+            hb, _HOLD[0] = _HOLD[0], None
+            role[1].end(hb)
         if dxs is None:
             dx, _ = _nt(L.EPI_NONE, dy, ctx.sh[1], ctx.pair)
         else:
@@ -226,8 +373,8 @@ class _MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, sh1, sh2, fork=False):
         p1, p2 = _paired(sh1, W1), _paired(sh2, W2)
-        g, gp = _nt(L.EPI_GELU, x, sh1[0], p1, _fbias(b1), want_c2=True)
-        y, _ = _nt(L.EPI_NONE, g, sh2[0], p2, _fbias(b2))
+        g, gp = _nt(L.EPI_GELU, x, sh1[0], p1, _fbias(b1), want_c2=True, bias_prep=sh1[2] if len(sh1) > 2 else None)
+        y, _ = _nt(L.EPI_NONE, g, sh2[0], p2, _fbias(b2), bias_prep=sh2[2] if len(sh2) > 2 else None)
         ctx.save_for_backward(x, g, gp)
         ctx.sh1, ctx.sh2, ctx.p1, ctx.p2 = sh1, sh2, p1, p2
         return (y, x) if fork else y                   # fork: see _LinearFn
@@ -324,13 +471,16 @@ class _WinAttnFn(torch.autograd.Function):
         ws = _ws(qkv.device, wsb)
         nw = (res // WS) ** 2
         dsp = torch.empty(B * nw * heads, device=qkv.device, dtype=torch.float32)
-        # (the bias_t argument is a leftover of the first-generation kernel: the kernel reads columns of its LDS copy of bias)
+        dscale = torch.empty(heads, device=qkv.device, dtype=torch.float32)
+        hb = _HOLD[0]
+        if hb is not None and hb.active:
+            hb.keep.append(dsp)         # partial sums of a held reduction: alive until the bracket's launch
         L.check(L.lib().rgbnm_window_attention_bwd(L.dt_of(qkv.dtype), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(),
-                                                   bias_c.data_ptr(), bias_c.data_ptr(), scale_c.data_ptr(),
+                                                   bias_c.data_ptr(), dscale.data_ptr(), scale_c.data_ptr(),
                                                    lse.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), dsp.data_ptr(), B,
                                                    res, C_, heads, shift, ws.data_ptr(), ws.numel(), L.stream()),
                 "window_attention_bwd")
-        return dqkv, dbias, dsp.view(-1, heads).sum(0), None, None, None, None, None
+        return dqkv, dbias, dscale, None, None, None, None, None
 
 
 class _MergeFn(torch.autograd.Function):
@@ -401,66 +551,93 @@ class WindowAttention(nn.Module):
         self.v_bias = nn.Parameter(torch.zeros(dim, **kw))
         self.proj = nn.Linear(dim, dim, **kw)
 
-    def bias_and_scale(self):
-        """[heads,64,64] position bias and [heads] logit scale (swinv2.py:158-168): parameter-only, fp32 torch ops."""
-        n = self.window_size[0] * self.window_size[1]
-        tab = self.cpb_mlp(self.relative_coords_table).view(-1, self.num_heads)
-        bias = tab[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1).contiguous()
-        scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().view(-1)
-        return 16 * torch.sigmoid(bias), scale
-
-
-class _TableGatherFn(torch.autograd.Function):
-    """out[..., i] = tab[..., idx[i]] with a backward that is neither an atomicAdd scatter (index_select: bits change run to run) nor
-    the sort-based index_put (advanced indexing: deterministic but 27 us per call): every table entry sums the <= 64 positions that
-    read it, listed once in a padded [entries, 64] matrix `inv` (inverse_index) -- a gather and a row sum, fixed order."""
-
-    @staticmethod
-    def forward(ctx, tab, idx, inv):
-        ctx.inv = inv
-        return tab[..., idx]
-
-    @staticmethod
-    def backward(ctx, g):
-        gp = torch.cat((g, g.new_zeros(g.shape[:-1] + (1,))), -1)        # column idx.numel(): the padding of `inv` reads zeros
-        return gp[..., ctx.inv].sum(-1), None, None
-
 
 def inverse_index(idx, n_entries):
-    """[n_entries, max count] positions i with idx[i] == entry (ascending), padded with idx.numel()."""
+    """[n_entries, 64] int32: the positions i with idx[i] == entry (ascending), padded with idx.numel() -- what the backward of the
+    position-bias gather sums over, in a fixed order (neither an atomicAdd scatter nor a sort-based index_put)."""
     i = idx.detach().cpu().view(-1)
     cnt = torch.bincount(i, minlength=n_entries)
-    inv = torch.full((n_entries, int(cnt.max())), i.numel(), dtype=torch.long)
+    assert int(cnt.max()) <= 64
+    inv = torch.full((n_entries, 64), i.numel(), dtype=torch.int32)
     order = torch.argsort(i, stable=True)
     pos = 0
     for e in range(n_entries):
         c = int(cnt[e])
-        inv[e, :c] = order[pos:pos + c]
+        inv[e, :c] = order[pos:pos + c].to(torch.int32)
         pos += c
     return inv.to(idx.device)
 
 
-def stage_bias_and_scale(blocks):
-    """WindowAttention.bias_and_scale of every block of one stage (same head count) as batched ops: the continuous-position-
-    bias MLP is parameter-only work of ~20 tiny kernels forward and as many backward PER BLOCK -- 2 ms of launches per SwinV2-T
-    step when run block by block.  Same math (swinv2.py:158-168), fp32."""
-    a0, nb = blocks[0].attn, len(blocks)
-    W1 = torch.stack([b.attn.cpb_mlp[0].weight for b in blocks])                 # [nb,512,2]
-    b1 = torch.stack([b.attn.cpb_mlp[0].bias for b in blocks])                   # [nb,512]
-    W2 = torch.stack([b.attn.cpb_mlp[2].weight for b in blocks])                 # [nb,H,512]
-    ls = torch.stack([b.attn.logit_scale.view(-1) for b in blocks])              # [nb,H]
-    tab = a0.relative_coords_table.view(1, -1, 2).expand(nb, -1, -1)             # [nb,225,2]
-    h = torch.relu(torch.baddbmm(b1.unsqueeze(1), tab, W1.transpose(1, 2)))      # [nb,225,512]
-    t = torch.bmm(W2, h.transpose(1, 2))                                         # [nb,H,225]
-    n = a0.window_size[0] * a0.window_size[1]
-    # (run-to-run identical bits: tests/test_swin.py::test_swin_step_is_bit_reproducible)
-    idx = a0.relative_position_index.view(-1)
-    inv = a0.__dict__.get("_inv_index")
-    if inv is None or inv.device != idx.device:
-        inv = a0.__dict__["_inv_index"] = inverse_index(idx, t.shape[-1])      # plain attribute: not a buffer, not in the state_dict
-    bias = 16 * torch.sigmoid(_TableGatherFn.apply(t, idx, inv)).view(nb, a0.num_heads, n, n)
-    scale = torch.clamp(ls, max=math.log(1.0 / 0.01)).exp()
-    return bias.unbind(0), scale.unbind(0)
+class _CpbFn(torch.autograd.Function):
+    """Position bias [heads,64,64] and logit scale [heads] of EVERY WindowAttention of the model (swinv2.py:158-168) as two launches
+    forward and two backward (rgbnm.h rgbnm_swin_cpb_fwd / _bwd) -- the parameter-only work the reference runs as ~20 tiny kernels
+    per block and direction.  Inputs: cpb_mlp[0].weight, cpb_mlp[0].bias, cpb_mlp[2].weight, logit_scale of each block, in block
+    order; outputs: (bias_0, scale_0, bias_1, scale_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, consts, *params):
+        coords, index, inv, heads = consts
+        nb = len(heads)
+        dev = coords.device
+        ps = [p.detach().float().contiguous() for p in params]
+        outs = []
+        blocks = (L.CpbBlock * nb)()
+        for i, h in enumerate(heads):
+            bias = torch.empty(h, 64, 64, device=dev, dtype=torch.float32)
+            scale = torch.empty(h, device=dev, dtype=torch.float32)
+            w1, b1, w2, ls = ps[4 * i:4 * i + 4]
+            blocks[i] = L.CpbBlock(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), ls.data_ptr(), bias.data_ptr(), scale.data_ptr(),
+                                   None, None, None, None, None, None, h, 0)
+            outs += [bias, scale]
+        table = torch.empty(L.lib().rgbnm_swin_cpb_table_elems(nb), device=dev, dtype=torch.float32)
+        L.check(L.lib().rgbnm_swin_cpb_fwd(blocks, nb, coords.data_ptr(), index.data_ptr(), table.data_ptr(), L.stream()), "swin_cpb_fwd")
+        ctx.save_for_backward(table, *ps)
+        ctx.consts = consts
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        coords, index, inv, heads = ctx.consts
+        table, *ps = ctx.saved_tensors
+        hb = _HOLD[0]
+        if hb is not None and hb.active:
+            hb.flush()              # d(bias) / d(scale) of the blocks are held reductions: this node reads them now
+        nb = len(heads)
+        dev = coords.device
+        blocks = (L.CpbBlock * nb)()
+        out, keep = [None], []
+        for i, h in enumerate(heads):
+            w1, b1, w2, ls = ps[4 * i:4 * i + 4]
+            dbias, dscale = grads[2 * i].contiguous().float(), grads[2 * i + 1].contiguous().float()
+            dw1, db1, dw2, dls = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(ls)
+            keep += [dbias, dscale]
+            blocks[i] = L.CpbBlock(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), ls.data_ptr(), None, None, dbias.data_ptr(),
+                                   dscale.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), dls.data_ptr(), h, 0)
+            out += [dw1, db1, dw2, dls]
+        dtable = torch.empty_like(table)
+        L.check(L.lib().rgbnm_swin_cpb_bwd(blocks, nb, coords.data_ptr(), inv.data_ptr(), table.data_ptr(), dtable.data_ptr(),
+                                           L.stream()), "swin_cpb_bwd")
+        return tuple(out)
+
+
+def model_bias_and_scale(blocks):
+    """[(bias [heads,64,64], scale [heads])] for a list of SwinTransformerBlocks (the whole model: one _CpbFn node)."""
+    a0 = blocks[0].attn
+    consts = a0.__dict__.get("_cpb_consts")
+    dev = a0.relative_coords_table.device
+    if consts is None or consts[0].device != dev:
+        idx = a0.relative_position_index.view(-1)
+        consts = a0.__dict__["_cpb_consts"] = (a0.relative_coords_table.detach().reshape(-1, 2).float().contiguous(),
+                                               idx.to(torch.int32).contiguous(), inverse_index(idx, 225).contiguous())
+    for b in blocks:
+        if b.attn.window_size != (WS, WS):
+            raise NotImplementedError("continuous position bias kernels cover 8 x 8 windows")
+    heads = tuple(b.attn.num_heads for b in blocks)
+    params = []
+    for b in blocks:
+        params += [b.attn.cpb_mlp[0].weight, b.attn.cpb_mlp[0].bias, b.attn.cpb_mlp[2].weight, b.attn.logit_scale.view(-1)]
+    res = _CpbFn.apply(consts + (heads,), *params)
+    return [(res[2 * i], res[2 * i + 1]) for i in range(len(blocks))]
 
 
 class SwinTransformerBlock(nn.Module):
@@ -499,15 +676,19 @@ class SwinTransformerBlock(nn.Module):
         return (torch.rand(B, device=dev) < keep).float() / keep
 
     def run(self, x, B, sh, pre, bias_scale=None, drop=None):
-        """bias_scale: (bias, scale) of this block from stage_bias_and_scale; drop: the block's two DropPath scale vectors [2,B]
+        """bias_scale: (bias, scale) of this block from model_bias_and_scale (None: computed here, for this block alone); drop: the block's two DropPath scale vectors [2,B]
         (drawn for the whole model at once) or None."""
         res, C_ = self.input_resolution[0], self.dim
         a = self.attn
-        bias, scale = a.bias_and_scale() if bias_scale is None else bias_scale
+        bias, scale = model_bias_and_scale([self])[0] if bias_scale is None else bias_scale
         ds1 = self._drop_scale(B, x.device) if drop is None else drop[0]
         ds2 = self._drop_scale(B, x.device) if drop is None else drop[1]
-        qb = torch.cat((a.q_bias, torch.zeros_like(a.v_bias, requires_grad=False), a.v_bias))
-        qkv, xs = _LinearFn.apply(x, a.qkv.weight, qb, sh[pre + "attn.qkv"], True)      # xs = x: the shortcut (fork)
+        shq = sh[pre + "attn.qkv"]
+        if len(shq) > 2 and shq[2] is not None:
+            qb = _QkvBiasFn.apply(a.q_bias, a.v_bias, shq[2])       # q_bias | 0 | v_bias as the prep launch wrote it: no cat, no fill
+        else:
+            qb = torch.cat((a.q_bias, torch.zeros_like(a.v_bias, requires_grad=False), a.v_bias))
+        qkv, xs = _LinearFn.apply(x, a.qkv.weight, qb, shq, True)      # xs = x: the shortcut (fork)
         o = _WinAttnFn.apply(qkv, bias, scale, B, res, C_, self.num_heads, self.shift_size)
         o = _LinearFn.apply(o, a.proj.weight, a.proj.bias, sh[pre + "attn.proj"])
         x = _LNFn.apply(o, self.norm1.weight, self.norm1.bias, xs, ds1, res * res)
@@ -589,6 +770,7 @@ class SwinTransformerV2(FlatParamModule):
         # one weight-gradient bracket around the backward pass (_DwBracket).  Default off, like ViT.defer_grad_reduction: the
         # weight gradients then exist only when backward() has returned, which torch DDP's reducer hooks do not wait for
         self.group_dw_backward = False
+        self.hold_reductions = True                 # with group_dw_backward: the pass's split-sum reductions as ONE launch too
         self._conv = None
         self._table_devs = set()                    # devices whose GELU table this model has made sure of (forward, lazily)
 
@@ -657,25 +839,33 @@ class SwinTransformerV2(FlatParamModule):
         if (self.group_dw_backward and torch.is_grad_enabled() and cdt == torch.bfloat16 and self._grad_sync is None
                 and self.head.weight.requires_grad and pe.projection[0].weight.requires_grad):
             br = self.__dict__.setdefault("_dw_bracket", _DwBracket())
+            hb = self.__dict__.setdefault("_hold_bracket", _HoldBracket())
             if br.active:                       # a backward pass that never reached the patch embedding
                 _ACTIVE[0] = None
                 br.abandon()
+            if hb.active:                       # (its recorded reductions are dropped when the owning thread opens the next bracket)
+                _HOLD[0] = None
+                hb.active, hb.keep, hb.post = False, [], []
+            hb.reserve(dev)
         x = _LinearFn.apply(feat, pe.projection[0].weight, pe.projection[0].bias, sh["patch_embed.projection.0"], False,
                             None if br is None else ("close", br))
         x = _LNFn.apply(x, pe.norm.weight, pe.norm.bias, None, None, 1)
         drops = self._drop_scales(B, dev)
+        # position bias / logit scale of all blocks: ONE autograd node, two launches per direction (_CpbFn)
+        cpb = model_bias_and_scale([blk for ly in self.layers for blk in ly.blocks])
         k = 0
         for li, ly in enumerate(self.layers):
-            biases, scales = stage_bias_and_scale(ly.blocks)
             for bi, blk in enumerate(ly.blocks):
-                x = blk.run(x, B, sh, f"layers.{li}.blocks.{bi}.", (biases[bi], scales[bi]), None if drops is None else drops[k])
+                x = blk.run(x, B, sh, f"layers.{li}.blocks.{bi}.", cpb[k], None if drops is None else drops[k])
                 k += 1
             if ly.downsample is not None:
                 x = ly.downsample.run(x, B, sh, f"layers.{li}.downsample.")
                 res //= 2
         x = _LNFn.apply(x, self.norm.weight, self.norm.bias, None, None, 1)
         x = _MeanFn.apply(x, B, res * res, self.num_features)
-        return _LinearFn.apply(x, self.head.weight, self.head.bias, sh["head"], False, None if br is None else ("open", br, [p for p in self.parameters() if p.requires_grad]))
+        return _LinearFn.apply(x, self.head.weight, self.head.bias, sh["head"], False,
+                               None if br is None else ("open", br, [p for p in self.parameters() if p.requires_grad],
+                                                        self._hold_bracket if self.hold_reductions else None))
 
     def _drop_scales(self, B, dev):
         """timm DropPath (per-sample Bernoulli(keep) / keep) for every residual branch of the model from ONE uniform draw:
@@ -699,7 +889,7 @@ class SwinTransformerV2(FlatParamModule):
         lin = [n[:-len(".weight")] for n, p in self.named_parameters()
                if n.endswith(".weight") and p.dim() == 2 and "cpb_mlp" not in n]
         descs = (L.LinearDesc * len(lin))()
-        self._sh_off, so = {}, 0
+        self._sh_off, so, bo = {}, 0, 0
         for k, name in enumerate(lin):
             Nn, Kk = self._shapes[name + ".weight"]
             # row pairing (see _paired): widths that are multiples of 96 but not both of 192 -- the first stage of SwinV2-T
@@ -707,10 +897,22 @@ class SwinTransformerV2(FlatParamModule):
             nel = Nn * Kk * (4 if pair else 1)
             ws, wst = so, so + align(nel)
             so = wst + align(nel)
-            descs[k] = L.LinearDesc(self._offs[name + ".weight"], 0, ws, wst, 0, Nn, Kk, 0, 0, 0, pair)
-            self._sh_off[name] = (ws, wst, Nn * (2 if pair else 1), Kk * (2 if pair else 1))
+            # the bias operand of the GEMM epilogue, prepared by the same launch (fp32; written twice for a row-paired layer; the
+            # qkv Linear's is q_bias | 0 | v_bias, swinv2.py:150-152) -- instead of a torch.cat (+ a zeros fill) per layer and step
+            mode, b_off, b2_off = 0, 0, 0
+            if name.endswith("attn.qkv"):
+                pre = name[:-len("qkv")]
+                mode, b_off, b2_off = 2, self._offs[pre + "q_bias"], self._offs[pre + "v_bias"]
+            elif name + ".bias" in self._offs:
+                mode, b_off = 1, self._offs[name + ".bias"]
+            bp = bo
+            if mode:
+                bo += align(Nn * (2 if pair else 1))
+            descs[k] = L.LinearDesc(self._offs[name + ".weight"], b_off, ws, wst, bp, Nn, Kk, 0, 0, 0, pair, 0, 0, mode, 0, b2_off)
+            self._sh_off[name] = (ws, wst, Nn * (2 if pair else 1), Kk * (2 if pair else 1), bp if mode else -1)
         self._ndesc, self._sh_total = len(lin), so
         self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        self._bias_prep = torch.zeros(max(bo, 1), device=dev, dtype=torch.float32)
         self._shadow, self._sh_views = {}, {}
 
     def _prep(self, cdtype):
@@ -718,9 +920,10 @@ class SwinTransformerV2(FlatParamModule):
         if cdtype not in self._shadow:
             buf = torch.zeros(self._sh_total, device=self._flat.device, dtype=cdtype)
             self._shadow[cdtype] = buf
-            self._sh_views[cdtype] = {n: (buf[ws:ws + Nn * Kk].view(Nn, Kk), buf[wst:wst + Nn * Kk].view(Kk, Nn))
-                                      for n, (ws, wst, Nn, Kk) in self._sh_off.items()}
+            self._sh_views[cdtype] = {n: (buf[ws:ws + Nn * Kk].view(Nn, Kk), buf[wst:wst + Nn * Kk].view(Kk, Nn),
+                                          None if bp < 0 else self._bias_prep[bp:bp + Nn])
+                                      for n, (ws, wst, Nn, Kk, bp) in self._sh_off.items()}
         L.check(L.lib().rgbnm_prep_weights(L.dt_of(cdtype), self._descs_dev.data_ptr(), self._ndesc,
-                                           self._flat.data_ptr(), self._shadow[cdtype].data_ptr(), None, L.stream()),
-                "prep_weights")
+                                           self._flat.data_ptr(), self._shadow[cdtype].data_ptr(), self._bias_prep.data_ptr(),
+                                           L.stream()), "prep_weights")
         return self._sh_views[cdtype]

@@ -475,3 +475,113 @@ def test_abandoned_weight_gradient_bracket_is_dropped_not_launched():
     rg.cls_transforms.cross_entropy(v(yv, cv), lv, grad_dtype=torch.bfloat16).backward()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p.grad).all() for p in v.parameters())
+
+
+@pytest.mark.gpu
+def test_position_bias_kernels_vs_oracle():
+    """rgbnm_swin_cpb_fwd / _bwd (round 6: the continuous position bias and logit scale of every block in two launches per direction)
+    against the oracle's restatement of swinv2.py:158-168 in fp64 autograd: bias, scale, and the gradients of cpb_mlp's two Linears
+    and of logit_scale (one of them beyond the clamp at ln 100, where the gradient must be zero), for blocks of 3, 6 and 24 heads in
+    ONE call; run twice: the same bits."""
+    from rgb_no_more_amd import swinv2 as SW
+    from oracle import swin_torch as ST
+    heads = [3, 6, 24]
+    blocks = []
+    for i, h in enumerate(heads):
+        blk = SW.SwinTransformerBlock(32 * h, (16, 16), h, 8, 0, 0.0, device=DEV)
+        with torch.no_grad():
+            blk.attn.cpb_mlp[0].weight.copy_(torch.from_numpy(detfill.normalish((512, 2), 300 + i)).to(DEV))
+            blk.attn.cpb_mlp[0].bias.copy_(torch.from_numpy(detfill.normalish((512,), 310 + i)).to(DEV) * 0.5)
+            blk.attn.cpb_mlp[2].weight.copy_(torch.from_numpy(detfill.normalish((h, 512), 320 + i)).to(DEV) * 0.1)
+            ls = detfill.uniform((h, 1, 1), 330 + i, 1.0, 5.0).astype(np.float32)     # some beyond ln 100 = 4.605
+            blk.attn.logit_scale.copy_(torch.from_numpy(ls).to(DEV))
+        blocks.append(blk)
+
+    def run():
+        for b in blocks:
+            b.zero_grad()
+        outs = SW.model_bias_and_scale(blocks)
+        gs = []
+        loss = 0
+        for i, (bias, scale) in enumerate(outs):
+            gb = torch.from_numpy(detfill.normalish(tuple(bias.shape), 340 + i)).to(DEV)
+            gsc = torch.from_numpy(detfill.normalish(tuple(scale.shape), 350 + i)).to(DEV)
+            gs.append((gb, gsc))
+            loss = loss + (bias * gb).sum() + (scale * gsc).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return outs, gs, [[p.grad.clone() for p in (b.attn.cpb_mlp[0].weight, b.attn.cpb_mlp[0].bias, b.attn.cpb_mlp[2].weight,
+                                                      b.attn.logit_scale)] for b in blocks]
+
+    outs, gs, grads = run()
+    outs2, _, grads2 = run()
+    for (b1, s1), (b2, s2) in zip(outs, outs2):
+        assert torch.equal(b1, b2) and torch.equal(s1, s2)
+    for g1, g2 in zip(grads, grads2):
+        assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    for i, blk in enumerate(blocks):
+        a = blk.attn
+        p = {"x.attn.cpb_mlp.0.weight": a.cpb_mlp[0].weight.detach().double().cpu().requires_grad_(True),
+             "x.attn.cpb_mlp.0.bias": a.cpb_mlp[0].bias.detach().double().cpu().requires_grad_(True),
+             "x.attn.cpb_mlp.2.weight": a.cpb_mlp[2].weight.detach().double().cpu().requires_grad_(True)}
+        ls = a.logit_scale.detach().double().cpu().requires_grad_(True)
+        # oracle/swin_torch.py position_bias in fp64, on the ORACLE's own table and index (not the product's buffers)
+        tab = ST.coords_table(8).double().reshape(-1, 2)
+        hid = torch.relu(tab @ p["x.attn.cpb_mlp.0.weight"].T + p["x.attn.cpb_mlp.0.bias"])
+        t = hid @ p["x.attn.cpb_mlp.2.weight"].T
+        bias_ref = 16.0 * torch.sigmoid(t[ST.position_index(8).reshape(-1)].reshape(64, 64, -1).permute(2, 0, 1))
+        scale_ref = torch.clamp(ls, max=float(np.log(1.0 / 0.01))).exp().view(-1)
+        gb, gsc = gs[i]
+        ((bias_ref * gb.double().cpu()).sum() + (scale_ref * gsc.double().cpu()).sum()).backward()
+        bias, scale = outs[i]
+        assert (bias.double().cpu() - bias_ref.detach()).abs().max() < 2e-5
+        assert ((scale.double().cpu() - scale_ref.detach()).abs() / scale_ref.detach()).max() < 2e-6
+        refs = [p["x.attn.cpb_mlp.0.weight"].grad, p["x.attn.cpb_mlp.0.bias"].grad, p["x.attn.cpb_mlp.2.weight"].grad, ls.grad]
+        for got, want, nm in zip(grads[i], refs, ("dW1", "db1", "dW2", "dls")):
+            err = (got.double().cpu().view(-1) - want.view(-1)).norm() / (want.norm() + 1e-30)
+            assert err < 2e-5, (heads[i], nm, err.item())
+        assert (ls.grad.view(-1)[ls.detach().view(-1) > np.log(100.0)] == 0).all()
+        assert (grads[i][3].view(-1).cpu()[ls.detach().view(-1) > np.log(100.0)] == 0).all()
+
+
+@pytest.mark.gpu
+def test_graph_replay_with_backward_wide_brackets_equals_the_eager_pass():
+    """group_dw_backward + hold_reductions (round 6: every split-sum reduction of the backward as one launch) inside a HIP-graph capture:
+    the buffers of the capture differ from the eager passes', the job tables are uploaded by copy nodes of the graph from page-locked
+    records of their own, partial sums must live until the bracket's launch (a freed d(scale) partial buffer showed as ONE differing
+    logit_scale gradient in two of five bench runs): three replays, every gradient the bits of the eager pass."""
+    B = 32
+    ws = torch.cuda.Stream()
+    with torch.cuda.stream(ws):
+        m, img, depths, heads, _ = _model("swt", DEV)
+        nb = img // 8
+        y = torch.from_numpy(detfill.normalish((B, 1, nb, nb, 8, 8), 291)).to(DEV).bfloat16()
+        c = torch.from_numpy(detfill.normalish((B, 2, nb // 2, nb // 2, 8, 8), 292)).to(DEV).bfloat16()
+        tgt = detfill.uniform((B, 1000), 293, 0.0, 1.0)
+        tgt = torch.from_numpy(tgt / tgt.sum(1, keepdims=True)).to(DEV)
+        m.eval()
+        m.compute_dtype = torch.bfloat16
+        m.group_dw_backward = m.hold_reductions = True
+
+        def part():
+            rg.cls_transforms.cross_entropy(m(y, c), tgt, grad_dtype=torch.bfloat16).backward()
+
+        m.zero_grad(set_to_none=True)
+        part()
+        torch.cuda.synchronize()
+        ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            part()
+        m.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=ws):
+            part()
+        for r in range(3):
+            junk = torch.full((1 << 24,), float("nan"), device=DEV)      # whatever the allocator hands out between replays
+            del junk
+            g.replay()
+            torch.cuda.synchronize()
+            bad = [n for n, p in m.named_parameters() if not torch.equal(ref[n], p.grad)]
+            assert not bad, (r, bad[:5])
+        del g

@@ -55,7 +55,7 @@ def main():
             f = lambda: L.check(lib.rgbnm_window_attention_fwd(1, qkv.data_ptr(), bias.data_ptr(), scale.data_ptr(), out.data_ptr(),  # noqa: E731
                                                                lse.data_ptr(), B, res, C, heads, shift, L.stream()))
             g = lambda: L.check(lib.rgbnm_window_attention_bwd(1, qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), bias.data_ptr(),  # noqa: E731
-                                                               bias_t.data_ptr(), scale.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                                               None, scale.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                                                                dbias.data_ptr(), dsp.data_ptr(), B, res, C, heads, shift,
                                                                ws.data_ptr(), wsb, L.stream()))
             tf, tb = timeit(f), timeit(g)

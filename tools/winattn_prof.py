@@ -29,7 +29,7 @@ ws = torch.empty(wsb, device="cuda", dtype=torch.uint8)
 L.check(lib.rgbnm_window_attention_fwd(1, qkv.data_ptr(), bias.data_ptr(), scale.data_ptr(), out.data_ptr(), lse.data_ptr(), B, res, Cc,
                                        heads, shift, L.stream()))
 for _ in range(5):
-    L.check(lib.rgbnm_window_attention_bwd(1, qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), bias.data_ptr(), bias.data_ptr(),
+    L.check(lib.rgbnm_window_attention_bwd(1, qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), bias.data_ptr(), None,
                                            scale.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), dsp.data_ptr(), B, res, Cc,
                                            heads, shift, ws.data_ptr(), wsb, L.stream()))
 torch.cuda.synchronize()
