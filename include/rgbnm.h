@@ -420,6 +420,13 @@ int rgbnm_vit_block_bwd_dw(const rgbnm_vit_cfg* cfg, const rgbnm_block_acts* a, 
 int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* cfg, int n, const rgbnm_block_acts* const* a, const rgbnm_block_grads* const* g,
                             const rgbnm_block_scratch* const* s, const void* const* dy, const float* const* part2,
                             const float* const* part1, void* stream);
+/* ... and the patch embedding's weight gradient (what rgbnm_patch_embed_bwd computes: pe_dw [E,384] / pe_db [E] = pe_dx0^T . pe_feat
+ * over the same token axis; pe_dx0 = the gradient rgbnm_vit_chain_bwd left for block 0's input) as one more job of the same
+ * grouped launch -- 252 + 4 = 256 output tiles at JPEG-Ti's B = 256: still no token split.  pe_dx0 NULL = the call above. */
+int rgbnm_vit_blocks_bwd_dw_pe(const rgbnm_vit_cfg* cfg, int n, const rgbnm_block_acts* const* a, const rgbnm_block_grads* const* g,
+                               const rgbnm_block_scratch* const* s, const void* const* dy, const float* const* part2,
+                               const float* const* part1, const void* pe_dx0, const void* pe_feat, float* pe_dw, float* pe_db,
+                               void* pe_ws, size_t pe_ws_bytes, void* stream);
 
 /* Table GELU of the bf16 path (csrc/mlp_fused.hip): in bf16 mode the pre-activation is rounded to bf16 before the GELU
  * (models/plainvit.py:487-488 under autocast), so gelu / gelu' are functions of 16 bits.  _init is a SET-UP call (it

@@ -537,7 +537,7 @@ int submit_tn_reduce(const GemmTN& p, float* dW, float* db, int S, int perm_head
 // deferred (grouped) weight-gradient launches
 struct TnPending { GemmTN p; float* dW; float* db; int perm_heads, accumulate; };
 thread_local bool g_tn_defer = false;     // per host thread, like the reduction queue (reduce.hip)
-constexpr int TN_QMAX = 48;
+constexpr int TN_QMAX = 52;      // = TN_MAXJOBS of gemm_tn_pipe.hip
 thread_local TnPending g_tn_q[TN_QMAX];
 thread_local int g_tn_n = 0, g_tn_cap = 4;
 thread_local int g_tn_tiles = 0;          // output tiles of the queued jobs (gemm_tn_pipe.hip: 128 x 192 tiles, one workgroup each)

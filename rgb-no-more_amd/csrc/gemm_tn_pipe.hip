@@ -49,7 +49,7 @@ struct TnPipe {
 // reads) shrink with the number of jobs grouped, and the write burst at the end of the launch happens once.  The four GEMMs of
 // one block (21 tiles) give S = 12; the 48 of all twelve blocks behind the one-launch backward (vit_chain_bwd.hip) 252 tiles and
 // S = 1: no split at all.
-constexpr int TN_MAXJOBS = 48;
+constexpr int TN_MAXJOBS = 52;      // the 48 of twelve ViT blocks + the patch embedding's (4 more tiles: 256 in all) and room to spare
 struct TnJobK {                   // per job, in the kernel argument segment
   const bf16* dY; const bf16* X; float* part; float* bpart;
   int ldy, ldx, No, Ki, ctiles, tile_end;       // tile_end: running sum of rtiles * ctiles

@@ -298,7 +298,18 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
 int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* c, int n, const rgbnm_block_acts* const* a, const rgbnm_block_grads* const* g,
                             const rgbnm_block_scratch* const* s, const void* const* dy, const float* const* part2,
                             const float* const* part1, void* st) {
+  return rgbnm_vit_blocks_bwd_dw_pe(c, n, a, g, s, dy, part2, part1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st);
+}
+
+// ... with the patch embedding's weight gradient (rgbnm_patch_embed_bwd: dW = dx0^T . feat, the same token axis) as one more job of
+// the same grouped launch: 252 + 4 = 256 tiles at B = 256, still no token split -- its own launch (21 us), its partial sums and
+// their share of the reduction are gone.  pe_dx0 == NULL: blocks only.
+int rgbnm_vit_blocks_bwd_dw_pe(const rgbnm_vit_cfg* c, int n, const rgbnm_block_acts* const* a, const rgbnm_block_grads* const* g,
+                               const rgbnm_block_scratch* const* s, const void* const* dy, const float* const* part2,
+                               const float* const* part1, const void* pe_dx0, const void* pe_feat, float* pe_dw, float* pe_db,
+                               void* pe_ws, size_t pe_ws_bytes, void* st) {
   if (!c || n < 1 || n > 12 || !a || !g || !s || !dy || !part2 || !part1) return RGBNM_EINVAL;
+  if (pe_dx0 && (!pe_feat || !pe_dw || !pe_ws)) return RGBNM_EINVAL;
   const int dt = c->dtype, M = c->B * c->N, E = c->E, I = c->heads * 64;
   size_t off[7];
   const size_t need = block_ws_offsets(M, E, I, off);
@@ -312,7 +323,7 @@ int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* c, int n, const rgbnm_block_act
   bool tn_open = false;
   const int rc = [&]() -> int {
     const int group = rgbnm_get_option("tn_group");
-    if (group) { rgbnm_tn_defer_begin_n(group == 1 ? 2 : 4 * n); tn_open = true; }
+    if (group) { rgbnm_tn_defer_begin_n(group == 1 ? 2 : 4 * n + (pe_dx0 ? 1 : 0)); tn_open = true; }
     for (int i = 0; i < n; ++i) {
       char* wsb = (char*)s[i]->ws;
 #define WS(k) (wsb + off[k]), (off[(k) + 1] - off[k])
@@ -322,6 +333,7 @@ int rgbnm_vit_blocks_bwd_dw(const rgbnm_vit_cfg* c, int n, const rgbnm_block_act
       TRY(rgbnm_gemm_tn(dt, s[i]->dqkv, 3 * I, a[i]->xn1, E, g[i]->dwqkv, g[i]->dbqkv, M, 3 * I, E, c->heads, 0, WS(3), st));
 #undef WS
     }
+    if (pe_dx0) TRY(rgbnm_gemm_tn(dt, pe_dx0, E, pe_feat, 384, pe_dw, pe_db, M, E, 384, 0, 0, pe_ws, pe_ws_bytes, st));
     if (group) { tn_open = false; TRY(rgbnm_tn_defer_flush((hipStream_t)st)); }
     for (int i = 0; i < n; ++i) {       // per-image partial sums of the LayerNorm parameter gradients (one panel per image)
       RgbnmReduceJob j;

@@ -159,6 +159,7 @@ PROTOTYPES = {
     "rgbnm_vit_chain_bwd": (_i, [_P(VitCfg), _P(ChainBwdBlock), _i, _vp, _vp]),
     "rgbnm_vit_block_bwd_dw": (_i, [_P(VitCfg), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp, _vp, _vp, _vp]),
     "rgbnm_vit_blocks_bwd_dw": (_i, [_P(VitCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rgbnm_vit_blocks_bwd_dw_pe": (_i, [_P(VitCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rgbnm_vit_block_fwd_chain": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _i, _P(BlockParams), _P(BlockActs), _vp]),
     "rgbnm_vit_block_bwd": (_i, [_P(VitCfg), _P(BlockParams), _P(BlockActs), _P(BlockGrads), _P(BlockScratch), _vp,
                                  _vp, _vp]),

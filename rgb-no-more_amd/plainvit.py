@@ -273,6 +273,7 @@ class _PatchEmbedFn(torch.autograd.Function):
                                                   m._pos.data_ptr(), a.feat.data_ptr(), a.xbuf(0).data_ptr(), Hb, Wb,
                                                   L.stream()), "patch_embed_fwd")
         ctx.st = st
+        st.pe_feat_ok = True        # a.feat holds this forward's patch features (the encoder node may compute this node's dW from them)
         return a.xbuf(0).detach()   # fresh tensor object per call (arena buffers are reused across steps)
 
     @staticmethod
@@ -284,8 +285,9 @@ class _PatchEmbedFn(torch.autograd.Function):
         # held reductions (head, encoder blocks and this node's own: a.ws is no other node's region) run as ONE launch now, before
         # the exchange
         try:
-            L.check(L.lib().rgbnm_patch_embed_bwd(C.byref(a.cfg), dx0.data_ptr(), a.feat.data_ptr(), gw.data_ptr(),
-                                                  gb.data_ptr(), a.ws.data_ptr(), a.ws_bytes, L.stream()), "patch_embed_bwd")
+            if getattr(st, "pe_done", None) != dx0.data_ptr():       # (else: computed by the encoder node's grouped launch)
+                L.check(L.lib().rgbnm_patch_embed_bwd(C.byref(a.cfg), dx0.data_ptr(), a.feat.data_ptr(), gw.data_ptr(),
+                                                      gb.data_ptr(), a.ws.data_ptr(), a.ws_bytes, L.stream()), "patch_embed_bwd")
         except BaseException:
             st.cancel_hold()
             raise
@@ -607,7 +609,19 @@ class _EncoderFn(torch.autograd.Function):
                     pdy = (C.c_void_p * n)(*[dy.data_ptr() if i == D - 1 else a.dx_blk[i + 1].data_ptr() for i in pend])
                     p2 = (C.c_void_p * n)(*[a.lnpart[i, 0].data_ptr() for i in pend])
                     p1 = (C.c_void_p * n)(*[a.lnpart[i, 1].data_ptr() for i in pend])
-                    L.check(L.lib().rgbnm_vit_blocks_bwd_dw(C.byref(a.cfg), n, pa, pg, ps, pdy, p2, p1, L.stream()), "vit_blocks_bwd_dw")
+                    # the launch that holds block 0 also takes the patch embedding's weight gradient (same token axis; dx0 is
+                    # a.dx_blk[0], which this node returns): 252 + 4 = 256 tiles -- its own launch and partial sums are gone
+                    pe = None
+                    if (pend[-1] == 0 and n == D and m.embed_kind == "group" and getattr(st, "pe_feat_ok", False)
+                            and all(p.requires_grad for p in m._pe_params_list())):
+                        pe = (m._gview(st.gbuf, "patchembed.projection.0.weight"), m._gview(st.gbuf, "patchembed.projection.0.bias"))
+                    if pe is None:
+                        L.check(L.lib().rgbnm_vit_blocks_bwd_dw(C.byref(a.cfg), n, pa, pg, ps, pdy, p2, p1, L.stream()), "vit_blocks_bwd_dw")
+                    else:
+                        L.check(L.lib().rgbnm_vit_blocks_bwd_dw_pe(C.byref(a.cfg), n, pa, pg, ps, pdy, p2, p1, a.dx_blk[0].data_ptr(),
+                                                                   a.feat.data_ptr(), pe[0].data_ptr(), pe[1].data_ptr(),
+                                                                   a.ws.data_ptr(), a.ws_bytes, L.stream()), "vit_blocks_bwd_dw_pe")
+                        st.pe_done = a.dx_blk[0].data_ptr()
                     if m._grad_sync is not None:
                         for i in pend:
                             m._grad_sync.ready(st.gbuf, m._block_names[i])
@@ -898,6 +912,12 @@ class ViT(FlatParamModule):
             self._build_names()
         return ([(self._head_names, False)] + [(self._block_names[i], False) for i in reversed(range(self.depth))] +
                 [(self._pe_names, True)])
+
+    def _pe_params_list(self):
+        pe = self.__dict__.get("_pe_params")
+        if pe is None:
+            pe = self.__dict__["_pe_params"] = [p for n, p in self._named.items() if n.startswith("patchembed.")]
+        return pe
 
     def _pptr(self, name):
         return self._flat.data_ptr() + self._offs[name] * 4
