@@ -38,7 +38,8 @@ def main(tag, name):
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     arch = "vitti"
-    for f in ("bench_line.json", "kernel_stats.csv", "pmc_mfma.json", "pmc_traffic.json", "calibration.json"):
+    for f in ("bench_line.json", "bench_line_fp32.json", "kernel_stats.csv", "step_order.txt", "pmc_mfma.json", "pmc_traffic.json",
+              "calibration.json", "pipeline_jpeg_fed.json"):
         p = os.path.join(src, f)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(dst, f"{name}_{f}"))

@@ -28,6 +28,7 @@ kstats() {   # kstats <outdir> <bench args...>
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python bench.py --steps 24 --warmup 4 --prewarm-sec 1 --no-cpu-baseline --no-trace "$@" > $OUT/kt.log 2>&1
   local f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -${KSTAT_LINES:-22} $OUT/kernel_stats.csv | cut -d, -f1-4 | cut -c1-150
+  python tools/step_order.py $OUT/kt $OUT/step_order.json > $OUT/step_order.txt 2>&1; head -1 $OUT/step_order.txt    # the launches of one step, in order
   rm -rf $OUT/kt
 }
 traffic() {  # traffic <outdir> <bench args...>: FETCH_SIZE / WRITE_SIZE in separate passes (eager: a graph capture would add dispatches)
@@ -46,6 +47,8 @@ pass)
   fi
   timeout 200 python tools/calib.py > $OUT/calibration.json 2>/dev/null; cat $OUT/calibration.json
   timeout 400 python bench.py --steps 100 --warmup 10 > $OUT/bench_line.json 2> $OUT/bench.err; cat $OUT/bench_line.json
+  timeout 600 python bench.py --dtype fp32 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_line_fp32.json 2>> $OUT/bench.err      # the mode that carries the 1e-3 tolerance
+  timeout 600 python tools/pipeline_bench.py > $OUT/pipeline_jpeg_fed.json 2>> $OUT/bench.err; tail -c 400 $OUT/pipeline_jpeg_fed.json   # JPEG files -> host decode -> H2D -> step (never `value`)
   kstats $OUT
   timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-sec 0 --no-cpu-baseline --no-trace --no-graph --no-parity-check > $OUT/pmc_mfma.log 2>&1
   python tools/pmc_mfma.py $OUT/pmc_mfma $OUT/pmc_mfma.json 2>&1 | tail -30

@@ -66,6 +66,7 @@ def main():
     opt = rg.custom_optims.FusedClipAdamWWD(model, lr=1e-3, eps=1e-8, weight_decay=1e-4, max_norm=1.0)
     mix = rg.cls_transforms.RandomMixup_DCT(1000, alpha=0.2)
     mix.out_dtype = torch.bfloat16
+    mix.lazy = True             # the ViT mixes while its sub-block kernel loads (cls_transforms.LazyMixed), as in bench.py
     aug = CT.TrainTransform_DCT(out_dtype=torch.bfloat16)
     sampler = CT.FastParamSampler(aug, seed=1234)
     lab = torch.randint(0, 999, (B,), device=dev)
