@@ -77,4 +77,10 @@ int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* qu
                               Wy, Hc, Wc, entry_clamp, nops, workspace, workspace_bytes, stream);
 }
 
+#ifdef AUG_PROF
+int rgbnm_debug_aug_prof(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(aug28::g_aug_prof), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 }  // extern "C"
