@@ -81,6 +81,9 @@ int rgbnm_dct_augment(const int16_t* Yq, const int16_t* CbCrq, const int16_t* qu
 int rgbnm_debug_aug_prof(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(aug28::g_aug_prof), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
 }
+int rgbnm_debug_aug_prof2(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(aug28::g_aug_prof2), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
 #endif
 
 }  // extern "C"

@@ -211,3 +211,22 @@ def test_swin_pipeline_32_block_grid_every_op_and_resize_cases():
     tt = CT.TrainTransform_DCT(size=32)
     sides = {p["box"][3] for p in tt.sample_params(400, 64, 64)}
     assert sides <= {16, 32, 64} and len(sides) == 3
+
+
+def test_torange_quotient_is_exact_for_every_int16():
+    """The kernel's ToRange divides by 2040 with a reciprocal and one residual step instead of the division sequence; the class
+    passes whatever coefficients the preceding transform left (no clamp), so EVERY int16 value must come out with the bits of
+    the reference's statements (custom_transforms.py:447-452): fp32 exactly, bf16 = the rounded fp32 chain."""
+    vals = np.arange(-32768, 32768, dtype=np.int16)
+    Y = np.zeros((2, 1, 28, 28, 8, 8), np.int16)
+    Y.reshape(-1)[:65536] = vals                       # 2 x 50176 luma slots hold all 65536 values
+    Y.reshape(-1)[65536:] = vals[::-1][:2 * 50176 - 65536]
+    C = np.zeros((2, 2, 14, 14, 8, 8), np.int16)
+    C.reshape(-1)[:] = vals[7000:7000 + 2 * 25088]
+    for dt in (torch.float32, torch.bfloat16):
+        oy, oc = CT.ToRange(-1, 1, -1024, 1016, dtype=dt)((torch.from_numpy(Y).to(DEV), torch.from_numpy(C).to(DEV)))
+        torch.cuda.synchronize()
+        for got, src in ((oy, Y), (oc, C)):
+            x = torch.from_numpy(src).float()
+            want = (-1.0 + ((x - (-1024)) / torch.full((), 2040.0)) * 2.0).to(dt)      # the fused pipeline's output cast (see the bf16 case above)
+            assert got.dtype == dt and torch.equal(got.cpu(), want.reshape(got.shape)), dt

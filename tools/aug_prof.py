@@ -23,6 +23,10 @@ lib = L.lib()
 f = lib.rgbnm_debug_aug_prof
 f.restype = C.c_int
 f.argtypes = [C.c_void_p]
+f2 = lib.rgbnm_debug_aug_prof2
+f2.restype = C.c_int
+f2.argtypes = [C.c_void_p]
+OPN = {}
 rows = []
 for it in range(12):
     packed, nops = sampler.sample(B, 64, 64)
@@ -57,3 +61,15 @@ for it in range(12):
           " mean end by xcc", [int(np.mean((t2 - start)[xcc == x])) for x in range(8)])
     pure = [(n[:, m] > 0) & (n.sum(1) == n[:, m]) for m in range(3)]
     print("   waves with ONE mode only: count / mean work / items:", [(int(q.sum()), int(work[q].mean()) if q.any() else 0, float(n[q].sum(1).mean()) if q.any() else 0) for q in pure])
+    b2 = np.zeros(4096 * 8, dtype=np.uint64)
+    assert f2(b2.ctypes.data) == 0
+    q = b2.reshape(256, 16, 8).astype(np.int64)
+    ld, o1, o2, stt, tot = q[:, :, 1] - q[:, :, 0], q[:, :, 2] - q[:, :, 1], q[:, :, 3] - q[:, :, 2], q[:, :, 4] - q[:, :, 3], q[:, :, 4] - q[:, :, 0]
+    print(f"   kernel 2 (per wave, cycles): load+sync mean {ld.mean():.0f} max {ld.max()}; op slot 0 mean {o1.mean():.0f} max {o1.max()}; op slot 1 mean {o2.mean():.0f} max {o2.max()}; "
+          f"ToRange+store mean {stt.mean():.0f} max {stt.max()}; wave life mean {tot.mean():.0f} p95 {np.percentile(tot, 95):.0f} max {tot.max()}")
+    ops = q[:, 0, 5]
+    byop = {}
+    for b in range(256):
+        byop.setdefault(int(q[b, 0, 5]), []).append(o1[b].max())
+        byop.setdefault(int(q[b, 0, 6]), []).append(o2[b].max())
+    print("   cycles by op id (slot time, slowest wave of the workgroup):", {k: int(np.mean(v)) for k, v in sorted(byop.items())})
