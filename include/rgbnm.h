@@ -53,6 +53,8 @@ int rgbnm_abi_version(void);
  *   "tn_group"     2  dW GEMMs of a ViT block: 0 one per launch, 1 pairs, 2 all four in one launch
  *   "tn_direct"    1  a grouped launch that ends up without a token split writes dW / db itself (no partial sums, no reduction)
  *   "tn_pack"      1  ... and places its tiles so that no GEMM straddles two XCDs (L2 locality)
+ *   "tn_wide"      1  weight-gradient launches whose GEMMs all have No % 192 == 0 and Ki % 384 == 0 (E = 384 and wider) run 192 x 384
+ *                     tiles (128 flops per byte taken in instead of 77: the kernel is bound by its intake there, not by HBM)
  *   "tn_wgs"     512  workgroup budget of the generic kernel's token split
  *   attention
  *   "attn_v2"      1  LDS-DMA / transpose-read attention kernels (0: first-generation kernels, also used for 294 tokens)

@@ -349,6 +349,214 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(TnGroup grp) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ wide tiles (round 6)
+// Every workgroup of the kernel above takes in ~18 bytes per cycle through the LDS-DMA path whatever it computes (JPEG-Ti's one
+// launch: 256 tiles x 50 176 tokens x 640 B in 770 us = 10.7 TB/s; a JPEG-S pair launch: the same 11 TB/s), and a 128 x 192 tile
+// does 77 flops per byte taken in: at E = 192 the operands are read from HBM once and that is the bound, at E = 384 each operand
+// row is shared by 2 - 12 tiles through L2, the HBM side idles at 2.8 TB/s and the MFMA pipe at 0.30 -- the intake is the bound.
+// Same pipeline with a 192 x 384 tile (128 flops per byte): 8 waves as 2 (M) x 4 (N), wave tile 96 x 96 = 3 x 3 MFMA tiles
+// (9 MFMAs per 6 fragment reads instead of 3 per 4), token tiles of 32 rows (36 KB) in a 4-stage ring (108 KB in flight per CU).
+// The A tile has the 384-byte rows of the narrow kernel's B tile and its swizzle; the B tile's 768-byte rows put all four rows of a
+// transpose read's footprint into the same 256-byte bank window, so its 64-byte segments are XOR-ed with (row & 3) inside
+// their group of four, like the narrow A tile.  Eligible: No % 192 == 0 and Ki % 384 == 0 (E = 384 / 768 / 1536 Linears).
+constexpr int WTK = 32;
+constexpr int WA_ROW = 384, WB_ROW = 768;
+constexpr int WA_STAGE = WTK * WA_ROW;          // 12 KB
+constexpr int WB_STAGE = WTK * WB_ROW;          // 24 KB
+constexpr int WSTAGE = WA_STAGE + WB_STAGE;     // 36 KB = 36 DMA instructions of 1 KB
+constexpr int WNSTAGE = 4;
+constexpr int WSMEM = WNSTAGE * WSTAGE;         // 144 KB
+
+// the 12 transpose reads of chunk C (16 tokens): 3 A fragments + 3 B fragments, no wait
+template <int C>
+__device__ __forceinline__ void trw_chunk(unsigned aA0, unsigned aA1, unsigned aA2, unsigned aB0, unsigned aB1, unsigned aB2,
+                                          u32x2 (&r)[12]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %12 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %1, %12 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %2, %13 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %3, %13 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %4, %14 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %5, %14 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %6, %15 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %7, %15 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %8, %16 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %9, %16 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %10, %17 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %11, %17 offset:%21\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+        "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11])
+      : "v"(aA0), "v"(aA1), "v"(aA2), "v"(aB0), "v"(aB1), "v"(aB2), "i"(C * 16 * WA_ROW), "i"(C * 16 * WA_ROW + 4 * WA_ROW),
+        "i"(C * 16 * WB_ROW), "i"(C * 16 * WB_ROW + 4 * WB_ROW)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int u = (blockIdx.x & 7) * 32 + (blockIdx.x >> 3);        // XCD-contiguous unit numbering (see the narrow kernel)
+  int s, tile, job = 0;
+  if (grp.packed) {
+    job = grp.unit_job[u];
+    if (job == 255) return;
+    tile = grp.unit_tile[u];
+    s = 0;
+  } else {
+    if (u >= grp.S * grp.tiles) return;
+    s = u / grp.tiles;
+    tile = u % grp.tiles;
+    while (tile >= grp.j[job].tile_end) ++job;
+    if (job) tile -= grp.j[job - 1].tile_end;
+  }
+  const TnJobK& q = grp.j[job];
+  const bf16* dY = q.dY; const bf16* X = q.X;
+  const int ldy = q.ldy, ldx = q.ldx, No = q.No, Ki = q.Ki, perm = q.perm;
+  float* bpart = q.bpart;
+  const int rt = tile / q.ctiles, ct = tile % q.ctiles;
+  const int r0 = rt * 192, c0 = ct * 384;
+  const int kt0 = s * grp.kt_per_split;
+  const int T = min(grp.kt_per_split, grp.M / WTK - kt0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  // ---- global source offsets (elements) of the stage's 36 LDS-DMA instructions: 0 - 11 the A tile, 12 - 35 the B tile; wave w
+  // issues instructions w, w + 8, w + 16, w + 24 of every tile and instruction 32 + (w & 3) of the tiles with (t & 1) == (w >> 2):
+  // 4 or 5 per tile, NINE per two consecutive tiles -- the count the waits below are written for
+  auto src_off = [&](int qi) -> int {
+    if (qi < 12) {
+      const int pidx = qi * 64 + lane;                            // 16-byte pieces, 24 per 384-byte row
+      const int row = pidx / 24, pv = pidx % 24;
+      const int v = (((pv >> 2) ^ ((row >> 1) & 1)) << 2) | (pv & 3);
+      return row * ldy + r0 + v * 8;
+    }
+    const int pidx = (qi - 12) * 64 + lane;                       // 48 per 768-byte row
+    const int row = pidx / 48, pv = pidx % 48;
+    const int sg = pv >> 2;
+    const int v = ((((sg & ~3) | ((sg & 3) ^ (row & 3)))) << 2) | (pv & 3);
+    return row * ldx + c0 + v * 8;
+  };
+  int off[5];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) off[j] = src_off(w + 8 * j);
+  off[4] = src_off(32 + (w & 3));
+  const bf16* gA = dY + (size_t)kt0 * WTK * ldy;
+  const bf16* gB = X + (size_t)kt0 * WTK * ldx;
+  const size_t stepA = (size_t)WTK * ldy, stepB = (size_t)WTK * ldx;
+
+  auto issue = [&](int stage, int t) {
+    unsigned char* st = smem + stage * WSTAGE;
+    // instruction w: A tile for every wave (w < 12); w + 8: A for waves 0 - 3, B for the others; the rest: B
+    __builtin_amdgcn_global_load_lds((glb_ptr)(gA + off[0]), (lds_ptr)(st + w * 1024), 16, 0, (TN_NT & 1) ? 2 : 0);
+    if (w < 4) __builtin_amdgcn_global_load_lds((glb_ptr)(gA + off[1]), (lds_ptr)(st + (w + 8) * 1024), 16, 0, (TN_NT & 1) ? 2 : 0);
+    else __builtin_amdgcn_global_load_lds((glb_ptr)(gB + off[1]), (lds_ptr)(st + (w + 8) * 1024), 16, 0, (TN_NT & 2) ? 2 : 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(gB + off[2]), (lds_ptr)(st + (w + 16) * 1024), 16, 0, (TN_NT & 2) ? 2 : 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(gB + off[3]), (lds_ptr)(st + (w + 24) * 1024), 16, 0, (TN_NT & 2) ? 2 : 0);
+    if (((t ^ (w >> 2)) & 1) == 0)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gB + off[4]), (lds_ptr)(st + (32 + (w & 3)) * 1024), 16, 0, (TN_NT & 2) ? 2 : 0);
+    gA += stepA;
+    gB += stepB;
+  };
+
+  // ---- per-lane LDS byte offsets of the transpose reads ----
+  const int k = (lane >> 2) & 3;
+  const int within = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  const int kb = (k >> 1) & 1;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned oA[3], oB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    oA[i] = (8 * g + k) * WA_ROW + (((3 * wm + i) ^ kb) << 6) + within;
+    const int sg = 3 * wn + i;
+    oB[i] = WA_STAGE + (8 * g + k) * WB_ROW + (((sg & ~3) | ((sg & 3) ^ k)) << 6) + within;
+  }
+
+  f32x16 acc[3][3], accb[3];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      accb[i][r] = 0.f;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[i][b][r] = 0.f;
+    }
+  }
+  const bool do_bias = (bpart != nullptr) && (ct == 0) && (wn == 0);
+  Frag<bf16> ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.v[e] = (bf16)1.0f;
+
+  int st_issue = 0, st_comp = 0;
+#pragma unroll
+  for (int i = 0; i < WNSTAGE - 1; ++i)
+    if (i < T) {
+      issue(i, i);
+      st_issue = i + 1 == WNSTAGE ? 0 : i + 1;
+    }
+  auto tiles = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
+    for (int t = 0; t < T; ++t) {
+      // tile t landed; the two younger tiles (nine DMA instructions of this wave together) may stay in flight; towards the end
+      // one younger tile (four or five: four is the safe count), then none
+      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();     // tile t landed for every wave; every wave is done with tile t - 1
+      if (t + WNSTAGE - 1 < T) {
+        issue(st_issue, t + WNSTAGE - 1);
+        st_issue = st_issue == WNSTAGE - 1 ? 0 : st_issue + 1;
+      }
+      const unsigned sb = lds0 + st_comp * WSTAGE;
+      st_comp = st_comp == WNSTAGE - 1 ? 0 : st_comp + 1;
+      u32x2 r[12];
+#define WCHUNK(C)                                                                                     \
+      trw_chunk<C>(sb + oA[0], sb + oA[1], sb + oA[2], sb + oB[0], sb + oB[1], sb + oB[2], r);        \
+      {                                                                                               \
+        Frag<bf16> fa[3], fb[3];                                                                      \
+        fa[0].v = pack8(r[0], r[1]); fa[1].v = pack8(r[2], r[3]); fa[2].v = pack8(r[4], r[5]);        \
+        fb[0].v = pack8(r[6], r[7]); fb[1].v = pack8(r[8], r[9]); fb[2].v = pack8(r[10], r[11]);      \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
+          _Pragma("unroll") for (int b = 0; b < 3; ++b) mma(acc[i][b], fa[i], fb[b]);                 \
+          if constexpr (BIAS) mma(accb[i], fa[i], ones);                                              \
+        }                                                                                             \
+      }
+      WCHUNK(0) WCHUNK(1)
+#undef WCHUNK
+    }
+  };
+  if (do_bias) tiles(BoolTag<true>());
+  else tiles(BoolTag<false>());
+
+  float* part = q.part + (size_t)s * No * Ki;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int orow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + wm * 96 + i * 32 + acc_row(r, lane);
+      int o = row;
+      if (perm > 0) {
+        const int inner = perm * 64, s3 = row / inner, rem = row % inner;
+        o = (rem / 64) * 192 + (rem % 64) * 3 + s3;
+      }
+      orow[r] = o;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int col = c0 + wn * 96 + b * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(size_t)orow[r] * Ki + col] = acc[i][b][r];
+    }
+    if (do_bias && l31 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bpart[(size_t)s * No + orow[r]] = accb[i][r];
+    }
+  }
+}
+
 // (Round 6 pruned the 192 x 192 / 6-wave variant, option tn_square: measured no faster at B = 256 and slower in its reduction.)
 
 }  // namespace
@@ -379,11 +587,23 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   TnGroup g;
   int tiles = 0;
   double flops = 0, bytes = 0;
+  // wide tiles (192 x 384) when every job of the launch has the shape for them
+  bool wide = rgbnm_get_option("tn_wide") != 0;
+  for (int i = 0; i < n && wide; ++i) wide = jobs[i].No % 192 == 0 && jobs[i].Ki % 384 == 0 && jobs[i].M % WTK == 0;
+  if (wide) {
+    static DevOnce attr_w;
+    if (attr_w.need()) {
+      if (hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM) != hipSuccess)
+        return RGBNM_ELAUNCH;
+      attr_w.done();
+    }
+  }
   for (int i = 0; i < n; ++i) {
     const RgbnmTnJob& j = jobs[i];
     if (j.M != jobs[0].M) return 1;
     TnPipe t;
     if (tn_fill(t, j.dY, j.ldy, j.X, j.ldx, j.part, j.bpart, j.M, j.No, j.Ki)) return 1;
+    if (wide) { t.rtiles = j.No / 192; t.ctiles = j.Ki / 384; }
     tiles += t.rtiles * t.ctiles;
     TnJobK& q = g.j[i];
     q.dY = t.dY; q.X = t.X; q.part = t.part; q.bpart = t.bpart; q.ldy = t.ldy; q.ldx = t.ldx; q.No = t.No; q.Ki = t.Ki;
@@ -393,7 +613,7 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   }
   for (int i = n; i < TN_MAXJOBS; ++i) { g.j[i] = g.j[0]; g.j[i].tile_end = tiles; }
   if (tiles > 256) return 1;
-  const int ktiles = jobs[0].M / TK;
+  const int ktiles = jobs[0].M / (wide ? WTK : TK);
   // one workgroup per CU (120 KB LDS) and at most 256 of them: a 257th would wait for a whole first round
   int S = 256 / tiles;
   if (S > RGBNM_TN_MAX_SPLIT) S = RGBNM_TN_MAX_SPLIT;
@@ -446,7 +666,8 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
     }
   }
   const int slot = rgbnm_trace_begin(TR_TN, flops, bytes, st);
-  hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(256), dim3(512), SMEM, st, g);
+  if (wide) hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3(256), dim3(512), WSMEM, st, g);
+  else hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(256), dim3(512), SMEM, st, g);
   rgbnm_trace_end(slot, st);
   LAUNCH_CHECK();
   return RGBNM_OK;

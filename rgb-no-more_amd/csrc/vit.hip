@@ -32,7 +32,7 @@ hipEvent_t take_event() {
 // process-wide configuration switches (A/B experiments): atomics, so reading them from concurrent calls is race-free;
 // they select between parity-tested kernels and are meant to be set before work is enqueued
 struct Opt { const char* name; std::atomic<int> value; };
-Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}, {"bwd_chain", 1}, {"tn_direct", 1}, {"tn_pack", 1}};
+Opt g_opts[] = {{"nt_staged", 1}, {"tn_tr", 1}, {"tn_pipe", 1}, {"attn_v2", 1}, {"nt_wres", 1}, {"nt_kpipe", 1}, {"attn_persist", 1}, {"ln_fuse", 1}, {"tn_group", 2}, {"trace", 0}, {"tn_wgs", 512}, {"mlp_fuse", 1}, {"nt_cold", 0}, {"mlp_bwd", 1}, {"nt_small", 1}, {"mlp_dmast", 1}, {"gelu_table", 1}, {"ln_rows", 1}, {"kp8", 1}, {"win_xcd", 1}, {"kp_persist", 1}, {"fwd_chain", 1}, {"bwd_chain", 1}, {"tn_direct", 1}, {"tn_pack", 1}, {"tn_wide", 1}};
 }
 
 int rgbnm_trace_begin(int tag, double flops, double bytes, hipStream_t st) {
@@ -250,7 +250,9 @@ int rgbnm_vit_block_bwd(const rgbnm_vit_cfg* c, const rgbnm_block_params* p, con
   // CUs; as pairs (48 tiles x 5 splits, 24 x 10: 240 CUs each, the first pair launched right behind the MLP data path whose
   // outputs it reads) the JPEG-S step is 1 % faster (13.26 -> 13.13 ms, interleaved)
   int group = rgbnm_get_option("tn_group");
-  if (group == 2 && E > 192) group = 1;
+  // (192 x 384 tiles, option tn_wide: a block's four GEMMs are 24 tiles -- one launch, 10 token splits, 240 CUs)
+  const bool wide4 = rgbnm_get_option("tn_wide") && E % 384 == 0 && I % 384 == 0 && M % 64 == 0;
+  if (group == 2 && E > 192 && !wide4) group = 1;
   if (group) { rgbnm_tn_defer_begin(); tn_open = true; }
   TRY(rgbnm_gemm_tn(dt, dy, E, a->gl, 4 * E, g->dw2, g->db2, M, E, 4 * E, 0, 0, WS(0), st));
   // du = (dy . W2) * gelu'(u) and dx_mid = dy + LN2'(du . W1) in ONE launch when eligible (mlp_fused.hip, option mlp_bwd)

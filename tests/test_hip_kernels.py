@@ -590,3 +590,14 @@ def test_gemm_tn_bf16_large_and_ragged_shapes():
     for shp in [(50176, 768, 192, 0), (50176, 192, 768, 0), (50176, 576, 192, 3), (64 * 49, 576, 192, 3),
                 (256, 1000, 192, 0), (64 * 100, 1152, 384, 6), (64 * 30, 384, 384, 0)]:
         test_gemm_tn(torch.bfloat16, *shp)
+
+
+@pytest.mark.parametrize("wide", [1, 0])
+def test_gemm_tn_bf16_wide_tiles(option, wide):
+    """Launches whose GEMMs all have No % 192 == 0 and Ki % 384 == 0 take the 192 x 384-tile kernel (tn_wide = 1, E = 384 and
+    wider): the Linears of a JPEG-S block and of SwinV2's stages 3 / 4, with the qkv row permutation, bias sums, token splits
+    (small M: many splits; one 32-token tile per split at M = 64 * 4) and accumulation -- against fp32 matmul, both settings."""
+    option("tn_wide", wide)
+    for shp in [(50176 // 4, 1152, 384, 6), (64 * 30, 384, 384, 0), (64 * 49, 1536, 384, 0), (64 * 49, 384, 1536, 0),
+                (64 * 4, 192, 384, 0), (16384, 2304, 768, 12), (64 * 20, 768, 3072, 0), (64 * 9, 3072, 768, 0)]:
+        test_gemm_tn(torch.bfloat16, *shp)

@@ -576,3 +576,33 @@ def test_bf16_gradient_edge_of_the_head():
     m.zero_grad()
     m(y, c)
     torch.cuda.synchronize()
+
+
+def test_bf16_weight_gradients_wide_and_narrow_tiles_at_e384():
+    """JPEG-S blocks (E = 384): with tn_wide the four dW GEMMs of a block run as ONE launch of 192 x 384 tiles, without it as two
+    pair launches of 128 x 192 tiles.  Same products, another grouping of the fp32 partial sums: every activation-side result
+    identical, weight gradients equal to fp32 rounding."""
+    from rgb_no_more_amd import lib as L
+    lib = L.lib()
+    B = 64
+    m, sd, _, _, _ = build("s_d2", torch.bfloat16)
+    y = torch.from_numpy(detfill.normalish((B, 1, 28, 28, 8, 8), 85)).to(DEV)
+    c = torch.from_numpy(detfill.normalish((B, 2, 14, 14, 8, 8), 86)).to(DEV)
+    old = lib.rgbnm_get_option(b"tn_wide")
+    grads = {}
+    try:
+        for mode in (0, 1):
+            L.check(lib.rgbnm_set_option(b"tn_wide", mode))
+            m.zero_grad(set_to_none=True)
+            m.train()
+            m(y, c).float().square().mean().backward()
+            grads[mode] = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()}
+    finally:
+        lib.rgbnm_set_option(b"tn_wide", old)
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert torch.isfinite(b).all()
+        rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
+        assert rel < 2e-6, (n, rel)
+        if "lrnorm" in n:
+            assert torch.equal(a, b), n
