@@ -236,7 +236,7 @@ def parity_check(arch, cdt, dev):
         y = torch.from_numpy(detfill.normalish((B, 1, 32, 32, 8, 8), 171)).to(dev)
         c = torch.from_numpy(detfill.normalish((B, 2, 16, 16, 8, 8), 172)).to(dev)
         t = detfill.uniform((B, 1000), 173, 0.0, 1.0)
-        tol = 3e-2 if bf16 else 1e-3                     # cosine attention with logit scales up to 30 (tests/test_swin.py; measured 1.9e-2)
+        tol = 2.5e-2 if bf16 else 1e-3                   # cosine attention with logit scales up to 30 (tests/test_swin.py; measured 1.9e-2)
         desc = f"reference SwinV2-T DCT, detfill weights, B={B}, drop_path 0"
     else:
         tag, emb, heads, depth, B, hard = {"vitti": ("ti_d12_b256", 192, 3, 12, 256, True),

@@ -591,6 +591,25 @@ int rgbnm_launch_tn_pipe_group(const RgbnmTnJob* jobs, int n, int* S_out, hipStr
   bool wide = rgbnm_get_option("tn_wide") != 0;
   for (int i = 0; i < n && wide; ++i) wide = jobs[i].No % 192 == 0 && jobs[i].Ki % 384 == 0 && jobs[i].M % WTK == 0;
   if (wide) {
+    // ... and the launch fills the chip with them: a job that brought a workspace for few token slices (sized by its 128 x 192
+    // tile count) may leave most CUs without a unit when its tiles get three times as large
+    auto units = [&](bool w) {
+      int tl = 0, cap = RGBNM_TN_MAX_SPLIT;
+      for (int i = 0; i < n; ++i) {
+        tl += w ? (jobs[i].No / 192) * (jobs[i].Ki / 384) : cdiv(jobs[i].No, 128) * (jobs[i].Ki / 192);
+        if (jobs[i].smax > 0 && jobs[i].smax < cap) cap = jobs[i].smax;
+      }
+      if (tl > 256) return 0;
+      int S = 256 / tl;
+      if (S > cap) S = cap;
+      const int kt = jobs[0].M / (w ? WTK : TK);
+      if (S > kt) S = kt;
+      return S * tl;
+    };
+    const int uw = units(true), un = units(false);
+    wide = uw > 0 && 4 * uw >= 3 * un;
+  }
+  if (wide) {
     static DevOnce attr_w;
     if (attr_w.need()) {
       if (hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM) != hipSuccess)

@@ -200,6 +200,15 @@ class _DwBracket:
 _ACTIVE = [None]        # the bracket of the backward pass that is running (its nodes run one after the other on one autograd thread)
 
 
+def _tn_max_splits(No, Ki):
+    """Token slices a single grouped launch can give this GEMM: 256 / its own tiles -- 192 x 384 tiles where the library uses them
+    (csrc/gemm_tn_pipe.hip, option tn_wide), else 128 x 192."""
+    t = ((No + 127) // 128) * (Ki // 192)
+    if No % 192 == 0 and Ki % 384 == 0:
+        t = min(t, (No // 192) * (Ki // 384))
+    return max(1, 256 // t)
+
+
 def _gemm_tn(dY, X, want_bias, slot=0, keep=None):
     M, No = dY.shape
     Ki = X.shape[1]
@@ -209,7 +218,7 @@ def _gemm_tn(dY, X, want_bias, slot=0, keep=None):
         hb = _HOLD[0]
         if hb is not None and hb.active and Ki % 192 == 0:
             # held: scratch of its own; a single launch splits the tokens at most 256 / its own 128 x 192 tiles ways
-            wsb = L.lib().rgbnm_gemm_tn_workspace_splits(No, Ki, max(1, 256 // (((No + 127) // 128) * (Ki // 192))))
+            wsb = L.lib().rgbnm_gemm_tn_workspace_splits(No, Ki, _tn_max_splits(No, Ki))
         else:
             wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
         ws = _ws(dY.device, wsb, slot)
@@ -217,7 +226,7 @@ def _gemm_tn(dY, X, want_bias, slot=0, keep=None):
         # launch splits the token axis 256 / (tiles of the group) ways, i.e. no further than 256 / this job's own tiles: room for
         # that many slices is all the job can use (the worst-case size pinned ~13 GB of scratch per backward)
         if Ki % 192 == 0:
-            wsb = L.lib().rgbnm_gemm_tn_workspace_splits(No, Ki, max(1, 256 // (((No + 127) // 128) * (Ki // 192))))
+            wsb = L.lib().rgbnm_gemm_tn_workspace_splits(No, Ki, _tn_max_splits(No, Ki))
         else:
             wsb = L.lib().rgbnm_gemm_tn_workspace(M, No, Ki)
         ws = torch.empty(wsb, device=dY.device, dtype=torch.uint8)

@@ -254,9 +254,9 @@ def test_swinv2t_at_batch_64_vs_reference_golden(golden, dt):
         assert abs(loss.item() - float(g[tag + "_loss"])) < 2e-5
         np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=2e-3, atol=2e-7)
     else:
-        assert err <= 3e-2                                   # (measured 1.9e-2; the bar was 6e-2 until round 4)
-        assert abs(loss.item() - float(g[tag + "_loss"])) < 5e-3
-        assert np.median(rel) < 3e-2
+        assert err <= 2.5e-2                                 # (measured 1.8e-2; the bar was 6e-2 until round 4, 3e-2 until round 6)
+        assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-3
+        assert np.median(rel) < 1e-2                         # (measured 1.4e-3)
 
 
 @pytest.mark.gpu
@@ -298,10 +298,10 @@ def test_swinv2t_at_the_timed_batch_256_vs_reference_golden(golden, dt):
         np.testing.assert_allclose(gn, g[tag + "_gradnorms"], rtol=2e-3, atol=2e-7)
         assert worst < 2e-3
     else:
-        assert err <= 3e-2
-        assert abs(loss.item() - float(g[tag + "_loss"])) < 5e-3
-        assert np.median(rel) < 3e-2
-        assert worst < 3e-2                                  # per-tensor bf16 gradient bar (measured 1.6e-2)
+        assert err <= 2.5e-2                                 # all 256 x 1000 logits (measured 1.9e-2; 3e-2 until round 6)
+        assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-3
+        assert np.median(rel) < 1e-2                         # (measured 1.5e-3)
+        assert worst < 2.5e-2                                # per-tensor bf16 gradient bar (measured 1.6e-2)
 
 
 @pytest.mark.gpu
