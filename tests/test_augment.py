@@ -230,3 +230,24 @@ def test_torange_quotient_is_exact_for_every_int16():
             x = torch.from_numpy(src).float()
             want = (-1.0 + ((x - (-1024)) / torch.full((), 2040.0)) * 2.0).to(dt)      # the fused pipeline's output cast (see the bf16 case above)
             assert got.dtype == dt and torch.equal(got.cpu(), want.reshape(got.shape)), dt
+
+
+def test_batches_beyond_one_prefix_table_equal_their_chunks():
+    """Kernel 1's cost prefix table (kernel arguments) covers 512 images; launch() loops beyond.  A batch of 600 with the sampler's
+    mix of crop sides must come out with the bits of the same images run as batches of 300."""
+    torch.manual_seed(1)
+    B = 600
+    t = CT.TrainTransform_DCT()
+    params = t.sample_params(B, 64, 64)
+    Y8, C8, q8 = synth(8, 64, 64, seed=9)
+    idx = np.arange(B) % 8
+    Y = torch.from_numpy(Y8[idx]).to(DEV)
+    Cc = torch.from_numpy(C8[idx]).to(DEV)
+    quant = torch.from_numpy(q8[idx]).to(DEV)
+    oy, oc = t(Y, Cc, quant, params=params)
+    for lo in (0, 300):
+        py, pc = t(Y[lo:lo + 300], Cc[lo:lo + 300], quant[lo:lo + 300], params=params[lo:lo + 300])
+        assert torch.equal(oy[lo:lo + 300], py) and torch.equal(oc[lo:lo + 300], pc)
+    ident = [b for b in range(64) if params[b]["box"][3] == 28][:6]            # identity-resize images: every op is exact
+    ry, rc = run_oracle(Y8[idx[ident]], C8[idx[ident]], q8[idx[ident]], [params[b] for b in ident])
+    assert np.array_equal(oy[ident].cpu().numpy(), ry) and np.array_equal(oc[ident].cpu().numpy(), rc)
