@@ -698,7 +698,9 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
                                                            const float* __restrict__ master, T* __restrict__ shadow,
                                                            float* __restrict__ bias_out, T* __restrict__ chain_fwd,
                                                            T* __restrict__ chain_bwd, int skip_chain_shadows) {
-  __shared__ float tile[32][33];
+  constexpr int TU = 2;        // tiles per turn, their loads in flight together (one tile per turn: four dependent load latencies
+                               // and two barriers per tile -- 22.9 us for 45 MB)
+  __shared__ float tile[TU][32][33];
   const rgbnm_linear_desc d = descs[blockIdx.y];
   if (bias_out && d.perm_heads > 0 && blockIdx.x < 3)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < d.N; i += 3 * 256)
@@ -717,38 +719,94 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const rgbnm_linear_de
   const int tr = (d.N + 31) / 32, tc = (d.K + 31) / 32;
   const int kind = (chain_fwd || chain_bwd) ? d.chain_kind : 0;
   const bool shadows = !(kind && skip_chain_shadows);
-  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
-    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  for (int t0 = blockIdx.x; t0 < tr * tc; t0 += TU * gridDim.x) {
+    float vv[TU][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r = r0 + ty + 8 * k, c = c0 + tx;               // r = shadow (GEMM) row
-      float v = 0.f;
-      if (r < d.N && c < d.K) {
-        const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
-        v = master[d.w_off + (size_t)src * d.K + c] + ((d.add_identity && r == c) ? 1.0f : 0.0f);
-        if (kind && chain_fwd) chain_fwd[d.chain_off + chain_fwd_pos(kind, r, c)] = from_f32<T>(v);
-        if (!shadows) {
-        } else if (d.pair) {                                     // diag(W, W): row pitch 2K, second copy at (N, K)
-          shadow[d.ws_off + (size_t)r * (2 * d.K) + c] = from_f32<T>(v);
-          shadow[d.ws_off + (size_t)(d.N + r) * (2 * d.K) + d.K + c] = from_f32<T>(v);
-        } else {
-          shadow[d.ws_off + (size_t)r * d.K + c] = from_f32<T>(v);
+    for (int u = 0; u < TU; ++u) {
+      const int t = t0 + u * gridDim.x;
+      const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;             // r = shadow (GEMM) row
+        float v = 0.f;
+        if (t < tr * tc && r < d.N && c < d.K) {
+          const int src = d.perm_heads > 0 ? qkv_row(r, d.perm_heads) : r;
+          v = master[d.w_off + (size_t)src * d.K + c];
         }
+        vv[u][k] = v;
       }
-      tile[ty + 8 * k][tx] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int t = t0 + u * gridDim.x;
+      const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (t < tr * tc && r < d.N && c < d.K) {
+          v = vv[u][k] + ((d.add_identity && r == c) ? 1.0f : 0.0f);
+          if (!shadows) {
+          } else if (d.pair) {                                   // diag(W, W): row pitch 2K, second copy at (N, K)
+            shadow[d.ws_off + (size_t)r * (2 * d.K) + c] = from_f32<T>(v);
+            shadow[d.ws_off + (size_t)(d.N + r) * (2 * d.K) + d.K + c] = from_f32<T>(v);
+          } else {
+            shadow[d.ws_off + (size_t)r * d.K + c] = from_f32<T>(v);
+          }
+        }
+        tile[u][ty + 8 * k][tx] = v;
+      }
     }
     __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+      // chain images (N, K multiples of 32): eight neighbours of the fast index lie together in both layouts (kind 2 forward:
+      // four), so threads 0 - 127 store the tile's 128 row vectors, threads 128 - 255 its 128 column vectors -- one 16-byte store
+      // per thread and image instead of four 2-byte ones (11 M scattered 2-byte stores per step were most of this kernel)
+      if (kind) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = c0 + ty + 8 * k, r = r0 + tx;
-      if (r < d.N && c < d.K) {
-        if (kind && chain_bwd) chain_bwd[d.chain_off + chain_bwd_pos(kind, c, r)] = from_f32<T>(tile[tx][ty + 8 * k]);
-        if (!shadows) {
-        } else if (d.pair) {
-          shadow[d.wst_off + (size_t)c * (2 * d.N) + r] = from_f32<T>(tile[tx][ty + 8 * k]);
-          shadow[d.wst_off + (size_t)(d.K + c) * (2 * d.N) + d.N + r] = from_f32<T>(tile[tx][ty + 8 * k]);
-        } else {
-          shadow[d.wst_off + (size_t)c * (d.ldn > 0 ? d.ldn : d.N) + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+        for (int u = 0; u < TU; ++u) {
+          const int t = t0 + u * gridDim.x;
+          if (t >= tr * tc) break;
+          const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+          const int id = threadIdx.x & 127, a = id >> 2, g8 = (id & 3) * 8;
+          typedef T vec8 __attribute__((ext_vector_type(8)));
+          typedef T vec4 __attribute__((ext_vector_type(4)));
+          vec8 o;
+          if (threadIdx.x < 128) {
+            if (chain_fwd) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) o[i] = from_f32<T>(tile[u][a][g8 + i]);
+              if (kind == 2) {
+                *reinterpret_cast<vec4*>(chain_fwd + d.chain_off + chain_fwd_pos(kind, r0 + a, c0 + g8)) = vec4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<vec4*>(chain_fwd + d.chain_off + chain_fwd_pos(kind, r0 + a, c0 + g8 + 4)) = vec4{o[4], o[5], o[6], o[7]};
+              } else {
+                *reinterpret_cast<vec8*>(chain_fwd + d.chain_off + chain_fwd_pos(kind, r0 + a, c0 + g8)) = o;
+              }
+            }
+          } else if (chain_bwd) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = from_f32<T>(tile[u][g8 + i][a]);
+            *reinterpret_cast<vec8*>(chain_bwd + d.chain_off + chain_bwd_pos(kind, c0 + a, r0 + g8)) = o;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int t = t0 + u * gridDim.x;
+      if (t >= tr * tc) break;
+      const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < d.N && c < d.K) {
+          if (!shadows) {
+          } else if (d.pair) {
+            shadow[d.wst_off + (size_t)c * (2 * d.N) + r] = from_f32<T>(tile[u][tx][ty + 8 * k]);
+            shadow[d.wst_off + (size_t)(d.K + c) * (2 * d.N) + d.N + r] = from_f32<T>(tile[u][tx][ty + 8 * k]);
+          } else {
+            shadow[d.wst_off + (size_t)c * (d.ldn > 0 ? d.ldn : d.N) + r] = from_f32<T>(tile[u][tx][ty + 8 * k]);
+          }
         }
       }
     }
