@@ -169,31 +169,64 @@ __global__ __launch_bounds__(256) void softxent_loss_kernel(const float* __restr
                                                             float* __restrict__ stat, float* __restrict__ loss,
                                                             unsigned* __restrict__ ticket, int C) {
   __shared__ float red[4];
+  __shared__ float red3[4][3];
   __shared__ int last_s;
   const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* z = logits + (size_t)b * C;
   const long long lab = hard ? hard[b] : -1;
   float m = -INFINITY;
-  for (int c = tid; c < C; c += 256) m = fmaxf(m, z[c]);
-  m = wave_max(m);
-  if (lane == 0) red[w] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float se = 0.f, st = 0.f, stz = 0.f;
-  for (int c = tid; c < C; c += 256) {
-    const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
-    se += __expf(z[c] - m);
-    st += t;
-    stz += t * z[c];
-  }
-  float vals[3] = {se, st, stz};
-  for (int k = 0; k < 3; ++k) {
-    const float v = wave_sum(vals[k]);
-    if (lane == 0) red[w] = v;
+  float vals[3];
+  if (C <= 1024) {
+    // the row (and its target) in registers: one round of loads, all in flight together, instead of two dependent passes; the three
+    // sums share one pair of barriers.  Same per-thread order, same wave sums, same order of the four partials: the same bits.
+    float zr[4], tr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + 256 * k;
+      zr[k] = c < C ? z[c] : -INFINITY;
+      tr[k] = c < C ? (hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c]) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = fmaxf(m, zr[k]);
+    m = wave_max(m);
+    if (lane == 0) red[w] = m;
     __syncthreads();
-    vals[k] = red[0] + red[1] + red[2] + red[3];
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f, st = 0.f, stz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (tid + 256 * k < C) {
+        se += __expf(zr[k] - m);
+        st += tr[k];
+        stz += tr[k] * zr[k];
+      }
+    se = wave_sum(se); st = wave_sum(st); stz = wave_sum(stz);
+    if (lane == 0) { red3[w][0] = se; red3[w][1] = st; red3[w][2] = stz; }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vals[k] = red3[0][k] + red3[1][k] + red3[2][k] + red3[3][k];
+  } else {
+    for (int c = tid; c < C; c += 256) m = fmaxf(m, z[c]);
+    m = wave_max(m);
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.f, st = 0.f, stz = 0.f;
+    for (int c = tid; c < C; c += 256) {
+      const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+      se += __expf(z[c] - m);
+      st += t;
+      stz += t * z[c];
+    }
+    vals[0] = se; vals[1] = st; vals[2] = stz;
+    for (int k = 0; k < 3; ++k) {
+      const float v = wave_sum(vals[k]);
+      if (lane == 0) red[w] = v;
+      __syncthreads();
+      vals[k] = red[0] + red[1] + red[2] + red[3];
+      __syncthreads();
+    }
   }
   const float lse = m + __logf(vals[0]);
   if (tid == 0) {
@@ -278,9 +311,19 @@ constexpr int NORM_BLOCKS = 256;
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
   __shared__ float red[4];
   float a = 0.f;
-  for (long long i = (blockIdx.x * 256LL + threadIdx.x) * 4; i < n; i += (long long)NORM_BLOCKS * 256 * 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);   // n is a multiple of 256 (padded segments)
-    a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  // four strides per turn with their loads issued together (one workgroup per CU: a load per turn was 22 exposed latencies);
+  // the terms are still added in ascending order: the same bits
+  constexpr long long STRIDE = (long long)NORM_BLOCKS * 256 * 4;
+  for (long long i = (blockIdx.x * 256LL + threadIdx.x) * 4; i < n; i += 4 * STRIDE) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long j = i + u * STRIDE;
+      v[u] = j < n ? *reinterpret_cast<const f32x4*>(g + j) : f32x4{0.f, 0.f, 0.f, 0.f};   // n is a multiple of 256 (padded segments)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * STRIDE < n) a += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
   }
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
