@@ -169,64 +169,31 @@ __global__ __launch_bounds__(256) void softxent_loss_kernel(const float* __restr
                                                             float* __restrict__ stat, float* __restrict__ loss,
                                                             unsigned* __restrict__ ticket, int C) {
   __shared__ float red[4];
-  __shared__ float red3[4][3];
   __shared__ int last_s;
   const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* z = logits + (size_t)b * C;
   const long long lab = hard ? hard[b] : -1;
   float m = -INFINITY;
-  float vals[3];
-  if (C <= 1024) {
-    // the row (and its target) in registers: one round of loads, all in flight together, instead of two dependent passes; the three
-    // sums share one pair of barriers.  Same per-thread order, same wave sums, same order of the four partials: the same bits.
-    float zr[4], tr[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = tid + 256 * k;
-      zr[k] = c < C ? z[c] : -INFINITY;
-      tr[k] = c < C ? (hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c]) : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) m = fmaxf(m, zr[k]);
-    m = wave_max(m);
-    if (lane == 0) red[w] = m;
+  for (int c = tid; c < C; c += 256) m = fmaxf(m, z[c]);
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f, st = 0.f, stz = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+    se += __expf(z[c] - m);
+    st += t;
+    stz += t * z[c];
+  }
+  float vals[3] = {se, st, stz};
+  for (int k = 0; k < 3; ++k) {
+    const float v = wave_sum(vals[k]);
+    if (lane == 0) red[w] = v;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float se = 0.f, st = 0.f, stz = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (tid + 256 * k < C) {
-        se += __expf(zr[k] - m);
-        st += tr[k];
-        stz += tr[k] * zr[k];
-      }
-    se = wave_sum(se); st = wave_sum(st); stz = wave_sum(stz);
-    if (lane == 0) { red3[w][0] = se; red3[w][1] = st; red3[w][2] = stz; }
+    vals[k] = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 3; ++k) vals[k] = red3[0][k] + red3[1][k] + red3[2][k] + red3[3][k];
-  } else {
-    for (int c = tid; c < C; c += 256) m = fmaxf(m, z[c]);
-    m = wave_max(m);
-    if (lane == 0) red[w] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float se = 0.f, st = 0.f, stz = 0.f;
-    for (int c = tid; c < C; c += 256) {
-      const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
-      se += __expf(z[c] - m);
-      st += t;
-      stz += t * z[c];
-    }
-    vals[0] = se; vals[1] = st; vals[2] = stz;
-    for (int k = 0; k < 3; ++k) {
-      const float v = wave_sum(vals[k]);
-      if (lane == 0) red[w] = v;
-      __syncthreads();
-      vals[k] = red[0] + red[1] + red[2] + red[3];
-      __syncthreads();
-    }
   }
   const float lse = m + __logf(vals[0]);
   if (tid == 0) {
