@@ -449,6 +449,8 @@ def main():
     # the ViT mixes the batch while its sub-block kernel loads it (cls_transforms.LazyMixed: same bits, the mixed batch never
     # exists in memory); needs the augment stage's output in the compute dtype (it is) -- SwinV2 mixes the ordinary way
     mix.lazy = (not swin) and not a.no_augment and os.environ.get("RGBNM_BENCH_LAZY_MIX", "1") == "1"
+    # ... and the loss mixes the target where it reads it (cls_transforms.LazyTarget: labels + lambda; same bits, no mixup_target launch)
+    mix.lazy_target = os.environ.get("RGBNM_BENCH_LAZY_TARGET", "1") == "1"
     B = a.batch
     lab = torch.randint(0, 999, (B,), device=dev)
     S = 32 if swin else 28
@@ -470,7 +472,10 @@ def main():
             y, c = CT.apply_packed(aug, Yq, Cq, quant, packed, nops, out=out[:2] if (out is not None and mix.lazy) else None)
         if mix.lazy:
             lam = mix.sample_lambda(lab.device, out=None if out is None else out[3])
-            return mix((y, c), lab, lam=lam, out=None if out is None else (None, None, out[2]))
+            return mix((y, c), lab, lam=lam, out=None if out is None else (None, None, None if mix.lazy_target else out[2]))
+        if mix.lazy_target:
+            lam = mix.sample_lambda(lab.device, out=None if out is None else out[3])
+            return mix((y, c), lab, lam=lam, out=None if out is None else (out[0], out[1], None))
         return mix((y, c), lab, out=None if out is None else out[:3])
 
     def model_part(my, mc, mt):
@@ -500,6 +505,8 @@ def main():
             data_part(out=static)
             if mix.lazy:
                 sy, sc = rg.cls_transforms.LazyMixed(sy, slam), rg.cls_transforms.LazyMixed(sc, slam)
+            if mix.lazy_target:         # the captured loss reads the labels and the lambda the data stage refreshes in place
+                smt = rg.cls_transforms.LazyTarget(lab, slam, 1000)
             if swin:
                 # DropPath draws new masks in every pass (captured Philox offsets advance with the replays), so a train-mode replay
                 # cannot be compared bit for bit.  The capture is therefore validated FIRST with DropPath off (eval mode: same ~600

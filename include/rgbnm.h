@@ -292,6 +292,15 @@ int rgbnm_softxent_loss(const float* logits, const float* soft_target, const lon
                         float* row_stats, float* loss, unsigned* ticket, int B, int C, void* stream);
 int rgbnm_softxent_grad(int dl_dtype, const float* logits, const float* soft_target, const long long* hard_target,
                         const float* row_stats, const float* gout_dev, void* dlogits, int B, int C, float grad_scale, void* stream);
+/* The same two launches on the target RandomMixup_DCT would have built (cls_transforms.py:163-176: one-hot labels, rolled by one, mixed
+ * with lam): target[b][c] = (labels[b] == c ? lam[0] : 0) + (labels[b-1] == c ? lam[1] : 0) is evaluated where it is used, the
+ * dense [B, C] target and the launch that writes it do not exist (cls_transforms.LazyTarget).  Same bits as rgbnm_mixup_target
+ * followed by rgbnm_softxent_loss / _grad on its output. */
+int rgbnm_softxent_loss_mix(const float* logits, const long long* labels, const float* mix_lam_dev, float* loss_rows,
+                            float* row_stats, float* loss, unsigned* ticket, int B, int C, void* stream);
+int rgbnm_softxent_grad_mix(int dl_dtype, const float* logits, const long long* labels, const float* mix_lam_dev,
+                            const float* row_stats, const float* gout_dev, void* dlogits, int B, int C, float grad_scale,
+                            void* stream);
 /* RandomMixup_DCT (cls_transforms.py:163-176): out[b] = lam[0]*in[b] + lam[1]*in[b-1]; lam on device. */
 int rgbnm_mixup(int in_dtype, int out_dtype, const void* in, void* out, const float* lam_dev, int B,
                 long long per_sample, void* stream);

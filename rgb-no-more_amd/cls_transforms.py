@@ -39,6 +39,33 @@ class LazyMixed:
         return o
 
 
+class LazyTarget:
+    """The target RandomMixup_DCT would have built -- one-hot labels, rolled by one, mixed with lambda -- as (labels, lambda): a
+    `cross_entropy` of this package evaluates target[b][c] = (labels[b] == c) * lam[0] + (labels[b-1] == c) * lam[1] where it uses
+    it (rgbnm_softxent_loss_mix / _grad_mix: the same bits), so the dense [B, num_classes] tensor and the launch that writes it
+    do not exist.  .materialize() gives the dense tensor to anybody else."""
+
+    def __init__(self, labels, lam, num_classes):
+        self.labels, self.lam, self.num_classes = labels, lam, num_classes
+
+    @property
+    def shape(self):
+        return torch.Size((self.labels.shape[0], self.num_classes))
+
+    @property
+    def device(self):
+        return self.labels.device
+
+    dtype = torch.float32
+
+    def materialize(self, out=None):
+        B = self.labels.shape[0]
+        tgt = torch.empty(B, self.num_classes, device=self.labels.device, dtype=torch.float32) if out is None else out
+        L.check(L.lib().rgbnm_mixup_target(self.labels.data_ptr(), tgt.data_ptr(), self.lam.data_ptr(), B, self.num_classes,
+                                           L.stream()), "mixup_target")
+        return tgt
+
+
 class RandomMixup_DCT(torch.nn.Module):
     """Roll-by-one batch mixup of (Y, CbCr) and labels; lambda ~ Dirichlet(alpha, alpha) sorted descending
     (cls_transforms.py:135-182).  As in the reference (:168) lambda is drawn on the HOST from torch's CPU generator -- the same
@@ -57,6 +84,9 @@ class RandomMixup_DCT(torch.nn.Module):
         # lazy = True: the batch items come back as LazyMixed (un-mixed tensor + lambda) for a rgb-no-more_amd model to mix while
         # it loads them -- same bits, two launches and one round trip of the batch less per step; the target is mixed at once
         self.lazy = False
+        # lazy_target = True: the target comes back as LazyTarget (labels + lambda) for this package's cross_entropy to mix where it
+        # reads it -- same bits, one launch and the dense [B, num_classes] tensor less per step
+        self.lazy_target = False
 
     def draw_lambda(self):
         """The reference's own draw on the CPU generator (cls_transforms.py:168): (lambda, 1 - lambda) sorted descending, fp32."""
@@ -114,6 +144,8 @@ class RandomMixup_DCT(torch.nn.Module):
             L.check(L.lib().rgbnm_mixup(L.dt_of(t.dtype), L.dt_of(od), t.data_ptr(), o.data_ptr(), lam.data_ptr(), B,
                                         t.numel() // B, L.stream()), "mixup")
             outs.append(o)
+        if self.lazy_target and (out is None or out[-1] is None):
+            return (outs[0] if single else tuple(outs)), LazyTarget(target, lam, self.num_classes)
         tgt = torch.empty(target.shape[0], self.num_classes, device=target.device, dtype=torch.float32) if out is None else out[-1]
         if tgt.shape != (target.shape[0], self.num_classes) or tgt.dtype != torch.float32 or not tgt.is_contiguous():
             raise ValueError("the out tensor of the target must be float32 [B, num_classes]")
@@ -142,31 +174,43 @@ class _SoftXent(torch.autograd.Function):
     gets its bf16 dlogits without the fp32 round trip autograd's dtype check would force on a gradient of fp32 logits."""
 
     @staticmethod
-    def forward(ctx, edge, logits, target):
+    def forward(ctx, edge, logits, target, mixlam=None):
         B, Cn = logits.shape
         hard = target.dtype == torch.int64
         rows = torch.empty(B, device=logits.device, dtype=torch.float32)
         stat = torch.empty(2 * B, device=logits.device, dtype=torch.float32)
         loss = torch.empty(1, device=logits.device, dtype=torch.float32)
-        L.check(L.lib().rgbnm_softxent_loss(logits.data_ptr(), None if hard else target.data_ptr(),
-                                            target.data_ptr() if hard else None, rows.data_ptr(), stat.data_ptr(),
-                                            loss.data_ptr(), _ticket(logits.device).data_ptr(), B, Cn, L.stream()), "softxent_loss")
-        ctx.save_for_backward(logits, target, stat)
+        if mixlam is not None:          # LazyTarget: labels + lambda, the mixed target built where it is read
+            L.check(L.lib().rgbnm_softxent_loss_mix(logits.data_ptr(), target.data_ptr(), mixlam.data_ptr(), rows.data_ptr(),
+                                                    stat.data_ptr(), loss.data_ptr(), _ticket(logits.device).data_ptr(), B, Cn,
+                                                    L.stream()), "softxent_loss_mix")
+            ctx.save_for_backward(logits, target, stat, mixlam)
+        else:
+            L.check(L.lib().rgbnm_softxent_loss(logits.data_ptr(), None if hard else target.data_ptr(),
+                                                target.data_ptr() if hard else None, rows.data_ptr(), stat.data_ptr(),
+                                                loss.data_ptr(), _ticket(logits.device).data_ptr(), B, Cn, L.stream()), "softxent_loss")
+            ctx.save_for_backward(logits, target, stat)
         ctx.dl_dtype = edge.dtype
         return loss[0]
 
     @staticmethod
     def backward(ctx, gout):
-        logits, target, stat = ctx.saved_tensors
+        logits, target, stat = ctx.saved_tensors[:3]
+        mixlam = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
         B, Cn = logits.shape
         hard = target.dtype == torch.int64
         dl = torch.empty(B, Cn, device=logits.device, dtype=ctx.dl_dtype)
         if gout.dtype != torch.float32 or not gout.is_cuda:
             gout = gout.to(device=logits.device, dtype=torch.float32)
-        L.check(L.lib().rgbnm_softxent_grad(L.dt_of(ctx.dl_dtype), logits.data_ptr(), None if hard else target.data_ptr(),
-                                            target.data_ptr() if hard else None, stat.data_ptr(), gout.data_ptr(), dl.data_ptr(),
-                                            B, Cn, 1.0 / B, L.stream()), "softxent_grad")
-        return dl, None, None
+        if mixlam is not None:
+            L.check(L.lib().rgbnm_softxent_grad_mix(L.dt_of(ctx.dl_dtype), logits.data_ptr(), target.data_ptr(), mixlam.data_ptr(),
+                                                    stat.data_ptr(), gout.data_ptr(), dl.data_ptr(), B, Cn, 1.0 / B, L.stream()),
+                    "softxent_grad_mix")
+        else:
+            L.check(L.lib().rgbnm_softxent_grad(L.dt_of(ctx.dl_dtype), logits.data_ptr(), None if hard else target.data_ptr(),
+                                                target.data_ptr() if hard else None, stat.data_ptr(), gout.data_ptr(), dl.data_ptr(),
+                                                B, Cn, 1.0 / B, L.stream()), "softxent_grad")
+        return dl, None, None, None
 
 
 def cross_entropy(logits: Tensor, target: Tensor, grad_dtype=torch.float32) -> Tensor:
@@ -174,6 +218,12 @@ def cross_entropy(logits: Tensor, target: Tensor, grad_dtype=torch.float32) -> T
     targets, mean reduction: one HIP launch forward, one backward.  grad_dtype: the dtype the model's head wants its dlogits
     in; honoured when `logits` come from a rgb-no-more_amd head that handed out a gradient edge of that dtype (fp32 logits keep an
     fp32 gradient otherwise, as autograd demands)."""
+    mixlam = None
+    if isinstance(target, LazyTarget):          # RandomMixup_DCT(lazy_target=True): labels + lambda
+        if target.num_classes != logits.shape[1]:
+            raise ValueError(f"LazyTarget for {target.num_classes} classes, logits have {logits.shape[1]}")
+        target, mixlam = target.labels, target.lam
+        L.require_cuda(mixlam)
     L.require_cuda(logits, target)
     edge = getattr(logits, "_rgbnm_grad_edge", None)
     if logits.dtype != torch.float32:
@@ -183,4 +233,4 @@ def cross_entropy(logits: Tensor, target: Tensor, grad_dtype=torch.float32) -> T
     logits = logits.contiguous()
     if edge is None or edge.dtype != grad_dtype or edge.shape != logits.shape or not edge.requires_grad:
         edge = logits
-    return _SoftXent.apply(edge, logits.detach(), target)
+    return _SoftXent.apply(edge, logits.detach(), target, mixlam)

@@ -167,12 +167,17 @@ __global__ __launch_bounds__(256) void softxent_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void softxent_loss_kernel(const float* __restrict__ logits, const float* __restrict__ soft,
                                                             const long long* __restrict__ hard, float* __restrict__ rows,
                                                             float* __restrict__ stat, float* __restrict__ loss,
-                                                            unsigned* __restrict__ ticket, int C) {
+                                                            unsigned* __restrict__ ticket, int C,
+                                                            const float* __restrict__ mixlam = nullptr) {
   __shared__ float red[4];
   __shared__ int last_s;
   const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* z = logits + (size_t)b * C;
   const long long lab = hard ? hard[b] : -1;
+  // mixlam (with hard labels): the roll-by-one mixup target of cls_transforms.RandomMixup_DCT built on the fly -- the expression of
+  // mixup_target_kernel, so the dense [B, C] target never exists (LazyTarget)
+  const long long lab2 = (hard && mixlam) ? hard[(b + B - 1) % B] : -1;
+  const float l0 = mixlam ? mixlam[0] : 1.f, l1 = mixlam ? mixlam[1] : 0.f;
   float m = -INFINITY;
   for (int c = tid; c < C; c += 256) m = fmaxf(m, z[c]);
   m = wave_max(m);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void softxent_loss_kernel(const float* __restr
   __syncthreads();
   float se = 0.f, st = 0.f, stz = 0.f;
   for (int c = tid; c < C; c += 256) {
-    const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+    const float t = hard ? (mixlam ? (c == lab ? l0 : 0.f) + (c == lab2 ? l1 : 0.f) : (c == lab ? 1.f : 0.f)) : soft[(size_t)b * C + c];
     se += __expf(z[c] - m);
     st += t;
     stz += t * z[c];
@@ -220,14 +225,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void softxent_grad_kernel(const float* __restrict__ logits, const float* __restrict__ soft,
                                                             const long long* __restrict__ hard, const float* __restrict__ stat,
                                                             const float* __restrict__ gout, T* __restrict__ dlogits, int C,
-                                                            float gscale) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+                                                            float gscale, const float* __restrict__ mixlam = nullptr) {
+  const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
   const float* z = logits + (size_t)b * C;
   const long long lab = hard ? hard[b] : -1;
+  const long long lab2 = (hard && mixlam) ? hard[(b + B - 1) % B] : -1;
+  const float l0 = mixlam ? mixlam[0] : 1.f, l1 = mixlam ? mixlam[1] : 0.f;
   const float lse = stat[2 * b], sumt = stat[2 * b + 1];
   const float g = gout ? gscale * gout[0] : gscale;
   for (int c = tid; c < C; c += 256) {
-    const float t = hard ? (c == lab ? 1.f : 0.f) : soft[(size_t)b * C + c];
+    const float t = hard ? (mixlam ? (c == lab ? l0 : 0.f) + (c == lab2 ? l1 : 0.f) : (c == lab ? 1.f : 0.f)) : soft[(size_t)b * C + c];
     dlogits[(size_t)b * C + c] = from_f32<T>((__expf(z[c] - lse) * sumt - t) * g);
   }
 }
@@ -398,6 +405,28 @@ int rgbnm_softxent_grad(int dl_dtype, const float* logits, const float* soft_tar
     hipLaunchKernelGGL((softxent_grad_kernel<bf16>), dim3(B), dim3(256), 0, st, logits, soft_target, hard_target, row_stats, gout_dev, (bf16*)dlogits, C, grad_scale);
   else if (dl_dtype == DT_F32)
     hipLaunchKernelGGL((softxent_grad_kernel<float>), dim3(B), dim3(256), 0, st, logits, soft_target, hard_target, row_stats, gout_dev, (float*)dlogits, C, grad_scale);
+  else return RGBNM_EINVAL;
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_softxent_loss_mix(const float* logits, const long long* labels, const float* mix_lam, float* loss_rows, float* row_stats,
+                            float* loss, unsigned* ticket, int B, int C, void* stream) {
+  if (!logits || !labels || !mix_lam || !loss_rows || !row_stats || !loss || !ticket || B <= 0 || C <= 0) return RGBNM_EINVAL;
+  hipLaunchKernelGGL(softxent_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, (const float*)nullptr, labels, loss_rows,
+                     row_stats, loss, ticket, C, mix_lam);
+  LAUNCH_CHECK();
+  return RGBNM_OK;
+}
+
+int rgbnm_softxent_grad_mix(int dl_dtype, const float* logits, const long long* labels, const float* mix_lam, const float* row_stats,
+                            const float* gout_dev, void* dlogits, int B, int C, float grad_scale, void* stream) {
+  if (!logits || !labels || !mix_lam || !row_stats || !dlogits || B <= 0 || C <= 0) return RGBNM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dl_dtype == DT_BF16)
+    hipLaunchKernelGGL((softxent_grad_kernel<bf16>), dim3(B), dim3(256), 0, st, logits, (const float*)nullptr, labels, row_stats, gout_dev, (bf16*)dlogits, C, grad_scale, mix_lam);
+  else if (dl_dtype == DT_F32)
+    hipLaunchKernelGGL((softxent_grad_kernel<float>), dim3(B), dim3(256), 0, st, logits, (const float*)nullptr, labels, row_stats, gout_dev, (float*)dlogits, C, grad_scale, mix_lam);
   else return RGBNM_EINVAL;
   LAUNCH_CHECK();
   return RGBNM_OK;

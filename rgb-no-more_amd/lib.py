@@ -117,6 +117,8 @@ PROTOTYPES = {
     "rgbnm_softxent": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "rgbnm_softxent_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "rgbnm_softxent_grad": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "rgbnm_softxent_loss_mix": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "rgbnm_softxent_grad_mix": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "rgbnm_mixup": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _vp]),
     "rgbnm_mixup_target": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "rgbnm_clip_adamw_wd_workspace": (_sz, []),

@@ -601,3 +601,35 @@ def test_gemm_tn_bf16_wide_tiles(option, wide):
     for shp in [(50176 // 4, 1152, 384, 6), (64 * 30, 384, 384, 0), (64 * 49, 1536, 384, 0), (64 * 49, 384, 1536, 0),
                 (64 * 4, 192, 384, 0), (16384, 2304, 768, 12), (64 * 20, 768, 3072, 0), (64 * 9, 3072, 768, 0)]:
         test_gemm_tn(torch.bfloat16, *shp)
+
+
+def test_lazy_mixup_target_has_the_bits_of_the_dense_one():
+    """RandomMixup_DCT(lazy_target=True) hands cross_entropy the labels and lambda (cls_transforms.LazyTarget) instead of the dense
+    [B, classes] target: loss, the gradient of the logits (fp32 and through a bf16 head edge's dtype) and the materialised target must
+    be the bits of the dense path -- rgbnm_mixup_target followed by rgbnm_softxent_loss / _grad."""
+    from rgb_no_more_amd import cls_transforms as CL
+    B, Cn = 256, 1000
+    lab = torch.from_numpy(detfill.integers((B,), 61, 0, Cn - 1, np.int64)).to(DEV)
+    lab[7] = lab[6]                                        # a row whose partner has the same label: target mass lam0 + lam1 on one class
+    z = dev(detfill.normalish((B, Cn), 62) * 3)
+    y = dev(detfill.normalish((B, 1, 4, 4, 8, 8), 63))
+    for lam_v in ((0.7, 0.3), (1.0, 0.0), (0.5, 0.5)):
+        lam = torch.tensor(lam_v, device=DEV, dtype=torch.float32)
+        mix = CL.RandomMixup_DCT(Cn, alpha=0.2)
+        (yd,), td = mix((y,), lab, lam=lam)
+        mix.lazy_target = True
+        (yl,), tl = mix((y,), lab, lam=lam)
+        assert isinstance(tl, CL.LazyTarget) and tuple(tl.shape) == (B, Cn) and torch.equal(yd, yl)
+        assert torch.equal(tl.materialize(), td)
+        for gd in (torch.float32, torch.bfloat16):
+            res = []
+            for tgt in (td, tl):
+                zz = z.clone().requires_grad_(True)
+                loss = CL.cross_entropy(zz, tgt, grad_dtype=gd)
+                (loss * 3.0).backward()
+                res.append((loss.detach().clone(), zz.grad.clone()))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (lam_v, gd)
+        ref = torch.nn.functional.cross_entropy(z, td)
+        assert abs(float(res[1][0]) - float(ref)) < 1e-5
+    with pytest.raises(ValueError):
+        CL.cross_entropy(z[:, :10].contiguous(), tl)
