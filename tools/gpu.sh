@@ -20,6 +20,7 @@
 # Stand-alone probes (run them directly on the box):  tools/nt384_probe.py E [out|-] M [opt=val]   activation GEMMs of a block vs the library GEMM
 #   tools/tn_probe.py E M [opt=val]          weight-gradient GEMMs of a block      tools/winattn_probe.py [B] [out|-] [opt=val]   window attention per stage
 #   tools/winattn_prof.py [shift] [fwd]      cycle stamps inside the window-attention kernels (build with RGBNM_HIPCC_FLAGS=-DWIN_PROF[=2])
+#   tools/aug_prof.py                        per-wave cycle stamps of the two augment kernels on the bench's data stage (build with RGBNM_HIPCC_FLAGS=-DAUG_PROF)
 export TMPDIR=/tmp
 CMD=$1; shift
 line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('$1', d['value'], d['ms_per_step'], r.get('avg_launch_us'), (d.get('parity_check') or {}).get('max_abs_dlogit'), 'host', d.get('host_ms_per_step'), 'blocked', d.get('host_blocked_on_rings_ms_per_step'), d.get('host_cpu'))"; }
