@@ -633,3 +633,29 @@ def test_lazy_mixup_target_has_the_bits_of_the_dense_one():
         assert abs(float(res[1][0]) - float(ref)) < 1e-5
     with pytest.raises(ValueError):
         CL.cross_entropy(z[:, :10].contiguous(), tl)
+
+
+def test_gemm_tn_wide_tiles_repeatable():
+    """The 192 x 384-tile kernel hand-counts its DMA waits over tiles of 4 and 5 instructions per wave (nine per two tiles); a
+    miscounted wait would read a tile before it has landed -- visible as run-to-run differences.  Thirty launches of a split and of
+    an unsplit shape must give the same bits, next to other traffic on the device."""
+    lib = L.lib()
+    for (M, No, Ki) in [(64 * 49, 1536, 384), (50176 // 2, 384, 1536)]:
+        dY = dev(detfill.normalish((M, No), 71), torch.bfloat16)
+        X = dev(detfill.normalish((M, Ki), 72), torch.bfloat16)
+        wsb = lib.rgbnm_gemm_tn_workspace(M, No, Ki)
+        ws = torch.empty(wsb, device=DEV, dtype=torch.uint8)
+        noise = torch.randn(64 << 20, device=DEV)
+        first = None
+        for rep in range(30):
+            dW = torch.empty(No, Ki, device=DEV)
+            db = torch.empty(No, device=DEV)
+            noise.mul_(1.0001)                              # something else in flight in front of every launch
+            L.check(lib.rgbnm_gemm_tn(L.dt_of(torch.bfloat16), dY.data_ptr(), No, X.data_ptr(), Ki, dW.data_ptr(), db.data_ptr(), M, No,
+                                      Ki, 0, 0, ws.data_ptr(), wsb, L.stream()))
+            if first is None:
+                first = (dW.clone(), db.clone())
+                ref = dY.float().T @ X.float()
+                assert relerr(dW, ref) < 1e-5
+            else:
+                assert torch.equal(dW, first[0]) and torch.equal(db, first[1]), rep
