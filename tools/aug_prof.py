@@ -26,7 +26,6 @@ f.argtypes = [C.c_void_p]
 f2 = lib.rgbnm_debug_aug_prof2
 f2.restype = C.c_int
 f2.argtypes = [C.c_void_p]
-OPN = {}
 rows = []
 for it in range(12):
     packed, nops = sampler.sample(B, 64, 64)
@@ -67,7 +66,6 @@ for it in range(12):
     ld, o1, o2, stt, tot = q[:, :, 1] - q[:, :, 0], q[:, :, 2] - q[:, :, 1], q[:, :, 3] - q[:, :, 2], q[:, :, 4] - q[:, :, 3], q[:, :, 4] - q[:, :, 0]
     print(f"   kernel 2 (per wave, cycles): load+sync mean {ld.mean():.0f} max {ld.max()}; op slot 0 mean {o1.mean():.0f} max {o1.max()}; op slot 1 mean {o2.mean():.0f} max {o2.max()}; "
           f"ToRange+store mean {stt.mean():.0f} max {stt.max()}; wave life mean {tot.mean():.0f} p95 {np.percentile(tot, 95):.0f} max {tot.max()}")
-    ops = q[:, 0, 5]
     byop = {}
     for b in range(256):
         byop.setdefault(int(q[b, 0, 5]), []).append(o1[b].max())
